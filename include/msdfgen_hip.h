@@ -1,0 +1,176 @@
+/*
+ * msdfgen_hip.h -- C ABI of the MI355X-native MSDF hot path (libmsdfgen_hip.so).
+ *
+ * Drop-in boundary for the per-texel signed-distance path of Chlumsky/msdfgen v1.13.0.  Each entry point names the
+ * reference interface it replaces (file:line relative to the reference tree).  Plain pointers and sizes only.
+ *
+ * Shape encoding (the reference's `const Shape &`, core/Shape.h:15-58, flattened once by the caller/binding):
+ *   contour_offsets int32[n_contours+1]  CSR offsets into the edge arrays; edges of a contour in Shape order
+ *   points          double[n_edges*8]    p0x,p0y,p1x,p1y,p2x,p2y,p3x,p3y (unused slots ignored)
+ *   types           uint8[n_edges]       1 linear, 2 quadratic, 3 cubic       (EDGE_TYPE, core/edge-segments.h:62,91,122)
+ *   colors          uint8[n_edges]       EdgeColor bitmask R=1 G=2 B=4        (core/EdgeColor.h:9-18)
+ *
+ * Transformation (the reference's `const SDFTransformation &`, core/SDFTransformation.h:13-24):
+ *   xf[6] = { Projection.scale.x, .scale.y, .translate.x, .translate.y,      (core/Projection.h:31-33)
+ *             DistanceMapping.scale, DistanceMapping.translate }             (core/DistanceMapping.h:28-30)
+ *   i.e. texel centre (x+.5, y+.5) -> shape point  coord/scale - translate  (core/Projection.cpp:14-16)
+ *        distance d -> float(mapScale*(d+mapTranslate))                      (core/DistanceMapping.cpp:15-17)
+ *
+ * Output bitmap (the reference's `const BitmapSection<float, N> &`, core/BitmapRef.hpp:74-111):
+ *   pixels, width, height, row_stride (in floats, may be negative), channel-interleaved.
+ *   `flip` != 0 when shape.getYAxisOrientation() != bitmap.yOrientation: rows are then written in reverse
+ *   (BitmapSection::reorient, core/BitmapRef.hpp:103-109).
+ *
+ * All functions return MSDFHIP_OK (0) or a negative MSDFHIP_ERR_* code; msdfhip_last_error() gives the text.
+ * There is NO CPU fallback: without a usable gfx950 device every compute entry point fails with MSDFHIP_ERR_NO_DEVICE.
+ * Thread safety: all entry points may be called concurrently from many host threads (the reference's generate* functions
+ * are re-entrant); host-pointer calls use a per-thread stream and staging buffers.
+ */
+#ifndef MSDFGEN_HIP_H
+#define MSDFGEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSDFHIP_ABI_VERSION 1
+
+/* mode: which generator (msdfgen.h:46-56) */
+#define MSDFHIP_MODE_SDF   1 /* generateSDF   msdfgen.h:47  (TrueDistanceSelector)          1 channel  */
+#define MSDFHIP_MODE_PSDF  2 /* generatePSDF  msdfgen.h:49  (PerpendicularDistanceSelector) 1 channel  */
+#define MSDFHIP_MODE_MSDF  3 /* generateMSDF  msdfgen.h:51  (MultiDistanceSelector)         3 channels */
+#define MSDFHIP_MODE_MTSDF 4 /* generateMTSDF msdfgen.h:53  (MultiAndTrueDistanceSelector)  4 channels */
+
+/* ErrorCorrectionConfig::Mode, core/generator-config.h:20-29 */
+#define MSDFHIP_EC_DISABLED       0
+#define MSDFHIP_EC_INDISCRIMINATE 1
+#define MSDFHIP_EC_EDGE_PRIORITY  2
+#define MSDFHIP_EC_EDGE_ONLY      3
+/* ErrorCorrectionConfig::DistanceCheckMode, core/generator-config.h:31-38 */
+#define MSDFHIP_DO_NOT_CHECK_DISTANCE  0
+#define MSDFHIP_CHECK_DISTANCE_AT_EDGE 1
+#define MSDFHIP_ALWAYS_CHECK_DISTANCE  2
+
+#define MSDFHIP_OK                  0
+#define MSDFHIP_ERR_NO_DEVICE      -1 /* no HIP device / not gfx950 / runtime error at init */
+#define MSDFHIP_ERR_INVALID        -2 /* bad argument */
+#define MSDFHIP_ERR_HIP            -3 /* a HIP call failed; see msdfhip_last_error() */
+#define MSDFHIP_ERR_TOO_COMPLEX    -4 /* a shape has more contours than the LDS-resident combiner state supports */
+#define MSDFHIP_ERR_NOMEM          -5
+
+/* MSDFGeneratorConfig + ErrorCorrectionConfig (core/generator-config.h:13-64) without the buffer pointer. */
+typedef struct MsdfHipConfig {
+    int32_t overlap_support;     /* GeneratorConfig::overlapSupport, default 1 */
+    int32_t ec_mode;             /* default MSDFHIP_EC_EDGE_PRIORITY */
+    int32_t ec_distance_check;   /* default MSDFHIP_CHECK_DISTANCE_AT_EDGE */
+    int32_t ec_stage_limit;      /* 0 = full pipeline. 1..4: debug -- stop the stencil pipeline after stage k of
+                                    core/msdf-error-correction.cpp:27-46 (1 protectCorners, 2 +protectEdges, 3 +findErrors(sdf),
+                                    4 +protectAll+findErrors(sdf,shape)) and do not apply; used by the parity tests */
+    double min_deviation_ratio;  /* default 1.11111111111111111 (core/MSDFErrorCorrection.cpp:22) */
+    double min_improve_ratio;    /* default 1.11111111111111111 (core/MSDFErrorCorrection.cpp:23) */
+} MsdfHipConfig;
+
+/* Per-glyph descriptor of a batch (one output tile per glyph). Lives in device memory for the *_device entry points. */
+typedef struct MsdfHipGlyph {
+    double xf[6];                /* sx, sy, tx, ty, mapScale, mapTranslate */
+    int64_t out_offset;          /* index (in floats) of texel (0,0) of memory row 0 of this tile in the output buffer */
+    int32_t row_stride;          /* floats between consecutive memory rows of the tile (BitmapSection::rowStride) */
+    int32_t flip;                /* 1: shape Y orientation != bitmap orientation */
+} MsdfHipGlyph;
+
+/* Fills *cfg with the reference's defaults (MSDFGeneratorConfig(), core/generator-config.h:46,53,62). */
+void msdfhip_default_config(MsdfHipConfig *cfg);
+
+int msdfhip_abi_version(void);
+/* Binds the calling thread (and by default the process) to HIP device `device`; checks that it is gfx950. */
+int msdfhip_init(int device);
+/* Text of the last error on the calling thread ("" if none). */
+const char *msdfhip_last_error(void);
+/* name buffer receives e.g. "gfx950:sramecc+:xnack-"; cus/lds_bytes may be NULL. */
+int msdfhip_device_info(char *name, size_t name_len, int *cus, int *lds_bytes);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Single-shape, host-pointer calls: the literal replacements of the reference's functions.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* generateSDF / generatePSDF / generateMSDF / generateMTSDF(output, shape, transformation, config)
+ *   replaces core/msdfgen.cpp:78-106 (declared msdfgen.h:46-53); the Projection+Range overloads (msdfgen.h:59-63) and the legacy
+ *   Range/scale/translate overloads (msdfgen.h:65-69) forward here after building xf.
+ * For modes 3, 4 the error-correction pass (core/msdfgen.cpp:97,105) runs as configured. `stencil` is the optional
+ * ErrorCorrectionConfig::buffer (core/generator-config.h:44): NULL, or width*height bytes that receive the final stencil. */
+int msdfhip_generate(int mode, float *pixels, int width, int height, int row_stride, int flip,
+                     const int32_t *contour_offsets, int n_contours, const double *points, const uint8_t *types, const uint8_t *colors,
+                     const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil);
+
+int msdfhip_generate_sdf(float *pixels, int width, int height, int row_stride, int flip,
+                         const int32_t *contour_offsets, int n_contours, const double *points, const uint8_t *types, const uint8_t *colors,
+                         const double *xf, const MsdfHipConfig *cfg);                      /* msdfgen.h:47 */
+int msdfhip_generate_psdf(float *pixels, int width, int height, int row_stride, int flip,
+                          const int32_t *contour_offsets, int n_contours, const double *points, const uint8_t *types, const uint8_t *colors,
+                          const double *xf, const MsdfHipConfig *cfg);                     /* msdfgen.h:49 */
+int msdfhip_generate_msdf(float *pixels, int width, int height, int row_stride, int flip,
+                          const int32_t *contour_offsets, int n_contours, const double *points, const uint8_t *types, const uint8_t *colors,
+                          const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil);   /* msdfgen.h:51 */
+int msdfhip_generate_mtsdf(float *pixels, int width, int height, int row_stride, int flip,
+                           const int32_t *contour_offsets, int n_contours, const double *points, const uint8_t *types, const uint8_t *colors,
+                           const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil);  /* msdfgen.h:53 */
+
+/* msdfErrorCorrection(sdf, shape, transformation, config) on an existing 3- or 4-channel bitmap, in place.
+ *   replaces core/msdf-error-correction.cpp:50-65 (declared core/msdf-error-correction.h:15-18). */
+int msdfhip_error_correction(int channels, float *pixels, int width, int height, int row_stride, int flip,
+                             const int32_t *contour_offsets, int n_contours, const double *points, const uint8_t *types, const uint8_t *colors,
+                             const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil);
+
+/* ShapeDistanceFinder<CC<Selector>>::oneShotDistance at n shape-space points (core/ShapeDistanceFinder.hpp:36-58; the
+ * per-pixel engine under generate*).  selector = mode 1..4; out receives n*4 doubles (unused channels 0). */
+int msdfhip_shape_distance(int selector, int overlap_support, const int32_t *contour_offsets, int n_contours, const double *points,
+                           const uint8_t *types, const uint8_t *colors, int n_points, const double *pts, double *out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Batched, device-resident path (what an atlas generator uses): G glyph shapes -> G tiles of width x height.
+ * "Upload once": the edge buffer is flattened by the caller, lives in HBM, and is pre-digested on the device into
+ * per-edge records (end tangents, corner bisectors, polynomial coefficients, contour windings).
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+typedef struct MsdfHipBatch MsdfHipBatch; /* opaque */
+
+/* Creates a batch from HOST arrays (copied to the device; contour_offsets are global edge indices):
+ *   glyph_contour_offsets int32[n_glyphs+1], contour_offsets int32[n_contours+1], points double[n_edges*8], types/colors uint8[n_edges]. */
+int msdfhip_batch_create(MsdfHipBatch **batch, int n_glyphs, const int32_t *glyph_contour_offsets, const int32_t *contour_offsets,
+                         const double *points, const uint8_t *types, const uint8_t *colors);
+/* Same, from DEVICE arrays that already live in HBM (e.g. torch tensors); they must stay valid until the batch is destroyed.
+ * max_contours_per_glyph / max_edges_per_glyph are host-known upper bounds used to size LDS. `stream` is a hipStream_t (or NULL). */
+int msdfhip_batch_create_device(MsdfHipBatch **batch, int n_glyphs, int n_contours, int n_edges, int max_contours_per_glyph, int max_edges_per_glyph,
+                                const int32_t *d_glyph_contour_offsets, const int32_t *d_contour_offsets,
+                                const double *d_points, const uint8_t *d_types, const uint8_t *d_colors, void *stream);
+/* Re-runs the on-device digestion (records + windings) on `stream`, e.g. after the caller rewrote the edge arrays in place
+ * (device-array batches) -- this is the per-upload part of the pipeline that a benchmark step should include. */
+int msdfhip_batch_digest(MsdfHipBatch *batch, void *stream);
+void msdfhip_batch_destroy(MsdfHipBatch *batch);
+/* Contour::winding (core/Contour.cpp:57-81) of every contour of the batch, as computed on the device (host int32[n_contours]). */
+int msdfhip_batch_windings(const MsdfHipBatch *batch, int32_t *windings);
+
+/* Generates all tiles of the batch: glyph g's tile is written at d_out + d_glyphs[g].out_offset with d_glyphs[g].row_stride.
+ * d_glyphs (device, MsdfHipGlyph[n_glyphs]), d_out (device floats), d_stencil (device, n_glyphs*width*height bytes, or NULL),
+ * d_scratch: device floats, same extent as the tiles (n_glyphs*width*height*N), needed only when error correction runs
+ * (pre-correction distance field); may be NULL, then an internal buffer is used.
+ * Asynchronous on `stream` (hipStream_t or NULL = default stream). Replaces a loop of msdfgen.h:46-53 calls. */
+int msdfhip_batch_generate(const MsdfHipBatch *batch, int mode, int width, int height, const MsdfHipGlyph *d_glyphs,
+                           float *d_out, uint8_t *d_stencil, float *d_scratch, const MsdfHipConfig *cfg, void *stream);
+/* Convenience: same but with HOST descriptors and HOST output (tiles copied back; synchronous). */
+int msdfhip_batch_generate_host(const MsdfHipBatch *batch, int mode, int width, int height, const MsdfHipGlyph *glyphs,
+                                float *out, size_t out_floats, uint8_t *stencil, const MsdfHipConfig *cfg);
+
+/* Timing hook for bench.py: average device time in milliseconds of the dominant kernel (the distance-field kernel) over
+ * the launches recorded since the last call with reset != 0, measured with hipEvents on the launching stream.
+ * Enable with msdfhip_set_kernel_timing(1) (adds two event records per launch). */
+int msdfhip_set_kernel_timing(int enable);
+int msdfhip_kernel_timing(double *avg_ms_distance, double *avg_ms_correction, int *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSDFGEN_HIP_H */

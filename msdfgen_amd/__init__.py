@@ -1,0 +1,12 @@
+"""msdfgen_amd -- MI355X-native (gfx950, hand-written HIP) implementation of msdfgen's per-texel signed-distance hot path:
+generateSDF / generatePSDF / generateMSDF / generateMTSDF and the MSDF error-correction pass, behind a C ABI
+(include/msdfgen_hip.h) and this thin host-side mirror of the reference's interface.  There is no CPU compute path."""
+from .shape import FlatShape, ShapeBatch, autoframe, distance_mapping  # noqa: F401
+from .lib import MsdfHipError, load, init, device_info, default_config  # noqa: F401
+from .api import (  # noqa: F401
+    Projection, Range, DistanceMapping, SDFTransformation, ErrorCorrectionConfig, GeneratorConfig, MSDFGeneratorConfig,
+    generate_sdf, generate_psdf, generate_msdf, generate_mtsdf, msdf_error_correction, shape_distance, contour_windings, GlyphBatch,
+    MODE_SDF, MODE_PSDF, MODE_MSDF, MODE_MTSDF, CHANNELS, EC_DISABLED, EC_INDISCRIMINATE, EC_EDGE_PRIORITY, EC_EDGE_ONLY,
+    DO_NOT_CHECK_DISTANCE, CHECK_DISTANCE_AT_EDGE, ALWAYS_CHECK_DISTANCE, Y_UPWARD, Y_DOWNWARD)
+
+__version__ = "0.1.0"

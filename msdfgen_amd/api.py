@@ -1,0 +1,309 @@
+"""Host-side mirror of the reference's generator interface for the hot path (msdfgen.h:46-56, core/msdf-error-correction.h:15-18),
+on top of the C ABI.  Same names, argument meaning and defaults as the reference; outputs are numpy float32 bitmaps
+`(height, width, N)` standing in for `BitmapSection<float, N>`.
+
+    generate_sdf / generate_psdf / generate_msdf / generate_mtsdf (output, shape, transformation, config)
+    msdf_error_correction(sdf, shape, transformation, config)
+    shape_distance(shape, selector, overlap_support, points)      -- ShapeDistanceFinder::oneShotDistance
+
+`GlyphBatch` is the batched, device-resident front door (one launch for thousands of glyph tiles); it uses torch only to own
+device memory and streams.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import lib as _lib
+from .lib import (MODE_SDF, MODE_PSDF, MODE_MSDF, MODE_MTSDF, CHANNELS, EC_DISABLED, EC_INDISCRIMINATE, EC_EDGE_PRIORITY, EC_EDGE_ONLY,
+                  DO_NOT_CHECK_DISTANCE, CHECK_DISTANCE_AT_EDGE, ALWAYS_CHECK_DISTANCE, MsdfHipError)
+from .shape import FlatShape, ShapeBatch, distance_mapping
+
+DEFAULT_MIN_DEVIATION_RATIO = 1.11111111111111111  # ErrorCorrectionConfig::defaultMinDeviationRatio (MSDFErrorCorrection.cpp:22)
+DEFAULT_MIN_IMPROVE_RATIO = 1.11111111111111111    # ErrorCorrectionConfig::defaultMinImproveRatio   (MSDFErrorCorrection.cpp:23)
+Y_UPWARD, Y_DOWNWARD = 0, 1                        # YAxisOrientation (core/YAxisOrientation.h:9-16)
+
+
+@dataclass
+class Projection:
+    """core/Projection.h: shape -> pixel affine map, project(c) = scale*(c+translate)."""
+    scale: Sequence[float] = (1., 1.)
+    translate: Sequence[float] = (0., 0.)
+
+
+@dataclass
+class Range:
+    """core/Range.hpp:12-18. Range(w) is the symmetric range (-w/2, +w/2)."""
+    lower: float = 0.
+    upper: Optional[float] = None
+
+    def __post_init__(self):
+        if self.upper is None:
+            w = float(self.lower)
+            self.lower, self.upper = -.5*w, .5*w
+
+
+@dataclass
+class DistanceMapping:
+    """core/DistanceMapping.h: d -> scale*(d+translate). Built from a Range as in DistanceMapping.cpp:13."""
+    scale: float = 1.
+    translate: float = 0.
+
+    @staticmethod
+    def from_range(r: Range) -> "DistanceMapping":
+        s, t = distance_mapping(r.lower, r.upper)
+        return DistanceMapping(s, t)
+
+
+@dataclass
+class SDFTransformation:
+    """core/SDFTransformation.h:13-24."""
+    projection: Projection = field(default_factory=Projection)
+    distance_mapping: DistanceMapping = field(default_factory=DistanceMapping)
+
+    @staticmethod
+    def from_xf(xf) -> "SDFTransformation":
+        """xf = (sx, sy, tx, ty, range_lower, range_upper) as produced by shape.autoframe()."""
+        xf = [float(v) for v in xf]
+        return SDFTransformation(Projection((xf[0], xf[1]), (xf[2], xf[3])), DistanceMapping.from_range(Range(xf[4], xf[5])))
+
+    def xf6(self) -> np.ndarray:
+        return np.array([self.projection.scale[0], self.projection.scale[1], self.projection.translate[0], self.projection.translate[1],
+                         self.distance_mapping.scale, self.distance_mapping.translate], np.float64)
+
+
+@dataclass
+class ErrorCorrectionConfig:
+    """core/generator-config.h:13-47."""
+    mode: int = EC_EDGE_PRIORITY
+    distance_check_mode: int = CHECK_DISTANCE_AT_EDGE
+    min_deviation_ratio: float = DEFAULT_MIN_DEVIATION_RATIO
+    min_improve_ratio: float = DEFAULT_MIN_IMPROVE_RATIO
+    buffer: Optional[np.ndarray] = None  # optional uint8 (h, w): receives the final stencil (rows in the bitmap's memory order)
+
+
+@dataclass
+class GeneratorConfig:
+    """core/generator-config.h:50-56."""
+    overlap_support: bool = True
+
+
+@dataclass
+class MSDFGeneratorConfig(GeneratorConfig):
+    """core/generator-config.h:58-64."""
+    error_correction: ErrorCorrectionConfig = field(default_factory=ErrorCorrectionConfig)
+    _stage_limit: int = 0  # test hook: stop the stencil pipeline after stage k (see MsdfHipConfig.ec_stage_limit)
+
+
+def _c_config(config) -> _lib.Config:
+    cfg = _lib.default_config()
+    if config is None:
+        return cfg
+    cfg.overlap_support = 1 if config.overlap_support else 0
+    ec = getattr(config, "error_correction", None)
+    if ec is not None:
+        cfg.ec_mode = int(ec.mode)
+        cfg.ec_distance_check = int(ec.distance_check_mode)
+        cfg.min_deviation_ratio = float(ec.min_deviation_ratio)
+        cfg.min_improve_ratio = float(ec.min_improve_ratio)
+    cfg.ec_stage_limit = int(getattr(config, "_stage_limit", 0))
+    return cfg
+
+
+def _shape_args(shape: FlatShape):
+    co = np.ascontiguousarray(shape.contour_offsets, np.int32)
+    pts = np.ascontiguousarray(shape.points, np.float64)
+    types = np.ascontiguousarray(shape.types, np.uint8)
+    colors = np.ascontiguousarray(shape.colors, np.uint8)
+    keep = (co, pts, types, colors)
+    return keep, (_lib.ptr(co, _lib._ip), shape.n_contours, _lib.ptr(pts, _lib._dp), _lib.ptr(types, _lib._bp), _lib.ptr(colors, _lib._bp))
+
+
+def _bitmap_args(output: np.ndarray, n: int):
+    if output.dtype != np.float32 or output.ndim != 3 or output.shape[2] != n:
+        raise ValueError("output must be float32 of shape (height, width, %d)" % n)
+    if output.strides[2] != 4 or output.strides[1] != 4*n or output.strides[0] % 4:
+        raise ValueError("output texels must be channel-interleaved and rows float-aligned")
+    h, w = output.shape[:2]
+    return _lib.ptr(output, _lib._fp), w, h, output.strides[0]//4  # row stride in floats; may be negative for a flipped view
+
+
+def _generate(mode, output, shape, transformation, config, y_orientation):
+    lib = _lib.load()
+    px, w, h, stride = _bitmap_args(output, CHANNELS[mode])
+    keep, sargs = _shape_args(shape)
+    xf = transformation.xf6()
+    cfg = _c_config(config)
+    flip = int(bool(shape.inverse_y) != (y_orientation == Y_DOWNWARD))  # shape.getYAxisOrientation() != output.yOrientation
+    stencil = None
+    ec = getattr(config, "error_correction", None)
+    if ec is not None and ec.buffer is not None:
+        stencil = ec.buffer
+        if stencil.dtype != np.uint8 or stencil.size < w*h or not stencil.flags.c_contiguous:
+            raise ValueError("error_correction.buffer must be C-contiguous uint8 with at least width*height bytes")
+    _lib.check(lib.msdfhip_generate(mode, px, w, h, stride, flip, *sargs, _lib.ptr(xf, _lib._dp), C.byref(cfg),
+                                    _lib.ptr(stencil, _lib._bp) if stencil is not None else None))
+    del keep
+    return output
+
+
+def generate_sdf(output, shape, transformation, config: Optional[GeneratorConfig] = None, y_orientation=Y_UPWARD):
+    """generateSDF (msdfgen.h:47, core/msdfgen.cpp:78-83)."""
+    return _generate(MODE_SDF, output, shape, transformation, config or GeneratorConfig(), y_orientation)
+
+
+def generate_psdf(output, shape, transformation, config: Optional[GeneratorConfig] = None, y_orientation=Y_UPWARD):
+    """generatePSDF (msdfgen.h:49, core/msdfgen.cpp:85-90)."""
+    return _generate(MODE_PSDF, output, shape, transformation, config or GeneratorConfig(), y_orientation)
+
+
+def generate_msdf(output, shape, transformation, config: Optional[MSDFGeneratorConfig] = None, y_orientation=Y_UPWARD):
+    """generateMSDF (msdfgen.h:51, core/msdfgen.cpp:92-98), including the error-correction pass."""
+    return _generate(MODE_MSDF, output, shape, transformation, config or MSDFGeneratorConfig(), y_orientation)
+
+
+def generate_mtsdf(output, shape, transformation, config: Optional[MSDFGeneratorConfig] = None, y_orientation=Y_UPWARD):
+    """generateMTSDF (msdfgen.h:53, core/msdfgen.cpp:100-106), including the error-correction pass."""
+    return _generate(MODE_MTSDF, output, shape, transformation, config or MSDFGeneratorConfig(), y_orientation)
+
+
+def msdf_error_correction(sdf, shape, transformation, config: Optional[MSDFGeneratorConfig] = None, y_orientation=Y_UPWARD):
+    """msdfErrorCorrection (core/msdf-error-correction.h:15-16), in place on a 3- or 4-channel bitmap."""
+    lib = _lib.load()
+    config = config or MSDFGeneratorConfig()
+    n = sdf.shape[2]
+    px, w, h, stride = _bitmap_args(sdf, n)
+    keep, sargs = _shape_args(shape)
+    xf = transformation.xf6()
+    cfg = _c_config(config)
+    flip = int(bool(shape.inverse_y) != (y_orientation == Y_DOWNWARD))
+    stencil = config.error_correction.buffer
+    _lib.check(lib.msdfhip_error_correction(n, px, w, h, stride, flip, *sargs, _lib.ptr(xf, _lib._dp), C.byref(cfg),
+                                            _lib.ptr(stencil, _lib._bp) if stencil is not None else None))
+    del keep
+    return sdf
+
+
+def shape_distance(shape, selector, overlap_support, points):
+    """ShapeDistanceFinder<CC<Selector>>::oneShotDistance (core/ShapeDistanceFinder.hpp:36-58) at shape-space points; (n, 4) float64."""
+    lib = _lib.load()
+    pts = np.ascontiguousarray(points, np.float64).reshape(-1, 2)
+    out = np.zeros((len(pts), 4), np.float64)
+    keep, sargs = _shape_args(shape)
+    _lib.check(lib.msdfhip_shape_distance(int(selector), int(bool(overlap_support)), *sargs, len(pts), _lib.ptr(pts, _lib._dp), _lib.ptr(out, _lib._dp)))
+    del keep
+    return out
+
+
+def contour_windings(shape: FlatShape):
+    """Contour::winding per contour (core/Contour.cpp:57-81) as computed by the device digestion kernel."""
+    lib = _lib.load()
+    keep, sargs = _shape_args(shape)
+    gco = np.array([0, shape.n_contours], np.int32)
+    handle = C.c_void_p()
+    _lib.check(lib.msdfhip_batch_create(C.byref(handle), 1, _lib.ptr(gco, _lib._ip), sargs[0], sargs[2], sargs[3], sargs[4]))
+    try:
+        out = np.zeros(max(shape.n_contours, 1), np.int32)
+        _lib.check(lib.msdfhip_batch_windings(handle, _lib.ptr(out, _lib._ip)))
+    finally:
+        lib.msdfhip_batch_destroy(handle)
+    del keep
+    return out[:shape.n_contours]
+
+
+class GlyphBatch:
+    """G glyph shapes resident in HBM ("uploaded once"), digested on the device, ready to be rendered into G tiles per launch.
+
+    torch owns the device buffers; the kernels run on torch's current stream unless one is given.
+    """
+
+    def __init__(self, shapes: ShapeBatch, device=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise MsdfHipError(_lib.ERR_NO_DEVICE, "no GPU visible to torch; msdfgen_amd has no CPU path")
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device) if not isinstance(device, torch.device) else device
+        _lib.init(self.device.index or 0)
+        self.shapes = shapes
+        self.n_glyphs = shapes.n_glyphs
+        dev = self.device
+        self._gco = torch.from_numpy(np.ascontiguousarray(shapes.glyph_contour_offsets, np.int32)).to(dev)
+        self._co = torch.from_numpy(np.ascontiguousarray(shapes.contour_offsets, np.int32)).to(dev)
+        n_e = max(shapes.n_edges, 1)
+        pts = np.zeros((n_e, 8), np.float64)
+        pts[:shapes.n_edges] = shapes.points
+        types = np.ones(n_e, np.uint8)
+        types[:shapes.n_edges] = shapes.types
+        colors = np.zeros(n_e, np.uint8)
+        colors[:shapes.n_edges] = shapes.colors
+        self._pts = torch.from_numpy(pts).to(dev)
+        self._types = torch.from_numpy(types).to(dev)
+        self._colors = torch.from_numpy(colors).to(dev)
+        gco, co = shapes.glyph_contour_offsets, shapes.contour_offsets
+        self.max_contours = int(np.diff(gco).max()) if self.n_glyphs else 0
+        self.max_edges = int((co[gco[1:]]-co[gco[:-1]]).max()) if self.n_glyphs else 0
+        self._handle = C.c_void_p()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.load().msdfhip_batch_create_device(C.byref(self._handle), self.n_glyphs, shapes.n_contours, shapes.n_edges, self.max_contours,
+                                                           self.max_edges, self._gco.data_ptr(), self._co.data_ptr(), self._pts.data_ptr(),
+                                                           self._types.data_ptr(), self._colors.data_ptr(), stream))
+        self._scratch = None
+        self._glyph_cache = {}
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle:
+            self.torch.cuda.synchronize(self.device)
+            _lib.load().msdfhip_batch_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def digest(self, stream=None):
+        """Re-runs the on-device digestion of the edge buffer (records + windings); part of every fresh upload."""
+        s = (stream or self.torch.cuda.current_stream(self.device)).cuda_stream
+        _lib.check(_lib.load().msdfhip_batch_digest(self._handle, s))
+
+    def windings(self):
+        out = np.zeros(max(self.shapes.n_contours, 1), np.int32)
+        _lib.check(_lib.load().msdfhip_batch_windings(self._handle, _lib.ptr(out, _lib._ip)))
+        return out[:self.shapes.n_contours]
+
+    def descriptors(self, xfs, width, height, channels, y_orientation=Y_UPWARD, out_offsets=None, row_stride=None):
+        """Device array of MsdfHipGlyph for contiguous tiles [g][h][w][N] (or custom atlas placement via out_offsets/row_stride).
+        xfs: (G, 6) rows (sx, sy, tx, ty, range_lower, range_upper)."""
+        xfs = np.ascontiguousarray(xfs, np.float64).reshape(self.n_glyphs, 6)
+        d = np.zeros(self.n_glyphs, _lib.GLYPH_DTYPE)
+        d["xf"][:, :4] = xfs[:, :4]
+        d["xf"][:, 4] = np.float64(1)/(xfs[:, 5]-xfs[:, 4])  # DistanceMapping.cpp:13
+        d["xf"][:, 5] = -xfs[:, 4]
+        tile = width*height*channels
+        d["out_offset"] = np.arange(self.n_glyphs, dtype=np.int64)*tile if out_offsets is None else np.asarray(out_offsets, np.int64)
+        d["row_stride"] = width*channels if row_stride is None else row_stride
+        d["flip"] = (self.shapes.inverse_y.astype(bool) != (y_orientation == Y_DOWNWARD)).astype(np.int32)
+        return self.torch.from_numpy(d.view(np.uint8).reshape(self.n_glyphs, 64)).to(self.device)
+
+    def generate(self, mode, width, height, xfs=None, config=None, out=None, stencil=None, descriptors=None, stream=None, y_orientation=Y_UPWARD):
+        """Renders every glyph of the batch into its tile; returns the float32 device tensor (G, height, width, N).
+        Asynchronous on `stream` (torch.cuda.Stream) or torch's current stream."""
+        torch = self.torch
+        n = CHANNELS[mode]
+        if descriptors is None:
+            descriptors = self.descriptors(xfs, width, height, n, y_orientation)
+        if out is None:
+            out = torch.empty((self.n_glyphs, height, width, n), dtype=torch.float32, device=self.device)
+        cfg = _c_config(config if config is not None else (MSDFGeneratorConfig() if mode >= 3 else GeneratorConfig()))
+        scratch_ptr = None
+        if mode >= 3 and cfg.ec_mode != EC_DISABLED:
+            need = self.n_glyphs*height*width*n
+            if self._scratch is None or self._scratch.numel() < need:
+                self._scratch = torch.empty(need, dtype=torch.float32, device=self.device)
+            scratch_ptr = self._scratch.data_ptr()
+        s = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        _lib.check(_lib.load().msdfhip_batch_generate(self._handle, mode, width, height, descriptors.data_ptr(), out.data_ptr(),
+                                                      stencil.data_ptr() if stencil is not None else None, scratch_ptr, C.byref(cfg), s))
+        return out

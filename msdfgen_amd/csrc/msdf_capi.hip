@@ -1,0 +1,644 @@
+// msdf_capi.hip -- implementation of the C ABI declared in include/msdfgen_hip.h (libmsdfgen_hip.so).
+// Host side of the MI355X MSDF hot path: device binding, batch upload + on-device digestion, kernel dispatch, and the
+// single-shape host-pointer entry points that stand in for the reference's generate* / msdfErrorCorrection functions.
+// There is deliberately no CPU compute path in this file: without a gfx950 device every compute call fails.
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "msdf_kernels.hpp"
+
+using namespace msdfhip;
+
+namespace {
+
+thread_local std::string tlsError;
+std::atomic<int> gDevice(-1);
+std::atomic<int> gLdsLimit(0);
+std::atomic<int> gTiming(0);
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    tlsError = buf;
+    return code;
+}
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(MSDFHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+int ensureDevice() {
+    int dev = gDevice.load();
+    if (dev < 0) {
+        int rc = msdfhip_init(0);
+        if (rc != MSDFHIP_OK)
+            return rc;
+        dev = gDevice.load();
+    }
+    if (hipSetDevice(dev) != hipSuccess)
+        return fail(MSDFHIP_ERR_NO_DEVICE, "hipSetDevice(%d) failed", dev);
+    return MSDFHIP_OK;
+}
+
+int channelsOf(int mode) { return mode <= 2 ? 1 : mode; }
+
+struct TimedLaunch { hipEvent_t a, b; int kind; };
+std::mutex gTimingMutex;
+std::vector<TimedLaunch> gTimed;
+
+struct ScopedTimer {
+    hipStream_t stream;
+    TimedLaunch t;
+    bool on;
+    ScopedTimer(hipStream_t s, int kind) : stream(s), on(gTiming.load() != 0) {
+        t.kind = kind;
+        if (on) {
+            if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) { on = false; return; }
+            hipEventRecord(t.a, stream);
+        }
+    }
+    ~ScopedTimer() {
+        if (on) {
+            hipEventRecord(t.b, stream);
+            std::lock_guard<std::mutex> lock(gTimingMutex);
+            gTimed.push_back(t);
+        }
+    }
+};
+
+} // namespace
+
+struct MsdfHipBatch {
+    int nGlyphs, nContours, nEdges, maxContours, maxEdges;
+    bool ownsInputs;
+    int32_t *dGlyphContourOffsets, *dContourOffsets;
+    double *dPoints;
+    uint8_t *dTypes, *dColors;
+    EdgeRec *dRecs;
+    int8_t *dWindings;
+    mutable float *dScratch;
+    mutable size_t scratchFloats;
+    mutable std::mutex scratchMutex;
+};
+
+namespace {
+
+BatchView viewOf(const MsdfHipBatch *b) {
+    BatchView v;
+    v.nGlyphs = b->nGlyphs;
+    v.glyphContourOffsets = b->dGlyphContourOffsets;
+    v.contourOffsets = b->dContourOffsets;
+    v.recs = b->dRecs;
+    v.windings = b->dWindings;
+    return v;
+}
+
+int digest(MsdfHipBatch *b, hipStream_t stream) {
+    if (!b->dRecs)
+        HIPCHK(hipMalloc((void **) &b->dRecs, sizeof(EdgeRec)*(size_t) (b->nEdges > 0 ? b->nEdges : 1)));
+    if (!b->dWindings)
+        HIPCHK(hipMalloc((void **) &b->dWindings, (size_t) (b->nContours > 0 ? b->nContours : 1)));
+    if (b->nEdges > 0)
+        hipLaunchKernelGGL(k_prep_records, dim3((b->nEdges+255)/256), dim3(256), 0, stream, b->dRecs, b->nEdges, b->nContours,
+                           b->dContourOffsets, b->dPoints, b->dTypes, b->dColors);
+    if (b->nContours > 0)
+        hipLaunchKernelGGL(k_windings, dim3((b->nContours+255)/256), dim3(256), 0, stream, b->dWindings, b->nContours,
+                           b->dContourOffsets, b->dPoints, b->dTypes, b->dColors);
+    HIPCHK(hipGetLastError());
+    return MSDFHIP_OK;
+}
+
+// LDS plan for a launch: bytes of dynamic LDS and whether the records are staged in LDS or read from global memory.
+struct LdsPlan { size_t bytes; bool ldsRec; };
+
+int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan) {
+    const size_t resBytes = overlap ? (size_t) b->maxContours*nch*WAVE*sizeof(double) : 0;
+    const size_t recBytes = (size_t) b->maxEdges*sizeof(EdgeRec);
+    const size_t limit = (size_t) gLdsLimit.load();
+    if (resBytes > limit)
+        return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours: the overlapping combiner needs %zu B of LDS per wavefront, device limit is %zu B",
+                    b->maxContours, resBytes, limit);
+    // Staging pays while several workgroups still fit on a CU: keep res+rec within 40 KB (>= 4 workgroups per CU).
+    plan.ldsRec = resBytes+recBytes <= 40*1024;
+    plan.bytes = resBytes+(plan.ldsRec ? recBytes : 0);
+    return MSDFHIP_OK;
+}
+
+template <class K>
+int setLds(K kernel, size_t bytes) {
+    if (bytes > 64*1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+    return MSDFHIP_OK;
+}
+
+template <int SEL, bool OVERLAP, bool LDSREC>
+int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, size_t lds, hipStream_t stream) {
+    const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE, tiles = tilesX*tilesY;
+    const unsigned blocks = (unsigned) ((b->nGlyphs+7)/8)*8u*(unsigned) tiles;
+    int rc = setLds(k_distance<SEL, OVERLAP, LDSREC>, lds);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    ScopedTimer timer(stream, 0);
+    hipLaunchKernelGGL((k_distance<SEL, OVERLAP, LDSREC>), dim3(blocks), dim3(WAVE), lds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, dst, toScratch);
+    HIPCHK(hipGetLastError());
+    return MSDFHIP_OK;
+}
+
+template <int SEL>
+int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, bool overlap, hipStream_t stream) {
+    LdsPlan plan;
+    int rc = planLds(b, SelTraits<SEL>::NCH, overlap, plan);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    if (overlap)
+        return plan.ldsRec ? launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, plan.bytes, stream)
+                           : launchDistance<SEL, true, false>(b, dGlyphs, w, h, dst, toScratch, plan.bytes, stream);
+    return plan.ldsRec ? launchDistance<SEL, false, true>(b, dGlyphs, w, h, dst, toScratch, plan.bytes, stream)
+                       : launchDistance<SEL, false, false>(b, dGlyphs, w, h, dst, toScratch, plan.bytes, stream);
+}
+
+template <int N, bool OVERLAP, bool LDSREC>
+int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, const float *src, float *out, uint8_t *stencil,
+             const MsdfHipConfig &cfg, size_t lds, hipStream_t stream) {
+    const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE, tiles = tilesX*tilesY;
+    const unsigned blocks = (unsigned) ((b->nGlyphs+7)/8)*8u*(unsigned) tiles;
+    int rc = setLds(k_error_correction<N, OVERLAP, LDSREC>, lds);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    ScopedTimer timer(stream, 1);
+    hipLaunchKernelGGL((k_error_correction<N, OVERLAP, LDSREC>), dim3(blocks), dim3(WAVE), lds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles,
+                       src, out, stencil, cfg);
+    HIPCHK(hipGetLastError());
+    return MSDFHIP_OK;
+}
+
+template <int N>
+int dispatchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, const float *src, float *out, uint8_t *stencil,
+               const MsdfHipConfig &cfg, hipStream_t stream) {
+    const bool overlap = cfg.overlap_support != 0;
+    LdsPlan plan;
+    int rc = planLds(b, 1, overlap, plan);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    if (overlap)
+        return plan.ldsRec ? launchEc<N, true, true>(b, dGlyphs, w, h, src, out, stencil, cfg, plan.bytes, stream)
+                           : launchEc<N, true, false>(b, dGlyphs, w, h, src, out, stencil, cfg, plan.bytes, stream);
+    return plan.ldsRec ? launchEc<N, false, true>(b, dGlyphs, w, h, src, out, stencil, cfg, plan.bytes, stream)
+                       : launchEc<N, false, false>(b, dGlyphs, w, h, src, out, stencil, cfg, plan.bytes, stream);
+}
+
+int checkConfig(const MsdfHipConfig *cfg) {
+    if (!cfg)
+        return fail(MSDFHIP_ERR_INVALID, "cfg is NULL");
+    if (cfg->ec_mode < 0 || cfg->ec_mode > 3 || cfg->ec_distance_check < 0 || cfg->ec_distance_check > 2 || cfg->ec_stage_limit < 0 || cfg->ec_stage_limit > 4)
+        return fail(MSDFHIP_ERR_INVALID, "bad error-correction config (mode %d, distance check %d, stage limit %d)", cfg->ec_mode, cfg->ec_distance_check, cfg->ec_stage_limit);
+    return MSDFHIP_OK;
+}
+
+int ensureScratch(const MsdfHipBatch *b, size_t floats, float **out) {
+    std::lock_guard<std::mutex> lock(b->scratchMutex);
+    if (b->scratchFloats < floats) {
+        if (b->dScratch)
+            hipFree(b->dScratch);
+        b->dScratch = NULL;
+        b->scratchFloats = 0;
+        HIPCHK(hipMalloc((void **) &b->dScratch, floats*sizeof(float)));
+        b->scratchFloats = floats;
+    }
+    *out = b->dScratch;
+    return MSDFHIP_OK;
+}
+
+// Error correction only: src (packed pre-correction tiles) -> out.
+int runCorrection(const MsdfHipBatch *b, int channels, int w, int h, const MsdfHipGlyph *dGlyphs, const float *src, float *out, uint8_t *stencil,
+                  const MsdfHipConfig &cfg, hipStream_t stream) {
+    return channels == 3 ? dispatchEc<3>(b, dGlyphs, w, h, src, out, stencil, cfg, stream) : dispatchEc<4>(b, dGlyphs, w, h, src, out, stencil, cfg, stream);
+}
+
+} // namespace
+
+extern "C" {
+
+void msdfhip_default_config(MsdfHipConfig *cfg) {
+    if (!cfg)
+        return;
+    cfg->overlap_support = 1;
+    cfg->ec_mode = MSDFHIP_EC_EDGE_PRIORITY;
+    cfg->ec_distance_check = MSDFHIP_CHECK_DISTANCE_AT_EDGE;
+    cfg->ec_stage_limit = 0;
+    cfg->min_deviation_ratio = 1.11111111111111111;
+    cfg->min_improve_ratio = 1.11111111111111111;
+}
+
+int msdfhip_abi_version(void) { return MSDFHIP_ABI_VERSION; }
+
+const char *msdfhip_last_error(void) { return tlsError.c_str(); }
+
+int msdfhip_init(int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(MSDFHIP_ERR_NO_DEVICE, "no HIP device visible (hipGetDeviceCount -> %d); this library has no CPU fallback", count);
+    if (device < 0 || device >= count)
+        return fail(MSDFHIP_ERR_INVALID, "device %d out of range (0..%d)", device, count-1);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return fail(MSDFHIP_ERR_NO_DEVICE, "hipGetDeviceProperties(%d) failed", device);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MSDFHIP_ERR_NO_DEVICE, "device %d is %s; libmsdfgen_hip is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    if (hipSetDevice(device) != hipSuccess)
+        return fail(MSDFHIP_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    gLdsLimit.store((int) (prop.maxSharedMemoryPerMultiProcessor > 0 ? prop.maxSharedMemoryPerMultiProcessor : prop.sharedMemPerBlock));
+    gDevice.store(device);
+    return MSDFHIP_OK;
+}
+
+int msdfhip_device_info(char *name, size_t name_len, int *cus, int *lds_bytes) {
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, gDevice.load()));
+    if (name && name_len) {
+        strncpy(name, prop.gcnArchName, name_len-1);
+        name[name_len-1] = 0;
+    }
+    if (cus)
+        *cus = prop.multiProcessorCount;
+    if (lds_bytes)
+        *lds_bytes = gLdsLimit.load();
+    return MSDFHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------- batches
+
+int msdfhip_batch_create_device(MsdfHipBatch **batch, int n_glyphs, int n_contours, int n_edges, int max_contours_per_glyph, int max_edges_per_glyph,
+                                const int32_t *d_glyph_contour_offsets, const int32_t *d_contour_offsets,
+                                const double *d_points, const uint8_t *d_types, const uint8_t *d_colors, void *stream) {
+    if (!batch || n_glyphs < 0 || n_contours < 0 || n_edges < 0)
+        return fail(MSDFHIP_ERR_INVALID, "bad batch dimensions");
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    MsdfHipBatch *b = new MsdfHipBatch();
+    b->nGlyphs = n_glyphs, b->nContours = n_contours, b->nEdges = n_edges;
+    b->maxContours = max_contours_per_glyph, b->maxEdges = max_edges_per_glyph;
+    b->ownsInputs = false;
+    b->dGlyphContourOffsets = const_cast<int32_t *>(d_glyph_contour_offsets);
+    b->dContourOffsets = const_cast<int32_t *>(d_contour_offsets);
+    b->dPoints = const_cast<double *>(d_points);
+    b->dTypes = const_cast<uint8_t *>(d_types);
+    b->dColors = const_cast<uint8_t *>(d_colors);
+    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0;
+    rc = digest(b, (hipStream_t) stream);
+    if (rc != MSDFHIP_OK) {
+        msdfhip_batch_destroy(b);
+        return rc;
+    }
+    *batch = b;
+    return MSDFHIP_OK;
+}
+
+int msdfhip_batch_create(MsdfHipBatch **batch, int n_glyphs, const int32_t *gco, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors) {
+    if (!batch || n_glyphs < 0 || !gco || !co)
+        return fail(MSDFHIP_ERR_INVALID, "bad batch arguments");
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    const int nC = gco[n_glyphs], nE = co[nC];
+    if (gco[0] != 0 || co[0] != 0 || nC < 0 || nE < 0)
+        return fail(MSDFHIP_ERR_INVALID, "offset arrays must start at 0");
+    int maxC = 0, maxE = 0;
+    for (int g = 0; g < n_glyphs; ++g) {
+        if (gco[g+1] < gco[g])
+            return fail(MSDFHIP_ERR_INVALID, "glyph_contour_offsets not monotonic at %d", g);
+        const int c = gco[g+1]-gco[g], e = co[gco[g+1]]-co[gco[g]];
+        maxC = c > maxC ? c : maxC;
+        maxE = e > maxE ? e : maxE;
+    }
+    for (int c = 0; c < nC; ++c)
+        if (co[c+1] < co[c])
+            return fail(MSDFHIP_ERR_INVALID, "contour_offsets not monotonic at %d", c);
+    for (int e = 0; e < nE; ++e)
+        if (types[e] < 1 || types[e] > 3)
+            return fail(MSDFHIP_ERR_INVALID, "edge %d has type %d (must be 1, 2 or 3)", e, (int) types[e]);
+    MsdfHipBatch *b = new MsdfHipBatch();
+    b->nGlyphs = n_glyphs, b->nContours = nC, b->nEdges = nE, b->maxContours = maxC, b->maxEdges = maxE;
+    b->ownsInputs = true;
+    b->dGlyphContourOffsets = NULL, b->dContourOffsets = NULL, b->dPoints = NULL, b->dTypes = NULL, b->dColors = NULL;
+    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0;
+    const size_t eAlloc = nE > 0 ? nE : 1;
+    #define ALLOC_COPY(dst, src, bytes, used) do { \
+        hipError_t e_ = hipMalloc((void **) &(dst), (bytes) ? (bytes) : 16); \
+        if (e_ == hipSuccess && (used)) e_ = hipMemcpy((dst), (src), (used), hipMemcpyHostToDevice); \
+        if (e_ != hipSuccess) { msdfhip_batch_destroy(b); return fail(MSDFHIP_ERR_HIP, "batch upload failed: %s", hipGetErrorString(e_)); } } while (0)
+    ALLOC_COPY(b->dGlyphContourOffsets, gco, sizeof(int32_t)*(size_t) (n_glyphs+1), sizeof(int32_t)*(size_t) (n_glyphs+1));
+    ALLOC_COPY(b->dContourOffsets, co, sizeof(int32_t)*(size_t) (nC+1), sizeof(int32_t)*(size_t) (nC+1));
+    ALLOC_COPY(b->dPoints, points, sizeof(double)*8*eAlloc, sizeof(double)*8*(size_t) nE);
+    ALLOC_COPY(b->dTypes, types, eAlloc, (size_t) nE);
+    ALLOC_COPY(b->dColors, colors, eAlloc, (size_t) nE);
+    #undef ALLOC_COPY
+    rc = digest(b, NULL);
+    if (rc == MSDFHIP_OK && hipStreamSynchronize(NULL) != hipSuccess)
+        rc = fail(MSDFHIP_ERR_HIP, "edge digestion failed: %s", hipGetErrorString(hipGetLastError()));
+    if (rc != MSDFHIP_OK) {
+        msdfhip_batch_destroy(b);
+        return rc;
+    }
+    *batch = b;
+    return MSDFHIP_OK;
+}
+
+int msdfhip_batch_digest(MsdfHipBatch *b, void *stream) {
+    if (!b)
+        return fail(MSDFHIP_ERR_INVALID, "NULL batch");
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    return digest(b, (hipStream_t) stream);
+}
+
+void msdfhip_batch_destroy(MsdfHipBatch *b) {
+    if (!b)
+        return;
+    if (b->ownsInputs) {
+        hipFree(b->dGlyphContourOffsets);
+        hipFree(b->dContourOffsets);
+        hipFree(b->dPoints);
+        hipFree(b->dTypes);
+        hipFree(b->dColors);
+    }
+    hipFree(b->dRecs);
+    hipFree(b->dWindings);
+    hipFree(b->dScratch);
+    delete b;
+}
+
+int msdfhip_batch_windings(const MsdfHipBatch *b, int32_t *windings) {
+    if (!b || !windings)
+        return fail(MSDFHIP_ERR_INVALID, "NULL argument");
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    std::vector<int8_t> tmp((size_t) b->nContours+1);
+    HIPCHK(hipDeviceSynchronize());
+    if (b->nContours)
+        HIPCHK(hipMemcpy(tmp.data(), b->dWindings, (size_t) b->nContours, hipMemcpyDeviceToHost));
+    for (int c = 0; c < b->nContours; ++c)
+        windings[c] = tmp[c];
+    return MSDFHIP_OK;
+}
+
+int msdfhip_batch_generate(const MsdfHipBatch *b, int mode, int w, int h, const MsdfHipGlyph *dGlyphs, float *dOut, uint8_t *dStencil,
+                           float *dScratch, const MsdfHipConfig *cfg, void *streamPtr) {
+    if (!b || mode < 1 || mode > 4 || w < 0 || h < 0 || !dGlyphs || !dOut)
+        return fail(MSDFHIP_ERR_INVALID, "bad arguments to msdfhip_batch_generate");
+    int rc = checkConfig(cfg);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    if (b->nGlyphs == 0 || w == 0 || h == 0)
+        return MSDFHIP_OK;                                       // zero-size bitmap: no-op, like the reference loops
+    hipStream_t stream = (hipStream_t) streamPtr;
+    const bool overlap = cfg->overlap_support != 0;
+    const bool correct = mode >= 3 && cfg->ec_mode != MSDFHIP_EC_DISABLED; // msdf-error-correction.cpp:13-14
+    float *dst = dOut;
+    if (correct) {
+        if (!dScratch) {
+            rc = ensureScratch(b, (size_t) b->nGlyphs*w*h*channelsOf(mode), &dScratch);
+            if (rc != MSDFHIP_OK)
+                return rc;
+        }
+        dst = dScratch;
+    }
+    switch (mode) {
+        case 1: rc = dispatchDistance<1>(b, dGlyphs, w, h, dst, 0, overlap, stream); break;
+        case 2: rc = dispatchDistance<2>(b, dGlyphs, w, h, dst, 0, overlap, stream); break;
+        case 3: rc = dispatchDistance<3>(b, dGlyphs, w, h, dst, correct, overlap, stream); break;
+        default: rc = dispatchDistance<4>(b, dGlyphs, w, h, dst, correct, overlap, stream); break;
+    }
+    if (rc != MSDFHIP_OK || !correct)
+        return rc;
+    return runCorrection(b, channelsOf(mode), w, h, dGlyphs, dScratch, dOut, dStencil, *cfg, stream);
+}
+
+int msdfhip_batch_generate_host(const MsdfHipBatch *b, int mode, int w, int h, const MsdfHipGlyph *glyphs, float *out, size_t outFloats,
+                                uint8_t *stencil, const MsdfHipConfig *cfg) {
+    if (!b || !glyphs || !out)
+        return fail(MSDFHIP_ERR_INVALID, "NULL argument");
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    MsdfHipGlyph *dGlyphs = NULL;
+    float *dOut = NULL;
+    uint8_t *dStencil = NULL;
+    const size_t nG = (size_t) b->nGlyphs;
+    hipError_t e = hipMalloc((void **) &dGlyphs, sizeof(MsdfHipGlyph)*(nG ? nG : 1));
+    if (e == hipSuccess) e = hipMalloc((void **) &dOut, sizeof(float)*(outFloats ? outFloats : 1));
+    if (e == hipSuccess && stencil) e = hipMalloc((void **) &dStencil, nG*w*h ? nG*w*h : 1);
+    if (e == hipSuccess && nG) e = hipMemcpy(dGlyphs, glyphs, sizeof(MsdfHipGlyph)*nG, hipMemcpyHostToDevice);
+    if (e == hipSuccess && outFloats) e = hipMemcpy(dOut, out, sizeof(float)*outFloats, hipMemcpyHostToDevice); // keep texels outside the tiles
+    if (e == hipSuccess) {
+        rc = msdfhip_batch_generate(b, mode, w, h, dGlyphs, dOut, dStencil, NULL, cfg, NULL);
+        if (rc == MSDFHIP_OK) {
+            e = hipStreamSynchronize(NULL);
+            if (e == hipSuccess && outFloats) e = hipMemcpy(out, dOut, sizeof(float)*outFloats, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && stencil && nG*w*h) e = hipMemcpy(stencil, dStencil, nG*w*h, hipMemcpyDeviceToHost);
+        }
+    }
+    hipFree(dGlyphs);
+    hipFree(dOut);
+    hipFree(dStencil);
+    if (e != hipSuccess)
+        return fail(MSDFHIP_ERR_HIP, "msdfhip_batch_generate_host: %s", hipGetErrorString(e));
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------- single-shape host calls
+
+static int singleShape(int mode, int channels, bool correctionOnly, float *pixels, int w, int h, int rowStride, int flip,
+                       const int32_t *co, int nC, const double *points, const uint8_t *types, const uint8_t *colors,
+                       const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil) {
+    if (w < 0 || h < 0 || nC < 0 || !co || !xf || (!pixels && w*h > 0))
+        return fail(MSDFHIP_ERR_INVALID, "bad arguments");
+    int rc = checkConfig(cfg);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    if (w == 0 || h == 0)
+        return MSDFHIP_OK;
+    if (correctionOnly && cfg->ec_mode == MSDFHIP_EC_DISABLED)
+        return MSDFHIP_OK;
+    const int32_t gco[2] = { 0, nC };
+    MsdfHipBatch *b = NULL;
+    rc = msdfhip_batch_create(&b, 1, gco, co, points, types, colors);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    MsdfHipGlyph gd;
+    memcpy(gd.xf, xf, sizeof(gd.xf));
+    gd.out_offset = 0;
+    gd.row_stride = w*channels;                                  // device tile is tightly packed in memory-row order
+    gd.flip = flip ? 1 : 0;
+    const size_t n = (size_t) w*h*channels;
+    std::vector<float> tile(n);
+    std::vector<uint8_t> st(stencil ? (size_t) w*h : 0);
+    if (correctionOnly) {
+        for (int y = 0; y < h; ++y)
+            memcpy(&tile[(size_t) y*w*channels], pixels+(ptrdiff_t) rowStride*y, sizeof(float)*(size_t) w*channels);
+        MsdfHipGlyph *dGlyph = NULL;
+        float *dSrc = NULL, *dOut = NULL;
+        uint8_t *dSt = NULL;
+        hipError_t e = hipMalloc((void **) &dGlyph, sizeof(gd));
+        if (e == hipSuccess) e = hipMalloc((void **) &dSrc, n*sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **) &dOut, n*sizeof(float));
+        if (e == hipSuccess && stencil) e = hipMalloc((void **) &dSt, (size_t) w*h);
+        if (e == hipSuccess) e = hipMemcpy(dGlyph, &gd, sizeof(gd), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dSrc, tile.data(), n*sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            rc = runCorrection(b, channels, w, h, dGlyph, dSrc, dOut, dSt, *cfg, NULL);
+            if (rc == MSDFHIP_OK) {
+                e = hipStreamSynchronize(NULL);
+                if (e == hipSuccess) e = hipMemcpy(tile.data(), dOut, n*sizeof(float), hipMemcpyDeviceToHost);
+                if (e == hipSuccess && stencil) e = hipMemcpy(st.data(), dSt, (size_t) w*h, hipMemcpyDeviceToHost);
+            }
+        }
+        hipFree(dGlyph), hipFree(dSrc), hipFree(dOut), hipFree(dSt);
+        if (e != hipSuccess)
+            rc = fail(MSDFHIP_ERR_HIP, "msdfhip_error_correction: %s", hipGetErrorString(e));
+    } else
+        rc = msdfhip_batch_generate_host(b, mode, w, h, &gd, tile.data(), n, stencil ? st.data() : NULL, cfg);
+    msdfhip_batch_destroy(b);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    for (int y = 0; y < h; ++y)
+        memcpy(pixels+(ptrdiff_t) rowStride*y, &tile[(size_t) y*w*channels], sizeof(float)*(size_t) w*channels);
+    if (stencil)
+        memcpy(stencil, st.data(), st.size());
+    return MSDFHIP_OK;
+}
+
+int msdfhip_generate(int mode, float *pixels, int w, int h, int rowStride, int flip, const int32_t *co, int nC, const double *points,
+                     const uint8_t *types, const uint8_t *colors, const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil) {
+    if (mode < 1 || mode > 4)
+        return fail(MSDFHIP_ERR_INVALID, "mode %d (must be 1..4)", mode);
+    return singleShape(mode, channelsOf(mode), false, pixels, w, h, rowStride, flip, co, nC, points, types, colors, xf, cfg, stencil);
+}
+
+int msdfhip_generate_sdf(float *pixels, int w, int h, int rowStride, int flip, const int32_t *co, int nC, const double *points,
+                         const uint8_t *types, const uint8_t *colors, const double *xf, const MsdfHipConfig *cfg) {
+    return msdfhip_generate(MSDFHIP_MODE_SDF, pixels, w, h, rowStride, flip, co, nC, points, types, colors, xf, cfg, NULL);
+}
+
+int msdfhip_generate_psdf(float *pixels, int w, int h, int rowStride, int flip, const int32_t *co, int nC, const double *points,
+                          const uint8_t *types, const uint8_t *colors, const double *xf, const MsdfHipConfig *cfg) {
+    return msdfhip_generate(MSDFHIP_MODE_PSDF, pixels, w, h, rowStride, flip, co, nC, points, types, colors, xf, cfg, NULL);
+}
+
+int msdfhip_generate_msdf(float *pixels, int w, int h, int rowStride, int flip, const int32_t *co, int nC, const double *points,
+                          const uint8_t *types, const uint8_t *colors, const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil) {
+    return msdfhip_generate(MSDFHIP_MODE_MSDF, pixels, w, h, rowStride, flip, co, nC, points, types, colors, xf, cfg, stencil);
+}
+
+int msdfhip_generate_mtsdf(float *pixels, int w, int h, int rowStride, int flip, const int32_t *co, int nC, const double *points,
+                           const uint8_t *types, const uint8_t *colors, const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil) {
+    return msdfhip_generate(MSDFHIP_MODE_MTSDF, pixels, w, h, rowStride, flip, co, nC, points, types, colors, xf, cfg, stencil);
+}
+
+int msdfhip_error_correction(int channels, float *pixels, int w, int h, int rowStride, int flip, const int32_t *co, int nC, const double *points,
+                             const uint8_t *types, const uint8_t *colors, const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil) {
+    if (channels != 3 && channels != 4)
+        return fail(MSDFHIP_ERR_INVALID, "channels %d (must be 3 or 4)", channels);
+    return singleShape(channels, channels, true, pixels, w, h, rowStride, flip, co, nC, points, types, colors, xf, cfg, stencil);
+}
+
+int msdfhip_shape_distance(int selector, int overlap, const int32_t *co, int nC, const double *points, const uint8_t *types, const uint8_t *colors,
+                           int nPoints, const double *pts, double *out) {
+    if (selector < 1 || selector > 4 || nPoints < 0 || !co || !pts || !out)
+        return fail(MSDFHIP_ERR_INVALID, "bad arguments");
+    if (nPoints == 0)
+        return MSDFHIP_OK;
+    const int32_t gco[2] = { 0, nC };
+    MsdfHipBatch *b = NULL;
+    int rc = msdfhip_batch_create(&b, 1, gco, co, points, types, colors);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    const int nch = channelsOf(selector);
+    const size_t lds = overlap ? (size_t) b->maxContours*nch*WAVE*sizeof(double) : 0;
+    double *dPts = NULL, *dOut = NULL;
+    hipError_t e = hipSuccess;
+    if (lds > (size_t) gLdsLimit.load())
+        rc = fail(MSDFHIP_ERR_TOO_COMPLEX, "%d contours need %zu B of LDS", b->maxContours, lds);
+    if (rc == MSDFHIP_OK) {
+        e = hipMalloc((void **) &dPts, sizeof(double)*2*(size_t) nPoints);
+        if (e == hipSuccess) e = hipMalloc((void **) &dOut, sizeof(double)*4*(size_t) nPoints);
+        if (e == hipSuccess) e = hipMemcpy(dPts, pts, sizeof(double)*2*(size_t) nPoints, hipMemcpyHostToDevice);
+    }
+    if (rc == MSDFHIP_OK && e == hipSuccess) {
+        const dim3 grid((nPoints+WAVE-1)/WAVE), block(WAVE);
+        const BatchView v = viewOf(b);
+        #define LAUNCH_SD(S, O) do { rc = setLds(k_shape_distance<S, O>, lds); if (rc == MSDFHIP_OK) hipLaunchKernelGGL((k_shape_distance<S, O>), grid, block, lds, 0, v, nPoints, dPts, dOut); } while (0)
+        switch (selector*2+(overlap ? 1 : 0)) {
+            case 2: LAUNCH_SD(1, false); break;
+            case 3: LAUNCH_SD(1, true); break;
+            case 4: LAUNCH_SD(2, false); break;
+            case 5: LAUNCH_SD(2, true); break;
+            case 6: LAUNCH_SD(3, false); break;
+            case 7: LAUNCH_SD(3, true); break;
+            case 8: LAUNCH_SD(4, false); break;
+            default: LAUNCH_SD(4, true); break;
+        }
+        #undef LAUNCH_SD
+        if (rc == MSDFHIP_OK) {
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(NULL);
+            if (e == hipSuccess) e = hipMemcpy(out, dOut, sizeof(double)*4*(size_t) nPoints, hipMemcpyDeviceToHost);
+        }
+    }
+    hipFree(dPts), hipFree(dOut);
+    msdfhip_batch_destroy(b);
+    if (e != hipSuccess)
+        return fail(MSDFHIP_ERR_HIP, "msdfhip_shape_distance: %s", hipGetErrorString(e));
+    return rc;
+}
+
+// -------------------------------------------------------------------------------------------------------- timing hook
+
+int msdfhip_set_kernel_timing(int enable) {
+    gTiming.store(enable ? 1 : 0);
+    return MSDFHIP_OK;
+}
+
+int msdfhip_kernel_timing(double *avgDistance, double *avgCorrection, int *launches, int reset) {
+    std::lock_guard<std::mutex> lock(gTimingMutex);
+    double sum[2] = { 0, 0 };
+    int cnt[2] = { 0, 0 };
+    for (size_t i = 0; i < gTimed.size(); ++i) {
+        float ms = 0;
+        if (hipEventSynchronize(gTimed[i].b) == hipSuccess && hipEventElapsedTime(&ms, gTimed[i].a, gTimed[i].b) == hipSuccess) {
+            sum[gTimed[i].kind] += ms;
+            ++cnt[gTimed[i].kind];
+        }
+    }
+    if (avgDistance) *avgDistance = cnt[0] ? sum[0]/cnt[0] : 0;
+    if (avgCorrection) *avgCorrection = cnt[1] ? sum[1]/cnt[1] : 0;
+    if (launches) *launches = cnt[0];
+    if (reset) {
+        for (size_t i = 0; i < gTimed.size(); ++i) {
+            hipEventDestroy(gTimed[i].a);
+            hipEventDestroy(gTimed[i].b);
+        }
+        gTimed.clear();
+    }
+    return MSDFHIP_OK;
+}
+
+} // extern "C"

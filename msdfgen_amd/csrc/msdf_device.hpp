@@ -1,0 +1,590 @@
+// msdf_device.hpp -- per-texel math of the MI355X MSDF hot path (device functions; also compilable for the host).
+//
+// Everything the reference evaluates per pixel is restructured around a pre-digested per-edge record (EdgeRec): all
+// pixel-independent quantities (end tangents, corner bisectors, polynomial coefficients, divisions by constants) are computed
+// once per edge by the prep kernel with the very same IEEE operations the reference uses per pixel, so results stay
+// bit-identical while the per-pixel instruction count drops. fp64 throughout, no FMA contraction (-ffp-contract=off).
+//
+// Reference semantics restated: ShapeDistanceFinder::oneShotDistance (core/ShapeDistanceFinder.hpp:36-58) -- the EdgeCache
+// pruning of distance() is a pure CPU optimisation.
+#pragma once
+
+#include <stdint.h>
+#include <math.h>
+#include <float.h>
+
+#if defined(__HIPCC__)
+#define MSDF_HD __host__ __device__ inline
+#define MSDF_NOINLINE __attribute__((noinline))
+#define MSDF_NOUNROLL _Pragma("clang loop unroll(disable)")
+#define MSDF_UNROLL _Pragma("unroll")
+#else
+#define MSDF_HD inline
+#define MSDF_NOINLINE
+#define MSDF_NOUNROLL
+#define MSDF_UNROLL
+#endif
+
+namespace msdfhip {
+
+// ----------------------------------------------------------------------------------------------------- edge record
+
+enum : int32_t {
+    REC_A_ZERO = 1,   // direction(0) has zero length: normalize() yields (0,1), normalize(true) yields (0,0) (Vector2.hpp:42-46)
+    REC_B_ZERO = 2,   // same for direction(1)
+    REC_NORMED = 4,   // quadratic: a != 0 && |b/a| < 1e6 -> solveCubicNormed, else solveQuadratic (equation-solver.cpp:63-70)
+    REC_CORNER = 8    // colour changes between the previous edge and this one (MSDFErrorCorrection.cpp:127-129)
+};
+
+struct alignas(16) EdgeRec {
+    double p[8];      // control points p0..p3
+    double ab[2];     // p1-p0
+    double br[2];     // (p2-p1)-ab                         (quadratic, cubic)
+    double as_[2];    // ((p3-p2)-(p2-p1))-br               (cubic)
+    double ep0[2];    // direction(0)                       (edge-segments.cpp:121-139)
+    double ep1[2];    // direction(1)
+    double e0dot;     // dot(ep0, ep0)
+    double e1dot;     // dot(ep1, ep1)
+    double aDirN[2];  // direction(0).normalize(true)       (edge-selectors.cpp:193)
+    double bDirN[2];  // direction(1).normalize(true)       (edge-selectors.cpp:194)
+    double na[2];     // (prevDirN+aDirN).normalize(true)   (edge-selectors.cpp:197)
+    double nb[2];     // (bDirN+nextDirN).normalize(true)   (edge-selectors.cpp:198)
+    double k[6];      // linear:    abab, orthoN.x, orthoN.y, abN.x, abN.y
+                      // quadratic: a, b, 2*dot(ab,ab), b/a, (b/a)^2, (b/a)*(1/3.)
+                      // cubic:     3*ab.x, 3*ab.y, 6*br.x, 6*br.y
+    int32_t type;     // 1, 2, 3
+    int32_t color;    // EdgeColor bitmask
+    int32_t flags;    // REC_*
+    int32_t contour;  // contour index within the batch
+};
+static_assert(sizeof(EdgeRec) == 288, "EdgeRec layout");
+
+struct V2 { double x, y; };
+
+MSDF_HD V2 mk(double x, double y) { V2 r; r.x = x; r.y = y; return r; }
+MSDF_HD V2 operator+(V2 a, V2 b) { return mk(a.x+b.x, a.y+b.y); }
+MSDF_HD V2 operator-(V2 a, V2 b) { return mk(a.x-b.x, a.y-b.y); }
+MSDF_HD V2 operator-(V2 a) { return mk(-a.x, -a.y); }
+MSDF_HD V2 operator*(double a, V2 b) { return mk(a*b.x, a*b.y); }
+MSDF_HD double dot(V2 a, V2 b) { return a.x*b.x+a.y*b.y; }
+MSDF_HD double cross(V2 a, V2 b) { return a.x*b.y-a.y*b.x; }
+MSDF_HD double vlen(V2 a) { return sqrt(a.x*a.x+a.y*a.y); }
+MSDF_HD V2 ld(const double *p) { return mk(p[0], p[1]); }
+
+MSDF_HD V2 normalize(V2 a, bool allowZero) {                                 // Vector2.hpp:42-46
+    double len = vlen(a);
+    if (len != 0)
+        return mk(a.x/len, a.y/len);
+    return mk(0, allowZero ? 0. : 1.);
+}
+
+MSDF_HD V2 orthonormalFalse(V2 a) {                                          // getOrthonormal(false, false), Vector2.hpp:54-58
+    double len = vlen(a);
+    if (len != 0)
+        return mk(a.y/len, -a.x/len);
+    return mk(0, -1.);
+}
+
+MSDF_HD V2 mixv(V2 a, V2 b, double w) { return (1.-w)*a+w*b; }               // arithmetics.hpp:27-31
+MSDF_HD double nonZeroSign(double n) { return n > 0 ? 1. : -1.; }            // arithmetics.hpp:59-61 (int 2*(n>0)-1, exact in double)
+MSDF_HD double dmin(double a, double b) { return b < a ? b : a; }
+MSDF_HD double dmax(double a, double b) { return a < b ? b : a; }
+MSDF_HD double median(double a, double b, double c) { return dmax(dmin(a, b), dmin(dmax(a, b), c)); }
+MSDF_HD float fmin_(float a, float b) { return b < a ? b : a; }
+MSDF_HD float fmax_(float a, float b) { return a < b ? b : a; }
+MSDF_HD float medianf(float a, float b, float c) { return fmax_(fmin_(a, b), fmin_(fmax_(a, b), c)); }
+MSDF_HD float mixf(float a, float b, double w) { return (float) ((1.-w)*a+w*b); } // arithmetics.hpp:27-31 (T=float, S=double)
+
+// ------------------------------------------------------------------------------------------------- equation solver
+
+MSDF_HD int solveQuadratic(double x[2], double a, double b, double c) {      // equation-solver.cpp:9-32
+    if (a == 0 || fabs(b) > 1e12*fabs(a)) {
+        if (b == 0) {
+            if (c == 0)
+                return -1;
+            return 0;
+        }
+        x[0] = -c/b;
+        return 1;
+    }
+    double dscr = b*b-4*a*c;
+    if (dscr > 0) {
+        dscr = sqrt(dscr);
+        x[0] = (-b+dscr)/(2*a);
+        x[1] = (-b-dscr)/(2*a);
+        return 2;
+    } else if (dscr == 0) {
+        x[0] = -b/(2*a);
+        return 1;
+    } else
+        return 0;
+}
+
+// solveCubicNormed (equation-solver.cpp:34-61) with the pixel-independent a, a*a and a*(1/3.) taken from the edge record.
+MSDF_HD int solveCubicNormedPre(double x[3], double a, double a2, double a3, double b, double c) {
+    double q = 1/9.*(a2-3*b);
+    double r = 1/54.*(a*(2*a2-9*b)+27*c);
+    double r2 = r*r;
+    double q3 = q*q*q;
+    if (r2 < q3) {
+        double t = r/sqrt(q3);
+        if (t < -1) t = -1;
+        if (t > 1) t = 1;
+        t = acos(t);
+        q = -2*sqrt(q);
+        x[0] = q*cos(1/3.*t)-a3;
+        x[1] = q*cos(1/3.*(t+2*M_PI))-a3;
+        x[2] = q*cos(1/3.*(t-2*M_PI))-a3;
+        return 3;
+    } else {
+        double u = (r < 0 ? 1. : -1.)*pow(fabs(r)+sqrt(r2-q3), 1/3.);
+        double v = u == 0 ? 0 : q/u;
+        x[0] = (u+v)-a3;
+        if (u == v || fabs(u-v) < 1e-12*fabs(u+v)) {
+            x[1] = -.5*(u+v)-a3;
+            return 2;
+        }
+        return 1;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------- signed distance
+
+struct SD { double d, dot; };                                                // SignedDistance.hpp:10-20
+
+MSDF_HD bool sdLess(SD a, SD b) {                                            // SignedDistance.hpp:22-24
+    return fabs(a.d) < fabs(b.d) || (fabs(a.d) == fabs(b.d) && a.dot < b.dot);
+}
+
+MSDF_HD V2 dirN0(const EdgeRec &e) { return (e.flags&REC_A_ZERO) ? mk(0, 1) : ld(e.aDirN); } // direction(0).normalize()
+MSDF_HD V2 dirN1(const EdgeRec &e) { return (e.flags&REC_B_ZERO) ? mk(0, 1) : ld(e.bDirN); } // direction(1).normalize()
+
+MSDF_HD SD sdLinear(const EdgeRec &e, V2 o, double &param) {                 // edge-segments.cpp:173-185
+    V2 p0 = ld(e.p), p1 = ld(e.p+2), ab = ld(e.ab);
+    V2 aq = o-p0;
+    param = dot(aq, ab)/e.k[0];
+    V2 eq = (param > .5 ? p1 : p0)-o;
+    double endpointDistance = vlen(eq);
+    if (param > 0 && param < 1) {
+        double orthoDistance = dot(mk(e.k[1], e.k[2]), aq);
+        if (fabs(orthoDistance) < endpointDistance) {
+            SD r = { orthoDistance, 0 };
+            return r;
+        }
+    }
+    SD r = { nonZeroSign(cross(aq, ab))*endpointDistance, fabs(dot(mk(e.k[3], e.k[4]), normalize(eq, false))) };
+    return r;
+}
+
+MSDF_HD SD sdQuadratic(const EdgeRec &e, V2 o, double &param) {              // edge-segments.cpp:187-226
+    V2 p0 = ld(e.p), p1 = ld(e.p+2), p2 = ld(e.p+4), ab = ld(e.ab), br = ld(e.br);
+    V2 qa = p0-o;
+    double c = e.k[2]+dot(qa, br);
+    double d = dot(qa, ab);
+    double t[3];
+    int solutions;
+    if (e.flags&REC_NORMED)                                                   // solveCubic, equation-solver.cpp:63-70
+        solutions = solveCubicNormedPre(t, e.k[3], e.k[4], e.k[5], c/e.k[0], d/e.k[0]);
+    else
+        solutions = solveQuadratic(t, e.k[1], c, d);
+
+    V2 epDir = ld(e.ep0);
+    double minDistance = nonZeroSign(cross(epDir, qa))*vlen(qa);
+    param = -dot(qa, epDir)/e.e0dot;
+    {
+        V2 qb = p2-o;
+        double distance = vlen(qb);
+        if (distance < fabs(minDistance)) {
+            epDir = ld(e.ep1);
+            minDistance = nonZeroSign(cross(epDir, qb))*distance;
+            param = dot(o-p1, epDir)/e.e1dot;
+        }
+    }
+    for (int i = 0; i < solutions; ++i) {
+        if (t[i] > 0 && t[i] < 1) {
+            V2 qe = qa+(2*t[i])*ab+(t[i]*t[i])*br;
+            double distance = vlen(qe);
+            if (distance <= fabs(minDistance)) {
+                minDistance = nonZeroSign(cross(ab+t[i]*br, qe))*distance;
+                param = t[i];
+            }
+        }
+    }
+    SD r;
+    r.d = minDistance;
+    if (param >= 0 && param <= 1)
+        r.dot = 0;
+    else if (param < .5)
+        r.dot = fabs(dot(dirN0(e), normalize(qa, false)));
+    else
+        r.dot = fabs(dot(dirN1(e), normalize(p2-o, false)));
+    return r;
+}
+
+MSDF_HD SD sdCubic(const EdgeRec &e, V2 o, double &param) {                  // edge-segments.cpp:228-277
+    V2 p0 = ld(e.p), p3 = ld(e.p+6), ab = ld(e.ab), br = ld(e.br), as = ld(e.as_);
+    V2 ab3 = mk(e.k[0], e.k[1]), br6 = mk(e.k[2], e.k[3]);
+    V2 qa = p0-o;
+    V2 epDir = ld(e.ep0);
+    double minDistance = nonZeroSign(cross(epDir, qa))*vlen(qa);
+    param = -dot(qa, epDir)/e.e0dot;
+    {
+        V2 qb = p3-o;
+        double distance = vlen(qb);
+        if (distance < fabs(minDistance)) {
+            epDir = ld(e.ep1);
+            minDistance = nonZeroSign(cross(epDir, qb))*distance;
+            param = dot(epDir-qb, epDir)/e.e1dot;
+        }
+    }
+    for (int i = 0; i <= 4; ++i) {                                            // MSDFGEN_CUBIC_SEARCH_STARTS, edge-segments.h:11
+        double t = 1./4*i;
+        V2 qe = qa+(3*t)*ab+(3*t*t)*br+(t*t*t)*as;
+        V2 d1 = ab3+(6*t)*br+(3*t*t)*as;
+        V2 d2 = br6+(6*t)*as;
+        double improvedT = t-dot(qe, d1)/(dot(d1, d1)+dot(qe, d2));
+        if (improvedT > 0 && improvedT < 1) {
+            int remainingSteps = 4;                                           // MSDFGEN_CUBIC_SEARCH_STEPS, edge-segments.h:12
+            do {
+                t = improvedT;
+                qe = qa+(3*t)*ab+(3*t*t)*br+(t*t*t)*as;
+                d1 = ab3+(6*t)*br+(3*t*t)*as;
+                if (!--remainingSteps)
+                    break;
+                d2 = br6+(6*t)*as;
+                improvedT = t-dot(qe, d1)/(dot(d1, d1)+dot(qe, d2));
+            } while (improvedT > 0 && improvedT < 1);
+            double distance = vlen(qe);
+            if (distance < fabs(minDistance)) {
+                minDistance = nonZeroSign(cross(d1, qe))*distance;
+                param = t;
+            }
+        }
+    }
+    SD r;
+    r.d = minDistance;
+    if (param >= 0 && param <= 1)
+        r.dot = 0;
+    else if (param < .5)
+        r.dot = fabs(dot(dirN0(e), normalize(qa, false)));
+    else
+        r.dot = fabs(dot(dirN1(e), normalize(p3-o, false)));
+    return r;
+}
+
+MSDF_HD SD signedDistance(const EdgeRec &e, V2 o, double &param) {
+    if (e.type == 1)
+        return sdLinear(e, o, param);
+    if (e.type == 2)
+        return sdQuadratic(e, o, param);
+    return sdCubic(e, o, param);
+}
+
+MSDF_HD V2 endPoint(const EdgeRec &e) { return ld(e.p+2*e.type); }           // point(1) == last control point
+
+// EdgeSegment::distanceToPerpendicularDistance, edge-segments.cpp:28-52
+MSDF_HD void distanceToPerpendicular(const EdgeRec &e, SD &distance, V2 o, double param) {
+    if (param < 0) {
+        V2 dir = dirN0(e);
+        V2 aq = o-ld(e.p);
+        double ts = dot(aq, dir);
+        if (ts < 0) {
+            double perp = cross(aq, dir);
+            if (fabs(perp) <= fabs(distance.d)) {
+                distance.d = perp;
+                distance.dot = 0;
+            }
+        }
+    } else if (param > 1) {
+        V2 dir = dirN1(e);
+        V2 bq = o-endPoint(e);
+        double ts = dot(bq, dir);
+        if (ts > 0) {
+            double perp = cross(bq, dir);
+            if (fabs(perp) <= fabs(distance.d)) {
+                distance.d = perp;
+                distance.dot = 0;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------- selectors
+
+struct PB {                              // PerpendicularDistanceSelectorBase, edge-selectors.h:40-70
+    double td, tdot;                     // minTrueDistance
+    double neg, pos;                     // min negative / positive perpendicular distance
+    double param;                        // nearEdgeParam
+    int near;                            // record index of nearEdge, -1 = NULL
+};
+
+MSDF_HD void pbInit(PB &b) {             // edge-selectors.cpp:54 followed by reset(delta): -DBL_MAX-delta == -DBL_MAX for any realistic delta
+    b.td = -DBL_MAX, b.tdot = 0;
+    b.neg = -DBL_MAX, b.pos = DBL_MAX;
+    b.param = 0;
+    b.near = -1;
+}
+
+MSDF_HD void pbAddTrue(PB &b, int idx, SD sd, double param) {                // edge-selectors.cpp:81-87
+    SD cur = { b.td, b.tdot };
+    if (sdLess(sd, cur)) {
+        b.td = sd.d, b.tdot = sd.dot;
+        b.near = idx;
+        b.param = param;
+    }
+}
+
+MSDF_HD void pbAddPerp(PB &b, double d) {                                    // edge-selectors.cpp:89-94
+    if (d <= 0 && d > b.neg)
+        b.neg = d;
+    if (d >= 0 && d < b.pos)
+        b.pos = d;
+}
+
+MSDF_HD void pbMerge(PB &b, const PB &o) {                                   // edge-selectors.cpp:96-106
+    SD a = { o.td, o.tdot }, c = { b.td, b.tdot };
+    if (sdLess(a, c)) {
+        b.td = o.td, b.tdot = o.tdot;
+        b.near = o.near;
+        b.param = o.param;
+    }
+    if (o.neg > b.neg)
+        b.neg = o.neg;
+    if (o.pos < b.pos)
+        b.pos = o.pos;
+}
+
+MSDF_HD double pbCompute(const PB &b, const EdgeRec *rec, V2 o) {            // edge-selectors.cpp:108-117
+    double m = b.td < 0 ? b.neg : b.pos;
+    if (b.near >= 0) {
+        SD sd = { b.td, b.tdot };
+        distanceToPerpendicular(rec[b.near], sd, o, b.param);
+        if (fabs(sd.d) < fabs(m))
+            m = sd.d;
+    }
+    return m;
+}
+
+MSDF_HD bool getPerpendicularDistance(double &distance, V2 ep, V2 edgeDir) { // edge-selectors.cpp:42-52
+    double ts = dot(ep, edgeDir);
+    if (ts > 0) {
+        double perp = cross(ep, edgeDir);
+        if (fabs(perp) < fabs(distance)) {
+            distance = perp;
+            return true;
+        }
+    }
+    return false;
+}
+
+// SEL: 1 TrueDistanceSelector, 2 PerpendicularDistanceSelector, 3 MultiDistanceSelector, 4 MultiAndTrueDistanceSelector
+template <int SEL> struct SelTraits { enum { NPB = SEL == 1 ? 0 : SEL == 2 ? 1 : 3, NCH = SEL <= 2 ? 1 : SEL }; };
+
+template <int SEL>
+struct Selector {
+    SD m;                                        // TrueDistanceSelector::minDistance (SEL == 1)
+    PB c[SelTraits<SEL>::NPB ? SelTraits<SEL>::NPB : 1];
+};
+
+template <int SEL>
+MSDF_HD void selInit(Selector<SEL> &s) {
+    s.m.d = -DBL_MAX, s.m.dot = 0;
+    for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
+        pbInit(s.c[i]);
+}
+
+// addEdge: edge-selectors.cpp:19-29 (true), :129-160 (perpendicular), :174-227 (multi)
+template <int SEL>
+MSDF_HD void selAddEdge(Selector<SEL> &s, const EdgeRec &e, int idx, V2 o) {
+    if (SEL == 1) {
+        double dummy;
+        SD sd = signedDistance(e, o, dummy);
+        if (sdLess(sd, s.m))
+            s.m = sd;
+        return;
+    }
+    const int mask = SEL == 2 ? 1 : (e.color&7);
+    if (!mask)
+        return;                                  // MultiDistanceSelector ignores BLACK edges (edge-selectors.cpp:175-179)
+    double param;
+    SD sd = signedDistance(e, o, param);
+    for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
+        if (mask&(1<<i))
+            pbAddTrue(s.c[i], idx, sd, param);
+    V2 ap = o-ld(e.p);
+    V2 bp = o-endPoint(e);
+    double add = dot(ap, ld(e.na));
+    double bdd = -dot(bp, ld(e.nb));
+    if (add > 0) {
+        double pd = sd.d;
+        if (getPerpendicularDistance(pd, ap, -ld(e.aDirN))) {
+            pd = -pd;
+            for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
+                if (mask&(1<<i))
+                    pbAddPerp(s.c[i], pd);
+        }
+    }
+    if (bdd > 0) {
+        double pd = sd.d;
+        if (getPerpendicularDistance(pd, bp, ld(e.bDirN))) {
+            for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
+                if (mask&(1<<i))
+                    pbAddPerp(s.c[i], pd);
+        }
+    }
+}
+
+template <int SEL>
+MSDF_HD void selMerge(Selector<SEL> &s, const Selector<SEL> &o) {            // edge-selectors.cpp:31-34, 229-233
+    if (SEL == 1) {
+        if (sdLess(o.m, s.m))
+            s.m = o.m;
+        return;
+    }
+    for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
+        pbMerge(s.c[i], o.c[i]);
+}
+
+// distance(): edge-selectors.cpp:36, :162, :235-260. out has NCH entries.
+template <int SEL>
+MSDF_HD void selDistance(const Selector<SEL> &s, const EdgeRec *rec, V2 o, double *out) {
+    if (SEL == 1) {
+        out[0] = s.m.d;
+        return;
+    }
+    for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
+        out[i] = pbCompute(s.c[i], rec, o);
+    if (SEL == 4) {                                                           // trueDistance(), :243-250
+        SD t = { s.c[0].td, s.c[0].tdot };
+        SD g = { s.c[SEL == 4 ? 1 : 0].td, s.c[SEL == 4 ? 1 : 0].tdot };
+        SD b = { s.c[SEL == 4 ? 2 : 0].td, s.c[SEL == 4 ? 2 : 0].tdot };
+        if (sdLess(g, t))
+            t = g;
+        if (sdLess(b, t))
+            t = b;
+        out[SEL == 4 ? 3 : 0] = t.d;
+    }
+}
+
+template <int SEL>
+MSDF_HD double resolve(const double *d) {                                    // contour-combiners.cpp:26-32
+    return SEL >= 3 ? median(d[0], d[SEL >= 3 ? 1 : 0], d[SEL >= 3 ? 2 : 0]) : d[0];
+}
+
+// ------------------------------------------------------------------------------------------------- shape distance
+//
+// rec:      pre-digested records of this glyph's edges, contour by contour, each contour already in the reference's visit order
+//           (last edge first, ShapeDistanceFinder.hpp:45-57); indexed relative to the glyph's first edge.
+// coff:     the glyph's slice of the global contour_offsets (C+1 entries); e0 = coff[0].
+// windings: Contour::winding per contour (contour-combiners.cpp:57-63).
+// res:      per-lane scratch for the per-contour distances of the overlapping combiner, element (c, ch) at res[(c*NCH+ch)*rstride].
+
+template <int SEL>
+MSDF_HD void shapeDistanceSimple(const EdgeRec *rec, const int32_t *coff, int C, V2 o, double *out) { // contour-combiners.cpp:34-50
+    Selector<SEL> sel;
+    selInit(sel);
+    const int e0 = coff[0];
+    const int nE = coff[C]-e0;
+    for (int i = 0; i < nE; ++i)
+        selAddEdge(sel, rec[i], i, o);
+    selDistance(sel, rec, o, out);
+}
+
+template <int SEL>
+MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const int32_t *coff, const int8_t *windings, int C, V2 o, double *res, int rstride, double *out) {
+    enum { NCH = SelTraits<SEL>::NCH };                                      // OverlappingContourCombiner::distance, contour-combiners.cpp:77-134
+    const int e0 = coff[0];
+    Selector<SEL> shapeSel, innerSel, outerSel;
+    selInit(shapeSel);
+    selInit(innerSel);
+    selInit(outerSel);
+    for (int c = 0; c < C; ++c) {
+        Selector<SEL> sel;
+        selInit(sel);
+        const int b = coff[c]-e0, e = coff[c+1]-e0;
+        for (int i = b; i < e; ++i)
+            selAddEdge(sel, rec[i], i, o);
+        double d[NCH];
+        selDistance(sel, rec, o, d);
+        for (int ch = 0; ch < NCH; ++ch)
+            res[(c*NCH+ch)*rstride] = d[ch];
+        const double m = resolve<SEL>(d);
+        const int w = windings[c];
+        selMerge(shapeSel, sel);
+        if (w > 0 && m >= 0)
+            selMerge(innerSel, sel);
+        if (w < 0 && m <= 0)
+            selMerge(outerSel, sel);
+    }
+    double shapeD[NCH], innerD[NCH], outerD[NCH];
+    selDistance(shapeSel, rec, o, shapeD);
+    selDistance(innerSel, rec, o, innerD);
+    selDistance(outerSel, rec, o, outerD);
+    const double innerScalar = resolve<SEL>(innerD);
+    const double outerScalar = resolve<SEL>(outerD);
+    double dist[NCH];
+    for (int ch = 0; ch < NCH; ++ch)
+        dist[ch] = -DBL_MAX;
+    int winding = 0;
+    if (innerScalar >= 0 && fabs(innerScalar) <= fabs(outerScalar)) {
+        for (int ch = 0; ch < NCH; ++ch)
+            dist[ch] = innerD[ch];
+        winding = 1;
+        for (int c = 0; c < C; ++c)
+            if (windings[c] > 0) {
+                double cd[NCH];
+                for (int ch = 0; ch < NCH; ++ch)
+                    cd[ch] = res[(c*NCH+ch)*rstride];
+                const double cm = resolve<SEL>(cd);
+                if (fabs(cm) < fabs(outerScalar) && cm > resolve<SEL>(dist))
+                    for (int ch = 0; ch < NCH; ++ch)
+                        dist[ch] = cd[ch];
+            }
+    } else if (outerScalar <= 0 && fabs(outerScalar) < fabs(innerScalar)) {
+        for (int ch = 0; ch < NCH; ++ch)
+            dist[ch] = outerD[ch];
+        winding = -1;
+        for (int c = 0; c < C; ++c)
+            if (windings[c] < 0) {
+                double cd[NCH];
+                for (int ch = 0; ch < NCH; ++ch)
+                    cd[ch] = res[(c*NCH+ch)*rstride];
+                const double cm = resolve<SEL>(cd);
+                if (fabs(cm) < fabs(innerScalar) && cm < resolve<SEL>(dist))
+                    for (int ch = 0; ch < NCH; ++ch)
+                        dist[ch] = cd[ch];
+            }
+    } else {
+        for (int ch = 0; ch < NCH; ++ch)
+            out[ch] = shapeD[ch];
+        return;
+    }
+    for (int c = 0; c < C; ++c)
+        if (windings[c] != winding) {
+            double cd[NCH];
+            for (int ch = 0; ch < NCH; ++ch)
+                cd[ch] = res[(c*NCH+ch)*rstride];
+            const double cm = resolve<SEL>(cd), dm = resolve<SEL>(dist);
+            if (cm*dm >= 0 && fabs(cm) < fabs(dm))
+                for (int ch = 0; ch < NCH; ++ch)
+                    dist[ch] = cd[ch];
+        }
+    if (resolve<SEL>(dist) == resolve<SEL>(shapeD))
+        for (int ch = 0; ch < NCH; ++ch)
+            dist[ch] = shapeD[ch];
+    for (int ch = 0; ch < NCH; ++ch)
+        out[ch] = dist[ch];
+}
+
+// -------------------------------------------------------------------------------------------------------- transform
+
+struct Xform {
+    double sx, sy, tx, ty;       // Projection (core/Projection.h:31-33)
+    double mapScale, mapTranslate; // DistanceMapping (core/DistanceMapping.h:28-30)
+};
+
+MSDF_HD V2 unproject(const Xform &t, V2 c) { return mk(c.x/t.sx-t.tx, c.y/t.sy-t.ty); }         // Projection.cpp:14-16
+MSDF_HD V2 project(const Xform &t, V2 c) { return mk(t.sx*(c.x+t.tx), t.sy*(c.y+t.ty)); }       // Projection.cpp:10-12
+MSDF_HD float mapDistance(const Xform &t, double d) { return (float) (t.mapScale*(d+t.mapTranslate)); } // DistanceMapping.cpp:15-17, msdfgen.cpp:20-48
+
+} // namespace msdfhip

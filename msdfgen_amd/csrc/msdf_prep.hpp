@@ -1,0 +1,162 @@
+// msdf_prep.hpp -- once-per-upload digestion of the raw CSR edge buffer into EdgeRec records and contour windings.
+// Every quantity is produced with the same IEEE operations, in the same order, that the reference applies per pixel
+// (edge-selectors.cpp:189-198, edge-segments.cpp:121-139, 173-277, equation-solver.cpp:63-70), so hoisting them is exact.
+#pragma once
+
+#include "msdf_device.hpp"
+
+namespace msdfhip {
+
+struct RawEdge {
+    V2 p[4];
+    int type, color;
+};
+
+MSDF_HD RawEdge loadRaw(const double *points, const uint8_t *types, const uint8_t *colors, int e) {
+    RawEdge r;
+    const double *p = points+8*(size_t) e;
+    for (int i = 0; i < 4; ++i)
+        r.p[i] = mk(p[2*i], p[2*i+1]);
+    r.type = types[e];
+    r.color = colors[e];
+    return r;
+}
+
+MSDF_HD bool nonzero(V2 a) { return a.x != 0 || a.y != 0; }
+
+MSDF_HD V2 rawDirection(const RawEdge &e, double t) {                         // edge-segments.cpp:121-139
+    if (e.type == 1)
+        return e.p[1]-e.p[0];
+    if (e.type == 2) {
+        V2 tangent = mixv(e.p[1]-e.p[0], e.p[2]-e.p[1], t);
+        if (!nonzero(tangent))
+            return e.p[2]-e.p[0];
+        return tangent;
+    }
+    V2 tangent = mixv(mixv(e.p[1]-e.p[0], e.p[2]-e.p[1], t), mixv(e.p[2]-e.p[1], e.p[3]-e.p[2], t), t);
+    if (!nonzero(tangent)) {
+        if (t == 0) return e.p[2]-e.p[0];
+        if (t == 1) return e.p[3]-e.p[1];
+    }
+    return tangent;
+}
+
+MSDF_HD V2 rawPoint(const RawEdge &e, double t) {                             // edge-segments.cpp:108-119
+    if (e.type == 1)
+        return mixv(e.p[0], e.p[1], t);
+    if (e.type == 2)
+        return mixv(mixv(e.p[0], e.p[1], t), mixv(e.p[1], e.p[2], t), t);
+    V2 p12 = mixv(e.p[1], e.p[2], t);
+    return mixv(mixv(mixv(e.p[0], e.p[1], t), p12, t), mixv(p12, mixv(e.p[2], e.p[3], t), t), t);
+}
+
+MSDF_HD void st(double *dst, V2 v) { dst[0] = v.x, dst[1] = v.y; }
+
+// Builds the record of edge `cur` whose cyclic neighbours in its contour are `prev` and `next`.
+MSDF_HD void buildRecord(EdgeRec &r, const RawEdge &prev, const RawEdge &cur, const RawEdge &next, int contour) {
+    for (int i = 0; i < 4; ++i)
+        st(r.p+2*i, i <= cur.type ? cur.p[i] : mk(0, 0));
+    for (int i = 0; i < 6; ++i)
+        r.k[i] = 0;
+    const V2 ab = cur.p[1]-cur.p[0];
+    V2 br = mk(0, 0), as = mk(0, 0);
+    if (cur.type >= 2)
+        br = cur.p[2]-cur.p[1]-ab;
+    if (cur.type == 3)
+        as = (cur.p[3]-cur.p[2])-(cur.p[2]-cur.p[1])-br;
+    st(r.ab, ab);
+    st(r.br, br);
+    st(r.as_, as);
+    const V2 ep0 = rawDirection(cur, 0), ep1 = rawDirection(cur, 1);
+    st(r.ep0, ep0);
+    st(r.ep1, ep1);
+    r.e0dot = dot(ep0, ep0);
+    r.e1dot = dot(ep1, ep1);
+    const V2 aDir = normalize(ep0, true), bDir = normalize(ep1, true);        // edge-selectors.cpp:193-194
+    const V2 prevDir = normalize(rawDirection(prev, 1), true);               // :195
+    const V2 nextDir = normalize(rawDirection(next, 0), true);               // :196
+    st(r.aDirN, aDir);
+    st(r.bDirN, bDir);
+    st(r.na, normalize(prevDir+aDir, true));                                  // :197
+    st(r.nb, normalize(bDir+nextDir, true));                                  // :198
+    int flags = 0;
+    if (vlen(ep0) == 0)
+        flags |= REC_A_ZERO;
+    if (vlen(ep1) == 0)
+        flags |= REC_B_ZERO;
+    if (cur.type == 1) {                                                      // edge-segments.cpp:173-185
+        r.k[0] = dot(ab, ab);
+        const V2 on = orthonormalFalse(ab), abn = normalize(ab, false);
+        r.k[1] = on.x, r.k[2] = on.y;
+        r.k[3] = abn.x, r.k[4] = abn.y;
+    } else if (cur.type == 2) {                                               // edge-segments.cpp:191-193, equation-solver.cpp:63-70, 34-39
+        const double a = dot(br, br);
+        const double b = 3*dot(ab, br);
+        r.k[0] = a;
+        r.k[1] = b;
+        r.k[2] = 2*dot(ab, ab);
+        if (a != 0) {
+            const double bn = b/a;
+            if (fabs(bn) < 1e6) {
+                flags |= REC_NORMED;
+                r.k[3] = bn;
+                r.k[4] = bn*bn;
+                r.k[5] = bn*(1/3.);
+            }
+        }
+    } else {                                                                  // edge-segments.cpp:247-249
+        st(r.k, 3*ab);
+        st(r.k+2, 6*br);
+    }
+    const int common = prev.color&cur.color;                                  // MSDFErrorCorrection.cpp:127-129
+    if (!(common&(common-1)))
+        flags |= REC_CORNER;
+    r.type = cur.type;
+    r.color = cur.color;
+    r.flags = flags;
+    r.contour = contour;
+}
+
+// Record slot r (global, = contour start + visit position) -> natural edge index. Visit order: last, first, ..., last-1.
+MSDF_HD int visitToEdge(int start, int n, int v) { return start+(v == 0 ? n-1 : v-1); }
+
+MSDF_HD void prepRecord(EdgeRec *recs, int slot, int contour, const int32_t *contourOffsets, const double *points, const uint8_t *types, const uint8_t *colors) {
+    const int start = contourOffsets[contour], n = contourOffsets[contour+1]-start;
+    const int e = visitToEdge(start, n, slot-start);
+    const int prev = start+(e-start+n-1)%n, next = start+(e-start+1)%n;
+    buildRecord(recs[slot], loadRaw(points, types, colors, prev), loadRaw(points, types, colors, e), loadRaw(points, types, colors, next), contour);
+}
+
+MSDF_HD double shoelace(V2 a, V2 b) { return (b.x-a.x)*(a.y+b.y); }           // Contour.cpp:7-9
+
+MSDF_HD int contourWinding(int contour, const int32_t *contourOffsets, const double *points, const uint8_t *types, const uint8_t *colors) { // Contour.cpp:57-81
+    const int begin = contourOffsets[contour], end = contourOffsets[contour+1];
+    const int n = end-begin;
+    if (n <= 0)
+        return 0;
+    double total = 0;
+    if (n == 1) {
+        RawEdge e = loadRaw(points, types, colors, begin);
+        V2 a = rawPoint(e, 0), b = rawPoint(e, 1/3.), c = rawPoint(e, 2/3.);
+        total += shoelace(a, b);
+        total += shoelace(b, c);
+        total += shoelace(c, a);
+    } else if (n == 2) {
+        RawEdge e0 = loadRaw(points, types, colors, begin), e1 = loadRaw(points, types, colors, begin+1);
+        V2 a = rawPoint(e0, 0), b = rawPoint(e0, .5), c = rawPoint(e1, 0), d = rawPoint(e1, .5);
+        total += shoelace(a, b);
+        total += shoelace(b, c);
+        total += shoelace(c, d);
+        total += shoelace(d, a);
+    } else {
+        V2 prev = rawPoint(loadRaw(points, types, colors, end-1), 0);
+        for (int i = begin; i < end; ++i) {
+            V2 cur = rawPoint(loadRaw(points, types, colors, i), 0);
+            total += shoelace(prev, cur);
+            prev = cur;
+        }
+    }
+    return (0 < total)-(total < 0);
+}
+
+} // namespace msdfhip

@@ -1,0 +1,64 @@
+"""Binding for tests/hostemu (the product's device headers compiled for the host; logic check only, see hostemu.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from msdfgen_amd.shape import distance_mapping
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostemu")
+SO = os.path.join(HERE, "libhostemu.so")
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "msdfgen_amd", "csrc")
+
+
+def build():
+    srcs = [os.path.join(HERE, "hostemu.cpp")]+[os.path.join(CSRC, f) for f in ("msdf_device.hpp", "msdf_prep.hpp", "msdf_ec.hpp")]
+    if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", SO, srcs[0]], check=True)
+    return SO
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Emu:
+    def __init__(self):
+        self.lib = C.CDLL(build())
+
+    def _shape(self, s):
+        co = np.ascontiguousarray(s.contour_offsets, np.int32)
+        pts = np.ascontiguousarray(s.points, np.float64)
+        t8 = np.ascontiguousarray(s.types, np.uint8)
+        c8 = np.ascontiguousarray(s.colors, np.uint8)
+        return (co, pts, t8, c8), (s.n_contours, _p(co, C.c_int32), _p(pts, C.c_double), _p(t8, C.c_uint8), _p(c8, C.c_uint8))
+
+    def windings(self, s):
+        keep, args = self._shape(s)
+        out = np.zeros(max(s.n_contours, 1), np.int32)
+        self.lib.emu_windings(*args, _p(out, C.c_int32))
+        return out[:s.n_contours]
+
+    def shape_distance(self, s, sel, overlap, pts):
+        keep, args = self._shape(s)
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2)
+        out = np.zeros((len(pts), 4))
+        self.lib.emu_shape_distance(sel, int(overlap), *args, len(pts), _p(pts, C.c_double), _p(out, C.c_double))
+        return out
+
+    def generate(self, s, mode, w, h, xf, overlap=True, ec_mode=2, ec_dist=1, stage=0, y_down=False, correct_only=None, stencil=None,
+                 min_dev=1.11111111111111111, min_imp=1.11111111111111111):
+        ms, mt = distance_mapping(xf[4], xf[5])
+        x6 = np.array([xf[0], xf[1], xf[2], xf[3], ms, mt], np.float64)
+        flip = int(bool(s.inverse_y) != bool(y_down))
+        if correct_only is None:
+            n = {1: 1, 2: 1, 3: 3, 4: 4}[mode]
+            out = np.zeros((h, w, n), np.float32)
+        else:
+            out = np.array(correct_only, np.float32, order="C")
+            n = mode = out.shape[2]
+        keep, args = self._shape(s)
+        self.lib.emu_generate(mode, int(correct_only is not None), _p(out, C.c_float), w, h, w*n, flip, *args, _p(x6, C.c_double), int(overlap),
+                              ec_mode, ec_dist, stage, C.c_double(min_dev), C.c_double(min_imp), _p(stencil, C.c_uint8) if stencil is not None else None)
+        return out

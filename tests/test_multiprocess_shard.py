@@ -1,0 +1,63 @@
+"""N>1 path on CPU: two gloo ranks shard a glyph list exactly like bench.py --gpus N does, agree on the partition, and assemble
+the final atlas with the optional gather (all_gather).  No GPU: the per-rank "render" is a stand-in that tags tiles."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from msdfgen_amd.shape import ShapeBatch
+    from msdfgen_amd.shard import shard, partition_contiguous, glyph_costs, gather_tiles
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = np.load(os.path.join(GOLDEN, "latin.npz"))
+    batch = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
+                       z["colors"].astype(np.int32), z["inverse_y"], [str(n) for n in z["names"]])
+    sub, xfs, (lo, hi) = shard(batch, z["xf64"], rank, world, 64, 64)
+    bounds = partition_contiguous(glyph_costs(batch, 64, 64), world)
+    # stand-in tiles: glyph index in channel 0, edge count in channel 1
+    tiles = torch.zeros((hi-lo, 4, 4, 3))
+    for i in range(hi-lo):
+        tiles[i, ..., 0] = lo+i
+        tiles[i, ..., 1] = sub.shape(i).n_edges
+    atlas = gather_tiles(tiles, bounds)
+    t = torch.tensor([float(hi-lo)])
+    dist.all_reduce(t)
+    q.put((rank, lo, hi, int(t.item()), atlas[:, 0, 0, 0].tolist(), atlas[:, 0, 0, 1].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_glyph_sharding_and_gather():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    z = np.load(os.path.join(GOLDEN, "latin.npz"))
+    co, gco = z["contour_offsets"], z["glyph_contour_offsets"]
+    edges = (co[gco[1:]]-co[gco[:-1]]).tolist()
+    (r0, lo0, hi0, tot0, ids0, e0), (r1, lo1, hi1, tot1, ids1, e1) = results
+    assert (lo0, hi1) == (0, 94) and hi0 == lo1 and 0 < hi0 < 94
+    assert tot0 == tot1 == 94
+    assert ids0 == ids1 == list(range(94)) and e0 == e1 == edges  # both ranks hold the same, correctly ordered atlas
+    work = [sum(edges[lo0:hi0]), sum(edges[lo1:hi1])]
+    assert abs(work[0]-work[1]) <= max(edges)+1
