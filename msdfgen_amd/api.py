@@ -123,7 +123,7 @@ def _shape_args(shape: FlatShape):
 def _bitmap_args(output: np.ndarray, n: int):
     if output.dtype != np.float32 or output.ndim != 3 or output.shape[2] != n:
         raise ValueError("output must be float32 of shape (height, width, %d)" % n)
-    if output.strides[2] != 4 or output.strides[1] != 4*n or output.strides[0] % 4:
+    if output.size and (output.strides[2] != 4 or output.strides[1] != 4*n or output.strides[0] % 4):
         raise ValueError("output texels must be channel-interleaved and rows float-aligned")
     h, w = output.shape[:2]
     return _lib.ptr(output, _lib._fp), w, h, output.strides[0]//4  # row stride in floats; may be negative for a flipped view
