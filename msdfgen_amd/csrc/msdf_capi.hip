@@ -87,6 +87,8 @@ struct MsdfHipBatch {
     int8_t *dWindings;
     mutable float *dScratch;
     mutable size_t scratchFloats;
+    mutable EcCandidate *dDeferred;   // [0] = header (count), [1..cap] = distance checks deferred to k_ec_query
+    mutable size_t deferredCap;
     mutable std::mutex scratchMutex;
 };
 
@@ -123,13 +125,14 @@ struct LdsPlan { size_t bytes; bool ldsRec; };
 int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan) {
     const size_t resBytes = overlap ? (size_t) b->maxContours*nch*WAVE*sizeof(double) : 0;
     const size_t recBytes = (size_t) b->maxEdges*sizeof(EdgeRec);
+    const size_t idxBytes = ((size_t) b->maxEdges+(size_t) b->maxContours+2)*sizeof(int);   // survivor list + per-contour offsets
     const size_t limit = (size_t) gLdsLimit.load();
-    if (resBytes > limit)
-        return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours: the overlapping combiner needs %zu B of LDS per wavefront, device limit is %zu B",
-                    b->maxContours, resBytes, limit);
-    // Staging pays while several workgroups still fit on a CU: keep res+rec within 40 KB (>= 4 workgroups per CU).
-    plan.ldsRec = resBytes+recBytes <= 40*1024;
-    plan.bytes = resBytes+(plan.ldsRec ? recBytes : 0);
+    if (resBytes+idxBytes > limit)
+        return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours / %d edges: the combiner state needs %zu B of LDS per wavefront, device limit is %zu B",
+                    b->maxContours, b->maxEdges, resBytes+idxBytes, limit);
+    // Staging the surviving records pays while several workgroups still fit on a CU: keep the total within 40 KB (>= 4 per CU).
+    plan.ldsRec = resBytes+recBytes+idxBytes <= 40*1024;
+    plan.bytes = resBytes+(plan.ldsRec ? recBytes : 0)+idxBytes;
     return MSDFHIP_OK;
 }
 
@@ -148,7 +151,7 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
     if (rc != MSDFHIP_OK)
         return rc;
     ScopedTimer timer(stream, 0);
-    hipLaunchKernelGGL((k_distance<SEL, OVERLAP, LDSREC>), dim3(blocks), dim3(WAVE), lds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, dst, toScratch);
+    hipLaunchKernelGGL((k_distance<SEL, OVERLAP, LDSREC>), dim3(blocks), dim3(WAVE), lds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, b->maxEdges, dst, toScratch);
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
 }
@@ -166,17 +169,61 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
                        : launchDistance<SEL, false, false>(b, dGlyphs, w, h, dst, toScratch, plan.bytes, stream);
 }
 
-template <int N, bool OVERLAP, bool LDSREC>
+int ensureDeferred(const MsdfHipBatch *b, size_t cap, EcCandidate **out) {
+    std::lock_guard<std::mutex> lock(b->scratchMutex);
+    if (b->deferredCap < cap) {
+        if (b->dDeferred)
+            hipFree(b->dDeferred);
+        b->dDeferred = NULL;
+        b->deferredCap = 0;
+        HIPCHK(hipMalloc((void **) &b->dDeferred, (cap+1)*sizeof(EcCandidate)));
+        b->deferredCap = cap;
+    }
+    *out = b->dDeferred;
+    return MSDFHIP_OK;
+}
+
+template <int N, bool OVERLAP>
 int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, const float *src, float *out, uint8_t *stencil,
-             const MsdfHipConfig &cfg, size_t lds, hipStream_t stream) {
+             const MsdfHipConfig &cfg, hipStream_t stream) {
     const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE, tiles = tilesX*tilesY;
     const unsigned blocks = (unsigned) ((b->nGlyphs+7)/8)*8u*(unsigned) tiles;
-    int rc = setLds(k_error_correction<N, OVERLAP, LDSREC>, lds);
+    const size_t allTexels = (size_t) b->nGlyphs*w*h;
+    if (allTexels >= 0xffffffffull)
+        return fail(MSDFHIP_ERR_INVALID, "batch of %zu texels exceeds the 32-bit texel index of the error-correction pass; split the batch", allTexels);
+    const size_t slowLds = OVERLAP ? (size_t) b->maxContours*WAVE*sizeof(double) : 0;
+    if (slowLds > (size_t) gLdsLimit.load())
+        return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours: the distance check needs %zu B of LDS per wavefront", b->maxContours, slowLds);
+    int rc = setLds(k_ec_slow<N, OVERLAP>, slowLds);
     if (rc != MSDFHIP_OK)
         return rc;
     ScopedTimer timer(stream, 1);
-    hipLaunchKernelGGL((k_error_correction<N, OVERLAP, LDSREC>), dim3(blocks), dim3(WAVE), lds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles,
-                       src, out, stencil, cfg);
+    if (cfg.ec_stage_limit != 0) {                               // test hook: stencil snapshots through the full pipeline for every texel
+        const unsigned slowBlocks = (unsigned) ((allTexels+WAVE-1)/WAVE < 16384 ? (allTexels+WAVE-1)/WAVE : 16384);
+        hipLaunchKernelGGL((k_ec_slow<N, OVERLAP>), dim3(slowBlocks), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
+                           (const EcCandidate *) NULL, 0u, 0);
+        HIPCHK(hipGetLastError());
+        return MSDFHIP_OK;
+    }
+    const size_t cap = allTexels/16 > 4096 ? allTexels/16 : 4096;
+    EcCandidate *deferred = NULL;
+    rc = ensureDeferred(b, cap, &deferred);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    rc = setLds(k_ec_query<N, OVERLAP>, slowLds);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    HIPCHK(hipMemsetAsync(deferred, 0, sizeof(EcCandidate), stream));
+    const size_t fastLds = (size_t) (b->maxEdges > 0 ? b->maxEdges : 1)*2*sizeof(int);
+    rc = setLds(k_ec_fast<N>, fastLds);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    hipLaunchKernelGGL((k_ec_fast<N>), dim3(blocks), dim3(WAVE), fastLds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, src, out, stencil, cfg,
+                       deferred, (unsigned) cap);
+    hipLaunchKernelGGL((k_ec_query<N, OVERLAP>), dim3(1024), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
+                       (const EcCandidate *) deferred, (unsigned) cap);
+    hipLaunchKernelGGL((k_ec_slow<N, OVERLAP>), dim3(2048), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
+                       (const EcCandidate *) deferred, (unsigned) cap, 1);
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
 }
@@ -184,16 +231,8 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
 template <int N>
 int dispatchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, const float *src, float *out, uint8_t *stencil,
                const MsdfHipConfig &cfg, hipStream_t stream) {
-    const bool overlap = cfg.overlap_support != 0;
-    LdsPlan plan;
-    int rc = planLds(b, 1, overlap, plan);
-    if (rc != MSDFHIP_OK)
-        return rc;
-    if (overlap)
-        return plan.ldsRec ? launchEc<N, true, true>(b, dGlyphs, w, h, src, out, stencil, cfg, plan.bytes, stream)
-                           : launchEc<N, true, false>(b, dGlyphs, w, h, src, out, stencil, cfg, plan.bytes, stream);
-    return plan.ldsRec ? launchEc<N, false, true>(b, dGlyphs, w, h, src, out, stencil, cfg, plan.bytes, stream)
-                       : launchEc<N, false, false>(b, dGlyphs, w, h, src, out, stencil, cfg, plan.bytes, stream);
+    return cfg.overlap_support ? launchEc<N, true>(b, dGlyphs, w, h, src, out, stencil, cfg, stream)
+                               : launchEc<N, false>(b, dGlyphs, w, h, src, out, stencil, cfg, stream);
 }
 
 int checkConfig(const MsdfHipConfig *cfg) {
@@ -297,7 +336,7 @@ int msdfhip_batch_create_device(MsdfHipBatch **batch, int n_glyphs, int n_contou
     b->dPoints = const_cast<double *>(d_points);
     b->dTypes = const_cast<uint8_t *>(d_types);
     b->dColors = const_cast<uint8_t *>(d_colors);
-    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0;
+    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0;
     rc = digest(b, (hipStream_t) stream);
     if (rc != MSDFHIP_OK) {
         msdfhip_batch_destroy(b);
@@ -334,7 +373,7 @@ int msdfhip_batch_create(MsdfHipBatch **batch, int n_glyphs, const int32_t *gco,
     b->nGlyphs = n_glyphs, b->nContours = nC, b->nEdges = nE, b->maxContours = maxC, b->maxEdges = maxE;
     b->ownsInputs = true;
     b->dGlyphContourOffsets = NULL, b->dContourOffsets = NULL, b->dPoints = NULL, b->dTypes = NULL, b->dColors = NULL;
-    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0;
+    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0;
     const size_t eAlloc = nE > 0 ? nE : 1;
     #define ALLOC_COPY(dst, src, bytes, used) do { \
         hipError_t e_ = hipMalloc((void **) &(dst), (bytes) ? (bytes) : 16); \
@@ -379,6 +418,7 @@ void msdfhip_batch_destroy(MsdfHipBatch *b) {
     hipFree(b->dRecs);
     hipFree(b->dWindings);
     hipFree(b->dScratch);
+    hipFree(b->dDeferred);
     delete b;
 }
 

@@ -52,12 +52,15 @@ struct alignas(16) EdgeRec {
     double k[6];      // linear:    abab, orthoN.x, orthoN.y, abN.x, abN.y
                       // quadratic: a, b, 2*dot(ab,ab), b/a, (b/a)^2, (b/a)*(1/3.)
                       // cubic:     3*ab.x, 3*ab.y, 6*br.x, 6*br.y
+    double lo[2];     // bounding box of the control points (tile culling only, msdf_cull.hpp)
+    double hi[2];
+    double mid[2];    // point(0.5): an on-curve sample (tile culling only)
     int32_t type;     // 1, 2, 3
     int32_t color;    // EdgeColor bitmask
     int32_t flags;    // REC_*
     int32_t contour;  // contour index within the batch
 };
-static_assert(sizeof(EdgeRec) == 288, "EdgeRec layout");
+static_assert(sizeof(EdgeRec) == 336, "EdgeRec layout");
 
 struct V2 { double x, y; };
 
@@ -181,7 +184,7 @@ MSDF_HD SD sdQuadratic(const EdgeRec &e, V2 o, double &param) {              // 
     V2 qa = p0-o;
     double c = e.k[2]+dot(qa, br);
     double d = dot(qa, ab);
-    double t[3];
+    double t[3] = { 0, 0, 0 };
     int solutions;
     if (e.flags&REC_NORMED)                                                   // solveCubic, equation-solver.cpp:63-70
         solutions = solveCubicNormedPre(t, e.k[3], e.k[4], e.k[5], c/e.k[0], d/e.k[0]);
@@ -200,8 +203,9 @@ MSDF_HD SD sdQuadratic(const EdgeRec &e, V2 o, double &param) {              // 
             param = dot(o-p1, epDir)/e.e1dot;
         }
     }
-    for (int i = 0; i < solutions; ++i) {
-        if (t[i] > 0 && t[i] < 1) {
+    MSDF_UNROLL
+    for (int i = 0; i < 3; ++i) {                                             // fixed trip count keeps t[] in registers
+        if (i < solutions && t[i] > 0 && t[i] < 1) {
             V2 qe = qa+(2*t[i])*ab+(t[i]*t[i])*br;
             double distance = vlen(qe);
             if (distance <= fabs(minDistance)) {
@@ -383,7 +387,7 @@ template <int SEL> struct SelTraits { enum { NPB = SEL == 1 ? 0 : SEL == 2 ? 1 :
 template <int SEL>
 struct Selector {
     SD m;                                        // TrueDistanceSelector::minDistance (SEL == 1)
-    PB c[SelTraits<SEL>::NPB ? SelTraits<SEL>::NPB : 1];
+    PB c[(int) SelTraits<SEL>::NPB > 0 ? (int) SelTraits<SEL>::NPB : 1];
 };
 
 template <int SEL>
@@ -479,21 +483,44 @@ MSDF_HD double resolve(const double *d) {                                    // 
 // windings: Contour::winding per contour (contour-combiners.cpp:57-63).
 // res:      per-lane scratch for the per-contour distances of the overlapping combiner, element (c, ch) at res[(c*NCH+ch)*rstride].
 
-template <int SEL>
-MSDF_HD void shapeDistanceSimple(const EdgeRec *rec, const int32_t *coff, int C, V2 o, double *out) { // contour-combiners.cpp:34-50
+// Edge enumeration of one glyph for the per-texel loops: contour c owns positions [begin(c), end(c)); at(k) is the record index.
+struct EdgesAll {                       // every edge, straight from the CSR offsets
+    const int32_t *coff;
+    MSDF_HD int begin(int c) const { return coff[c]-coff[0]; }
+    MSDF_HD int end(int c) const { return coff[c+1]-coff[0]; }
+    MSDF_HD int at(int k) const { return k; }
+};
+struct EdgesCulled {                    // survivors of the per-tile cull (msdf_cull.hpp), still grouped by contour and in visit order
+    const int *cstart;                  // C+1 compacted offsets
+    const int *list;                    // record index per position, or NULL if the surviving records were copied in this order
+    MSDF_HD int begin(int c) const { return cstart[c]; }
+    MSDF_HD int end(int c) const { return cstart[c+1]; }
+    MSDF_HD int at(int k) const { return list ? list[k] : k; }
+};
+
+template <int SEL, class Edges>
+MSDF_HD void shapeDistanceSimple(const EdgeRec *rec, const Edges &edges, int C, V2 o, double *out) { // contour-combiners.cpp:34-50
     Selector<SEL> sel;
     selInit(sel);
-    const int e0 = coff[0];
-    const int nE = coff[C]-e0;
-    for (int i = 0; i < nE; ++i)
-        selAddEdge(sel, rec[i], i, o);
+    for (int c = 0; c < C; ++c) {
+        const int e = edges.end(c);
+        for (int k = edges.begin(c); k < e; ++k) {
+            const int i = edges.at(k);
+            selAddEdge(sel, rec[i], i, o);
+        }
+    }
     selDistance(sel, rec, o, out);
 }
 
-template <int SEL>
-MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const int32_t *coff, const int8_t *windings, int C, V2 o, double *res, int rstride, double *out) {
+template <int SEL, class Edges>
+MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const int8_t *windings, int C, V2 o, double *res, int rstride, double *out) {
     enum { NCH = SelTraits<SEL>::NCH };                                      // OverlappingContourCombiner::distance, contour-combiners.cpp:77-134
-    const int e0 = coff[0];
+    if (C == 1) {
+        // One contour: the shape/inner/outer selectors can only ever hold that contour's own state, and every branch of
+        // contour-combiners.cpp:104-133 then returns that contour's distance -- identical to the simple combiner.
+        shapeDistanceSimple<SEL>(rec, edges, C, o, out);
+        return;
+    }
     Selector<SEL> shapeSel, innerSel, outerSel;
     selInit(shapeSel);
     selInit(innerSel);
@@ -501,9 +528,11 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const int32_t *coff, const
     for (int c = 0; c < C; ++c) {
         Selector<SEL> sel;
         selInit(sel);
-        const int b = coff[c]-e0, e = coff[c+1]-e0;
-        for (int i = b; i < e; ++i)
+        const int e = edges.end(c);
+        for (int k = edges.begin(c); k < e; ++k) {
+            const int i = edges.at(k);
             selAddEdge(sel, rec[i], i, o);
+        }
         double d[NCH];
         selDistance(sel, rec, o, d);
         for (int ch = 0; ch < NCH; ++ch)

@@ -1,0 +1,248 @@
+// msdf_ec_fast.hpp -- the lean, single-sweep form of the error-correction classifier used for ALL texels; the handful of texels whose
+// verdict depends on an exact shape-distance query (ShapeDistanceChecker, MSDFErrorCorrection.cpp:58-82; ~0.1 % of texels) are
+// deferred to the full per-texel pipeline of msdf_ec.hpp (k_ec_slow).
+//
+// What is restructured relative to the reference, and why each step is exact:
+//  * findErrors(sdf) (:383-410) and findErrors(sdf, shape) (:412-457) enumerate the SAME interpolation candidates (t, xm) -- they
+//    differ only in the classifier (protectedFlag, distance check).  One sweep computes each candidate once and derives both
+//    verdicts.  The sweep runs in shape orientation: a row flip maps every neighbour test of the native-order sweep onto a test
+//    with identical operands (hasDiagonalArtifact always receives (texel, horizontal, vertical, diagonal neighbour)), and the
+//    per-texel result is an OR over the tests, so the order does not matter.
+//  * The texel's ERROR flag is an OR of side-effect-free predicates, so all cheap predicates are evaluated first; only if none
+//    fires and some candidate needs the distance check is the texel deferred (result: identical flag).
+//  * Linear pairs: t = dA/(dA-dB) lies in (0,1) only if dA and dB have strictly opposite signs (float subtraction and division are
+//    monotone), so the fp64 division is skipped otherwise.
+//  * Diagonal pairs: solveQuadratic (sqrt + 2 divisions) is skipped when the quadratic provably has no real root in
+//    [0.005, 0.995] (the reference keeps only roots in (0.01, 0.99); the computed roots are within ~1e-4 of the real ones because
+//    |b| <= 1e12*|a| in that branch).  The extremum parameters tEx (3 divisions) are computed only when a root survives.
+#pragma once
+
+#include "msdf_ec.hpp"
+
+namespace msdfhip {
+
+enum { EC_DEFER = 0x80 };   // internal: texel must be re-evaluated by the full pipeline (needs a shape-distance query)
+
+// Which of the reference's two findErrors passes apply (core/msdf-error-correction.cpp:36-46).
+MSDF_HD bool ecHasBasePass(const EcParams &p) { return p.distanceCheck == EC_DO_NOT_CHECK || (p.distanceCheck == EC_CHECK_AT_EDGE && p.mode != EC_MODE_EDGE_ONLY); }
+MSDF_HD bool ecHasShapePass(const EcParams &p) { return p.distanceCheck == EC_ALWAYS_CHECK || p.distanceCheck == EC_CHECK_AT_EDGE; }
+
+struct FastCtx {
+    double span;
+    bool p1;          // protectedFlag of the base pass (and of the shape pass under ALWAYS_CHECK)
+    bool pShape;      // protectedFlag of the shape pass
+    bool basePass, shapePass;
+};
+
+// rangeTest (:30-40) for both classifiers at once. Returns flags of the base pass in bits 0-1 and of the shape pass in bits 2-3.
+MSDF_HD int rangeTest2(const FastCtx &c, double at, double bt, double xt, float am, float bm, float xm) {
+    const bool inversion = (am > .5f && bm > .5f && xm <= .5f) || (am < .5f && bm < .5f && xm >= .5f);
+    const bool outside = medianf(am, bm, xm) != xm;
+    const bool candBase = c.basePass && (inversion || (!c.p1 && outside));
+    const bool candShape = c.shapePass && (inversion || (!c.pShape && outside));
+    if (!(candBase || candShape))
+        return 0;
+    const double axSpan = (xt-at)*c.span, bxSpan = (bt-xt)*c.span;
+    const int f = (xm >= am-axSpan && xm <= am+axSpan && xm >= bm-bxSpan && xm <= bm+bxSpan) ? 1 : 3;
+    return (candBase ? f : 0)|(candShape ? f<<2 : 0);
+}
+
+// 1: ERROR decided; 2: needs the distance check; 0: nothing.
+MSDF_HD int judge(int flags) {
+    if (flags&2)
+        return 1;                     // base classifier: evaluate() == (flags&ARTIFACT) (:42-44)
+    const int fs = flags>>2;
+    if (fs&1)
+        return (fs&2) ? 1 : 2;        // shape classifier: artifact already, or candidate -> distance check (:60-64)
+    return 0;
+}
+
+// Conservative: false only if a*t^2+b*t+c has no real root in [0.005, 0.995] (see header comment). a, b, c as passed to solveQuadratic.
+MSDF_HD bool quadraticMayHaveRootInRange(double a, double b, double c) {
+    if (a == 0 || fabs(b) > 1e12*fabs(a))
+        return true;                                    // linear / degenerate branch of solveQuadratic: let it decide
+    const double lo = .005, hi = .995;
+    const double mag = fabs(a)+fabs(b)+fabs(c);
+    const double eps = 1e-9*mag;
+    const double flo = (a*lo+b)*lo+c, fhi = (a*hi+b)*hi+c;
+    if (!(flo > eps && fhi > eps) && !(flo < -eps && fhi < -eps))
+        return true;                                    // sign change (or too close to call) between the interval ends
+    const double s = flo > 0 ? 1. : -1.;                // sign of f at both ends; a root needs an interior extremum of the opposite sign
+    const double as = a*s, bs = b*s, cs = c*s;          // as*t^2+bs*t+cs is positive at both ends
+    if (as <= 0)
+        return false;                                   // concave: minimum over the interval is at an end
+    // convex: vertex at -bs/(2*as); inside (lo, hi) iff 2*as*lo < -bs < 2*as*hi
+    if (!(-bs > 2*as*lo*(1-1e-9) && -bs < 2*as*hi*(1+1e-9)))
+        return false;                                   // monotone on the interval
+    return !(4*as*cs-bs*bs > 1e-9*mag*mag);             // minimum value cs-bs^2/(4as) not clearly positive -> may have roots
+}
+
+// One diagonal channel pair (:291-327) with lazy extremum parameters. Returns judge() of the accumulated flags, OR-ed over roots;
+// candidates that need the distance check are handed to `sink(t)`.
+template <class Sink>
+MSDF_HD int diagonalPairFast(const FastCtx &cx, float am, float dm, const float *a, const float *l, const float *q,
+                             float dA, float dBC, float dD, int i0, int i1, Sink &sink) {
+    const double qa = dD-dBC+dA, qb = dBC-dA-dA, qc = dA;   // float expressions promoted, exactly as passed at :295
+    if (!quadraticMayHaveRootInRange(qa, qb, qc))
+        return 0;
+    double t[2];
+    const int solutions = solveQuadratic(t, qa, qb, qc);
+    int verdict = 0;
+    for (int i = 0; i < solutions; ++i) {
+        if (t[i] > MSDF_ARTIFACT_T_EPSILON && t[i] < 1-MSDF_ARTIFACT_T_EPSILON) {
+            const float xm = interpolatedMedianQuad(a, l, q, t[i]);
+            int rangeFlags = rangeTest2(cx, 0, 1, t[i], am, dm, xm);
+            const double tEx0 = -.5*l[i0]/q[i0], tEx1 = -.5*l[i1]/q[i1];   // :361-365
+            if (tEx0 > 0 && tEx0 < 1) {
+                double tEnd0 = 0, tEnd1 = 1;
+                float em0 = am, em1 = dm;
+                const float ex = interpolatedMedianQuad(a, l, q, tEx0);
+                if (tEx0 > t[i])
+                    tEnd1 = tEx0, em1 = ex;
+                else
+                    tEnd0 = tEx0, em0 = ex;
+                rangeFlags |= rangeTest2(cx, tEnd0, tEnd1, t[i], em0, em1, xm);
+            }
+            if (tEx1 > 0 && tEx1 < 1) {
+                double tEnd0 = 0, tEnd1 = 1;
+                float em0 = am, em1 = dm;
+                const float ex = interpolatedMedianQuad(a, l, q, tEx1);
+                if (tEx1 > t[i])
+                    tEnd1 = tEx1, em1 = ex;
+                else
+                    tEnd0 = tEx1, em0 = ex;
+                rangeFlags |= rangeTest2(cx, tEnd0, tEnd1, t[i], em0, em1, xm);
+            }
+            const int v = judge(rangeFlags);
+            if (v&2)
+                sink(t[i]);
+            verdict |= v;
+            if (verdict&1)
+                return verdict;
+        }
+    }
+    return verdict;
+}
+
+// Fused findErrors for texel (x, ys) in shape orientation. Returns bit0: ERROR decided, bit1: some candidate needs the distance check;
+// every such candidate is reported as sink(t, dx, dy) (interpolation parameter and neighbour direction, MSDFErrorCorrection.cpp:65).
+template <class Sink>
+MSDF_HD int texelFindFast(const SdfView &sdf, const EcParams &p, int x, int ys, bool p1, Sink &sink) {
+    FastCtx cx;
+    cx.basePass = ecHasBasePass(p);
+    cx.shapePass = ecHasShapePass(p);
+    cx.p1 = p1;
+    cx.pShape = (p.distanceCheck == EC_CHECK_AT_EDGE) ? true : p1;   // protectAll() precedes the shape pass only in that mode (:38-39, :33)
+    const int w = sdf.w, h = sdf.h;
+    const float *c = sdf.shape(x, ys);
+    const float cm = medianf(c[0], c[1], c[2]);
+    const float cdev = fabsf(cm-.5f);
+    int verdict = 0;
+    MSDF_NOUNROLL
+    for (int k = 0; k < 4; ++k) {                        // l, b, r, t
+        const int dx = k == 0 ? -1 : k == 2 ? 1 : 0, dy = k == 1 ? -1 : k == 3 ? 1 : 0;
+        const int nx = x+dx, ny = ys+dy;
+        if (nx < 0 || ny < 0 || nx >= w || ny >= h)
+            continue;
+        const float *b = sdf.shape(nx, ny);
+        const float bm = medianf(b[0], b[1], b[2]);
+        if (!(cdev >= fabsf(bm-.5f)))                    // :335
+            continue;
+        cx.span = dy == 0 ? p.hSpan : p.vSpan;
+        for (int j = 0; j < 3; ++j) {                    // channel pairs (1,0), (2,1), (0,2)
+            const int i0 = j, i1 = j == 2 ? 0 : j+1;
+            const float dA = c[i1]-c[i0], dB = b[i1]-b[i0];
+            if (!((dA > 0 && dB < 0) || (dA < 0 && dB > 0)))
+                continue;                                // t = dA/(dA-dB) cannot lie in (0, 1)
+            const double t = (double) dA/(dA-dB);        // :281
+            if (t > MSDF_ARTIFACT_T_EPSILON && t < 1-MSDF_ARTIFACT_T_EPSILON) {
+                const float xm = interpolatedMedianLin(c, b, t);
+                const int v = judge(rangeTest2(cx, 0, 1, t, cm, bm, xm));
+                if (v&2)
+                    sink(t, dx, dy);
+                verdict |= v;
+                if (verdict&1)
+                    return verdict;
+            }
+        }
+    }
+    cx.span = p.dSpan;
+    MSDF_NOUNROLL
+    for (int k = 0; k < 4; ++k) {                        // (l,b) (r,b) (l,t) (r,t)
+        const int dx = (k&1) ? 1 : -1, dy = (k&2) ? 1 : -1;
+        const int nx = x+dx, ny = ys+dy;
+        if (nx < 0 || ny < 0 || nx >= w || ny >= h)
+            continue;
+        const float *d = sdf.shape(nx, ny);
+        const float dm = medianf(d[0], d[1], d[2]);
+        if (!(cdev >= fabsf(dm-.5f)))                    // :349
+            continue;
+        const float *a = c, *b = sdf.shape(nx, ys), *cc = sdf.shape(x, ny);
+        const float abc[3] = { a[0]-b[0]-cc[0], a[1]-b[1]-cc[1], a[2]-b[2]-cc[2] };
+        const float l[3] = { -a[0]-abc[0], -a[1]-abc[1], -a[2]-abc[2] };
+        const float q[3] = { d[0]+abc[0], d[1]+abc[1], d[2]+abc[2] };
+        struct DirSink {
+            Sink &sink;
+            int dx, dy;
+            MSDF_HD void operator()(double t) { sink(t, dx, dy); }
+        } dirSink = { sink, dx, dy };
+        for (int j = 0; j < 3; ++j) {
+            const int i0 = j, i1 = j == 2 ? 0 : j+1;
+            verdict |= diagonalPairFast(cx, cm, dm, a, l, q, a[i1]-a[i0], b[i1]-b[i0]+cc[i1]-cc[i0], d[i1]-d[i0], i0, i1, dirSink);
+            if (verdict&1)
+                return verdict;
+        }
+    }
+    return verdict;
+}
+
+// Stencil byte of texel (x, yn) [native order] by the fast path: PROTECTED/ERROR as in ecTexelStencil, plus EC_DEFER if the verdict
+// hinges on shape-distance checks (each reported through `sink`). corners: (l, b) pairs of protectCorners (:131-134) in shape
+// orientation, precomputed per tile.
+template <class Sink>
+MSDF_HD int ecTexelFast(const SdfView &sdf, const EcParams &p, const int *corners, int nCorners, int x, int yn, Sink &sink) {
+    const int ys = sdf.flip ? sdf.h-1-yn : yn;
+    int st = 0;
+    if (p.mode == EC_MODE_EDGE_PRIORITY) {
+        for (int i = 0; i < nCorners; ++i) {
+            const int l = corners[2*i], b = corners[2*i+1];
+            if ((x == l || x == l+1) && (ys == b || ys == b+1)) {
+                st |= EC_PROTECTED;
+                break;
+            }
+        }
+        if (!(st&EC_PROTECTED) && protectedByEdges(sdf, p, x, yn))
+            st |= EC_PROTECTED;
+    } else if (p.mode == EC_MODE_EDGE_ONLY)
+        st |= EC_PROTECTED;
+    const int verdict = texelFindFast(sdf, p, x, ys, (st&EC_PROTECTED) != 0, sink);
+    if (ecHasBasePass(p) && p.distanceCheck == EC_CHECK_AT_EDGE)
+        st |= EC_PROTECTED;                              // protectAll (:38-39)
+    if (verdict&1)
+        st |= EC_ERROR;
+    else if (verdict&2)
+        st |= EC_DEFER;
+    return st;
+}
+
+// The distance check of one deferred candidate: ShapeDistanceChecker::ArtifactClassifier::evaluate past its flag tests (:65-79).
+// (x, ys): texel in shape orientation; t, (dx, dy): as reported by texelFindFast; query(V2) -> exact PSDF distance at a shape point.
+template <class Query>
+MSDF_HD bool ecEvaluateCandidate(const SdfView &sdf, const EcParams &p, int x, int ys, double t, int dx, int dy, const Query &query) {
+    const float *msd = sdf.shape(x, ys);
+    const V2 tVector = t*mk(dx, dy);
+    float oldMSD[3], newMSD[3];
+    interpolate3(oldMSD, sdf, mk(x+.5, ys+.5)+tVector);
+    const double aWeight = (1-fabs(tVector.x))*(1-fabs(tVector.y));
+    const float aPSD = medianf(msd[0], msd[1], msd[2]);
+    newMSD[0] = (float) (oldMSD[0]+aWeight*(aPSD-msd[0]));
+    newMSD[1] = (float) (oldMSD[1]+aWeight*(aPSD-msd[1]));
+    newMSD[2] = (float) (oldMSD[2]+aWeight*(aPSD-msd[2]));
+    const float oldPSD = medianf(oldMSD[0], oldMSD[1], oldMSD[2]);
+    const float newPSD = medianf(newMSD[0], newMSD[1], newMSD[2]);
+    const V2 q = unproject(p.t, mk(x+.5, ys+.5))+mk(tVector.x*p.texelX, tVector.y*p.texelY);
+    const float refPSD = mapDistance(p.t, query(q));
+    return p.minImproveRatio*fabsf(newPSD-refPSD) < (double) fabsf(oldPSD-refPSD);
+}
+
+} // namespace msdfhip

@@ -6,7 +6,9 @@
 //                                 every lane runs the full per-contour nearest-edge selection in fp64 registers. The overlapping
 //                                 contour combiner keeps its per-contour distances in LDS, laid out [contour][channel][lane] so that
 //                                 lane-consecutive 8-byte accesses are bank-conflict free.
-//   k_error_correction<N,OVERLAP,LDSREC>  the whole stencil pipeline as a per-texel gather over the pre-correction field
+//   k_ec_fast<N>                  error correction, lean single sweep over all texels (gather form, no atomics on the stencil);
+//                                 texels whose verdict needs an exact shape-distance query (~0.1 %) are appended to a list
+//   k_ec_slow<N,OVERLAP>          full per-texel pipeline incl. the PSDF distance query for the listed texels
 //   k_shape_distance<SEL,OVERLAP> distance queries at arbitrary points (known-answer tests)
 //
 // Workgroup -> work mapping is XCD-aware: hardware places block b on XCD b%8 (MI355X_MICROARCH.md), so all tiles of glyph g are
@@ -17,10 +19,15 @@
 #include "msdf_device.hpp"
 #include "msdf_prep.hpp"
 #include "msdf_ec.hpp"
+#include "msdf_ec_fast.hpp"
+#include "msdf_cull.hpp"
 #include "../../include/msdfgen_hip.h"
 
 namespace msdfhip {
 
+#ifndef MSDF_DISTANCE_WAVES_PER_SIMD
+#define MSDF_DISTANCE_WAVES_PER_SIMD 2   // caps k_distance at 256 VGPRs so that two wavefronts share a SIMD and hide fp64 latency
+#endif
 constexpr int TILE = 8;          // 8x8 texels per wavefront
 constexpr int WAVE = 64;
 constexpr int REC_DOUBLES = sizeof(EdgeRec)/sizeof(double);
@@ -93,11 +100,25 @@ __device__ inline void stageRecords(double *dst, const EdgeRec *src, int n) {
 
 // ----------------------------------------------------------------------------------------------------- distance field
 
+// Wave-wide minimum of a double (all 64 lanes receive it).
+__device__ inline double waveMin(double v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(v, off, WAVE);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
 // dst: tile-major destination. If toScratch, texels go to the tightly packed pre-correction buffer [g][h][w][N] (native rows),
 // else straight to the caller's bitmap at out_offset/row_stride (generateDistanceField, core/msdfgen.cpp:52-76).
+//
+// Phase 1 (lanes = edges): per contour, bound the tile's distance to each channel, cull edges that cannot matter for any texel of
+// the tile (msdf_cull.hpp), and compact the survivors -- in visit order -- into LDS.  Phase 2 (lanes = texels): every lane runs
+// the reference's per-contour nearest-edge selection over the survivors with wave-uniform (broadcast) record reads.
+// LDS: [res: C*NCH*64 doubles (overlap)] [records: maxEdges (LDSREC)] [list: maxEdges ints] [cstart: C+1 ints].
 template <int SEL, bool OVERLAP, bool LDSREC>
-__global__ void __launch_bounds__(WAVE)
-k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph, float *dst, int toScratch) {
+__global__ void __launch_bounds__(WAVE, MSDF_DISTANCE_WAVES_PER_SIMD)
+k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges, float *dst, int toScratch) {
     enum { NCH = SelTraits<SEL>::NCH };
     extern __shared__ double smem[];
     const GlyphWork wk = decodeBlock(batch.nGlyphs, tilesPerGlyph);
@@ -105,30 +126,94 @@ k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, i
         return;
     const int c0 = batch.glyphContourOffsets[wk.g], C = batch.glyphContourOffsets[wk.g+1]-c0;
     const int32_t *coff = batch.contourOffsets+c0;
-    const int e0 = coff[0], nE = coff[C]-e0;
+    const int e0 = coff[0];
     const int lane = threadIdx.x;
+    const EdgeRec *recGlobal = batch.recs+e0;
 
     double *res = smem;                                             // [C][NCH][64] (overlap only)
-    const EdgeRec *rec = batch.recs+e0;
-    if (LDSREC) {
-        double *recLds = smem+(OVERLAP ? (size_t) C*NCH*WAVE : 0);
-        stageRecords(recLds, rec, nE);
+    double *recLds = smem+(OVERLAP ? (size_t) C*NCH*WAVE : 0);
+    int *list = reinterpret_cast<int *>(recLds+(LDSREC ? (size_t) maxEdges*REC_DOUBLES : 0));
+    int *cstart = list+maxEdges;
+
+    const MsdfHipGlyph gd = glyphs[wk.g];
+    const Xform t = loadXform(gd);
+    const int tx = wk.tile%tilesX, ty = wk.tile/tilesX;
+
+    // ---- phase 1: cull + compact (lanes = edges)
+    const V2 tc = unproject(t, mk(tx*TILE+.5*TILE, ty*TILE+.5*TILE));
+    const double hx = (.5*TILE-.5)/fabs(t.sx), hy = (.5*TILE-.5)/fabs(t.sy);
+    const double tr = sqrt(hx*hx+hy*hy);
+    int nSurv = 0;
+    // The bounds U[ch] are per contour for the overlapping combiner (one selector per contour, every contour's own distance is
+    // needed) and over the whole shape for the simple combiner (a single selector).
+    double U[3] = { DBL_MAX, DBL_MAX, DBL_MAX };
+    const int groups = OVERLAP ? C : 1;
+    for (int grp = 0; grp < groups; ++grp) {
+        const int cBegin = OVERLAP ? grp : 0, cEnd = OVERLAP ? grp+1 : C;
+        const int b = coff[cBegin]-e0, e = coff[cEnd]-e0;
+        U[0] = U[1] = U[2] = DBL_MAX;
+        for (int base = b; base < e; base += WAVE) {
+            const int i = base+lane;
+            double ub = DBL_MAX;
+            int mask = 0;
+            if (i < e) {
+                ub = cullUpperDistance(recGlobal[i], tc);
+                mask = cullMask<SEL>(recGlobal[i]);
+            }
+            for (int ch = 0; ch < (SEL <= 2 ? 1 : 3); ++ch)
+                U[ch] = dmin(U[ch], waveMin((mask>>ch)&1 ? ub : DBL_MAX));
+        }
+        for (int c = cBegin; c < cEnd; ++c) {
+            const int cb = coff[c]-e0, ce = coff[c+1]-e0;
+            if (lane == 0)
+                cstart[c] = nSurv;
+            for (int base = cb; base < ce; base += WAVE) {
+                const int i = base+lane;
+                bool keep = false;
+                if (i < ce) {
+                    const int mask = cullMask<SEL>(recGlobal[i]);
+                    if (mask) {
+                        double umax = 0;
+                        for (int ch = 0; ch < (SEL <= 2 ? 1 : 3); ++ch)
+                            if ((mask>>ch)&1)
+                                umax = dmax(umax, U[ch]);
+                        keep = cullEdgeSurvives<(SEL >= 2)>(recGlobal[i], tc, tr, umax);
+                    }
+                }
+                const unsigned long long ballot = __ballot(keep);
+                if (keep)
+                    list[nSurv+__popcll(ballot&((1ull<<lane)-1ull))] = i;
+                nSurv += __popcll(ballot);
+            }
+        }
+    }
+    if (lane == 0)
+        cstart[C] = nSurv;
+    __syncthreads();
+    const EdgeRec *rec = recGlobal;
+    if (LDSREC) {                                                   // stage the surviving records, in list order
+        for (int k = 0; k < nSurv; ++k) {
+            const double *src = reinterpret_cast<const double *>(recGlobal+list[k]);
+            if (lane < REC_DOUBLES)
+                recLds[(size_t) k*REC_DOUBLES+lane] = src[lane];
+        }
         rec = reinterpret_cast<const EdgeRec *>(recLds);
         __syncthreads();
     }
 
-    const int tx = wk.tile%tilesX, ty = wk.tile/tilesX;
+    // ---- phase 2: per-texel selection over the survivors (lanes = texels)
     const int x = tx*TILE+(lane&(TILE-1)), y = ty*TILE+(lane>>3);
     if (x >= width || y >= height)
         return;
-    const MsdfHipGlyph gd = glyphs[wk.g];
-    const Xform t = loadXform(gd);
     const V2 p = unproject(t, mk(x+.5, y+.5));                      // msdfgen.cpp:68
+    EdgesCulled edges;
+    edges.cstart = cstart;
+    edges.list = LDSREC ? (const int *) 0 : list;
     double d[NCH];
     if (OVERLAP)
-        shapeDistanceOverlap<SEL>(rec, coff, batch.windings+c0, C, p, res+lane, WAVE, d);
+        shapeDistanceOverlap<SEL>(rec, edges, batch.windings+c0, C, p, res+lane, WAVE, d);
     else
-        shapeDistanceSimple<SEL>(rec, coff, C, p, d);
+        shapeDistanceSimple<SEL>(rec, edges, C, p, d);
     const int yn = gd.flip ? height-1-y : y;                        // output.reorient(shape orientation), msdfgen.cpp:55
     float *px = toScratch ? dst+(((size_t) wk.g*height+yn)*width+x)*NCH
                           : dst+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) NCH*x;
@@ -145,23 +230,49 @@ struct PsdfQuery {                                                  // ShapeDist
     const int8_t *windings;
     int C;
     double *res;
-    __device__ MSDF_NOINLINE double operator()(V2 q) const {
+    __device__ double operator()(V2 q) const {
         double out[1];
+        EdgesAll edges;
+        edges.coff = coff;
         if (OVERLAP)
-            shapeDistanceOverlap<2>(rec, coff, windings, C, q, res, WAVE, out);
+            shapeDistanceOverlap<2>(rec, edges, windings, C, q, res, WAVE, out);
         else
-            shapeDistanceSimple<2>(rec, coff, C, q, out);
+            shapeDistanceSimple<2>(rec, edges, C, q, out);
         return out[0];
     }
 };
 
-// src: pre-correction field, packed [g][h][w][N] in native row order. Writes corrected texels to the caller's bitmap
-// (msdfErrorCorrectionInner, core/msdf-error-correction.cpp:12-48) and, if stencilOut, the final stencil byte [g][h][w] (native rows).
-template <int N, bool OVERLAP, bool LDSREC>
+// One deferred distance check: texel (packed index), neighbour direction and interpolation parameter. cands[0] is the header
+// (texel = number of candidates pushed so far, zeroed by the host before k_ec_fast); records start at cands[1].
+struct EcCandidate {
+    unsigned texel;
+    int dir;          // (dx+1) | (dy+1)<<2
+    double t;
+};
+static_assert(sizeof(EcCandidate) == 16, "EcCandidate layout");
+
+struct CandidateSink {
+    EcCandidate *cands;
+    unsigned capacity, texel;
+    __device__ void operator()(double t, int dx, int dy) {
+        const unsigned slot = atomicAdd(&cands[0].texel, 1u);
+        if (slot < capacity) {
+            EcCandidate c;
+            c.texel = texel, c.dir = (dx+1)|((dy+1)<<2), c.t = t;
+            cands[1+slot] = c;
+        }
+    }
+};
+
+// Error correction, fast sweep over ALL texels (msdf_ec_fast.hpp). src: pre-correction field, packed [g][h][w][N] in native row order.
+// Writes corrected texels to the caller's bitmap (msdfErrorCorrectionInner, core/msdf-error-correction.cpp:12-48) and, if stencilOut,
+// the stencil byte [g][h][w] (native rows). Candidates whose verdict needs an exact shape-distance query are appended to `cands`
+// and judged by k_ec_query; a texel with a cheaply decided ERROR never needs them (the flag is an OR).
+template <int N>
 __global__ void __launch_bounds__(WAVE)
-k_error_correction(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph,
-                   const float *src, float *out, uint8_t *stencilOut, MsdfHipConfig cfg) {
-    extern __shared__ double smem[];
+k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph,
+          const float *src, float *out, uint8_t *stencilOut, MsdfHipConfig cfg, EcCandidate *cands, unsigned capacity) {
+    extern __shared__ int smemCorners[];                            // (l, b) per colour-change corner of the glyph
     const GlyphWork wk = decodeBlock(batch.nGlyphs, tilesPerGlyph);
     if (!wk.valid)
         return;
@@ -169,13 +280,29 @@ k_error_correction(BatchView batch, const MsdfHipGlyph *glyphs, int width, int h
     const int32_t *coff = batch.contourOffsets+c0;
     const int e0 = coff[0], nE = coff[C]-e0;
     const int lane = threadIdx.x;
+    const MsdfHipGlyph gd = glyphs[wk.g];
+    EcParams p;
+    p.t = loadXform(gd);
+    p.minDeviationRatio = cfg.min_deviation_ratio;
+    p.minImproveRatio = cfg.min_improve_ratio;
+    p.mode = cfg.ec_mode, p.distanceCheck = cfg.ec_distance_check, p.overlap = cfg.overlap_support, p.stageLimit = 0;
+    ecDerive(p);
 
-    double *res = smem;                                             // [C][1][64] (overlap only)
-    const EdgeRec *rec = batch.recs+e0;
-    if (LDSREC) {
-        double *recLds = smem+(OVERLAP ? (size_t) C*WAVE : 0);
-        stageRecords(recLds, rec, nE);
-        rec = reinterpret_cast<const EdgeRec *>(recLds);
+    int nCorners = 0;
+    if (p.mode == EC_MODE_EDGE_PRIORITY) {                          // protectCorners (MSDFErrorCorrection.cpp:121-151): lanes = edges, ordered compaction
+        const EdgeRec *rec = batch.recs+e0;
+        for (int base = 0; base < nE; base += WAVE) {
+            const int e = base+lane;
+            const bool corner = e < nE && (rec[e].flags&REC_CORNER);
+            const unsigned long long mask = __ballot(corner);
+            if (corner) {
+                const V2 pp = project(p.t, ld(rec[e].p));
+                const int slot = nCorners+__popcll(mask&((1ull<<lane)-1ull));
+                smemCorners[2*slot] = (int) floor(pp.x-.5);
+                smemCorners[2*slot+1] = (int) floor(pp.y-.5);
+            }
+            nCorners += __popcll(mask);
+        }
         __syncthreads();
     }
 
@@ -183,33 +310,120 @@ k_error_correction(BatchView batch, const MsdfHipGlyph *glyphs, int width, int h
     const int x = tx*TILE+(lane&(TILE-1)), yn = ty*TILE+(lane>>3);
     if (x >= width || yn >= height)
         return;
-    const MsdfHipGlyph gd = glyphs[wk.g];
-    EcParams p;
-    p.t = loadXform(gd);
-    p.minDeviationRatio = cfg.min_deviation_ratio;
-    p.minImproveRatio = cfg.min_improve_ratio;
-    p.mode = cfg.ec_mode, p.distanceCheck = cfg.ec_distance_check, p.overlap = OVERLAP, p.stageLimit = cfg.ec_stage_limit;
-    ecDerive(p);
     SdfView sdf;
     sdf.px = src+(size_t) wk.g*height*width*N;
     sdf.w = width, sdf.h = height, sdf.N = N, sdf.flip = gd.flip;
-    PsdfQuery<OVERLAP> query;
-    query.rec = rec, query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.res = res+lane;
-
-    const int st = ecTexelStencil(sdf, p, rec, nE, x, yn, &query);
+    const size_t texel = ((size_t) wk.g*height+yn)*width+x;
+    CandidateSink sink;
+    sink.cands = cands, sink.capacity = capacity, sink.texel = (unsigned) texel;
+    int st = ecTexelFast(sdf, p, smemCorners, nCorners, x, yn, sink);
     const float *in = sdf.native(x, yn);
     float v[N];
     for (int i = 0; i < N; ++i)
         v[i] = in[i];
-    if ((st&EC_ERROR) && cfg.ec_stage_limit == 0) {                 // apply, MSDFErrorCorrection.cpp:459-479 (alpha untouched)
+    if (st&EC_ERROR) {                                              // apply, MSDFErrorCorrection.cpp:459-479 (alpha untouched)
         const float m = medianf(v[0], v[1], v[2]);
         v[0] = m, v[1] = m, v[2] = m;
     }
     float *px = out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
     for (int i = 0; i < N; ++i)
         px[i] = v[i];
+    st &= ~EC_DEFER;
     if (stencilOut)
-        stencilOut[((size_t) wk.g*height+yn)*width+x] = (uint8_t) st;
+        stencilOut[texel] = (uint8_t) st;
+}
+
+// The deferred distance checks, one lane per candidate (all lanes run exactly one PSDF query: convergent). A candidate that
+// turns out to be an artifact flags its texel: rgb := median (apply, MSDFErrorCorrection.cpp:459-479), stencil |= ERROR. Several
+// candidates of one texel write identical values.
+template <int N, bool OVERLAP>
+__global__ void __launch_bounds__(WAVE)
+k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, const float *src, float *out, uint8_t *stencilOut,
+           MsdfHipConfig cfg, const EcCandidate *cands, unsigned capacity) {
+    extern __shared__ double smem[];                                // [maxContours][64] combiner scratch (overlap only)
+    const unsigned count = cands[0].texel;
+    if (count > capacity)
+        return;                                                     // overflow: k_ec_slow redoes every texel
+    const size_t texelsPerGlyph = (size_t) width*height;
+    for (size_t i = (size_t) blockIdx.x*WAVE+threadIdx.x; i < count; i += (size_t) gridDim.x*WAVE) {
+        const EcCandidate cand = cands[1+i];
+        const size_t texel = cand.texel;
+        const int g = (int) (texel/texelsPerGlyph);
+        const int rem = (int) (texel%texelsPerGlyph);
+        const int yn = rem/width, x = rem%width;
+        const int c0 = batch.glyphContourOffsets[g], C = batch.glyphContourOffsets[g+1]-c0;
+        const int32_t *coff = batch.contourOffsets+c0;
+        const MsdfHipGlyph gd = glyphs[g];
+        EcParams p;
+        p.t = loadXform(gd);
+        p.minDeviationRatio = cfg.min_deviation_ratio;
+        p.minImproveRatio = cfg.min_improve_ratio;
+        p.mode = cfg.ec_mode, p.distanceCheck = cfg.ec_distance_check, p.overlap = OVERLAP, p.stageLimit = 0;
+        ecDerive(p);
+        SdfView sdf;
+        sdf.px = src+(size_t) g*texelsPerGlyph*N;
+        sdf.w = width, sdf.h = height, sdf.N = N, sdf.flip = gd.flip;
+        PsdfQuery<OVERLAP> query;
+        query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.res = smem+threadIdx.x;
+        const int ys = gd.flip ? height-1-yn : yn;
+        if (ecEvaluateCandidate(sdf, p, x, ys, cand.t, (cand.dir&3)-1, ((cand.dir>>2)&3)-1, query)) {
+            const float *in = sdf.native(x, yn);
+            const float m = medianf(in[0], in[1], in[2]);
+            float *px = out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
+            px[0] = m, px[1] = m, px[2] = m;
+            if (stencilOut)
+                stencilOut[texel] |= (uint8_t) EC_ERROR;
+        }
+    }
+}
+
+// Full per-texel pipeline incl. the exact shape-distance check (msdf_ec.hpp) for EVERY texel of the batch: used for the stage
+// snapshots of the tests (overflowOnly == 0) and as the safety net when the candidate list overflowed (overflowOnly != 0).
+template <int N, bool OVERLAP>
+__global__ void __launch_bounds__(WAVE)
+k_ec_slow(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, const float *src, float *out, uint8_t *stencilOut,
+          MsdfHipConfig cfg, const EcCandidate *cands, unsigned capacity, int overflowOnly) {
+    extern __shared__ double smem[];                                // [maxContours][64] combiner scratch (overlap only)
+    const size_t texelsPerGlyph = (size_t) width*height;
+    const size_t allTexels = texelsPerGlyph*batch.nGlyphs;
+    if (overflowOnly && cands[0].texel <= capacity)
+        return;                                                     // the candidate list held everything: k_ec_query did the job
+    for (size_t i = (size_t) blockIdx.x*WAVE+threadIdx.x; i < allTexels; i += (size_t) gridDim.x*WAVE) {
+        const size_t texel = i;
+        const int g = (int) (texel/texelsPerGlyph);
+        const int rem = (int) (texel%texelsPerGlyph);
+        const int yn = rem/width, x = rem%width;
+        const int c0 = batch.glyphContourOffsets[g], C = batch.glyphContourOffsets[g+1]-c0;
+        const int32_t *coff = batch.contourOffsets+c0;
+        const int e0 = coff[0], nE = coff[C]-e0;
+        const EdgeRec *rec = batch.recs+e0;
+        const MsdfHipGlyph gd = glyphs[g];
+        EcParams p;
+        p.t = loadXform(gd);
+        p.minDeviationRatio = cfg.min_deviation_ratio;
+        p.minImproveRatio = cfg.min_improve_ratio;
+        p.mode = cfg.ec_mode, p.distanceCheck = cfg.ec_distance_check, p.overlap = OVERLAP, p.stageLimit = cfg.ec_stage_limit;
+        ecDerive(p);
+        SdfView sdf;
+        sdf.px = src+(size_t) g*texelsPerGlyph*N;
+        sdf.w = width, sdf.h = height, sdf.N = N, sdf.flip = gd.flip;
+        PsdfQuery<OVERLAP> query;
+        query.rec = rec, query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.res = smem+threadIdx.x;
+        const int st = ecTexelStencil(sdf, p, rec, nE, x, yn, &query);
+        const float *in = sdf.native(x, yn);
+        float v[N];
+        for (int k = 0; k < N; ++k)
+            v[k] = in[k];
+        if ((st&EC_ERROR) && cfg.ec_stage_limit == 0) {
+            const float m = medianf(v[0], v[1], v[2]);
+            v[0] = m, v[1] = m, v[2] = m;
+        }
+        float *px = out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
+        for (int k = 0; k < N; ++k)
+            px[k] = v[k];
+        if (stencilOut)
+            stencilOut[texel] = (uint8_t) st;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------- distance queries
@@ -225,10 +439,12 @@ k_shape_distance(BatchView batch, int nPoints, const double *pts, double *out) {
     const int C = batch.glyphContourOffsets[1]-batch.glyphContourOffsets[0];
     double d[4] = { 0, 0, 0, 0 };
     const V2 p = mk(pts[2*i], pts[2*i+1]);
+    EdgesAll edges;
+    edges.coff = batch.contourOffsets;
     if (OVERLAP)
-        shapeDistanceOverlap<SEL>(batch.recs, batch.contourOffsets, batch.windings, C, p, smem+threadIdx.x, WAVE, d);
+        shapeDistanceOverlap<SEL>(batch.recs, edges, batch.windings, C, p, smem+threadIdx.x, WAVE, d);
     else
-        shapeDistanceSimple<SEL>(batch.recs, batch.contourOffsets, C, p, d);
+        shapeDistanceSimple<SEL>(batch.recs, edges, C, p, d);
     for (int ch = 0; ch < 4; ++ch)
         out[4*(size_t) i+ch] = ch < NCH ? d[ch] : 0.;
 }

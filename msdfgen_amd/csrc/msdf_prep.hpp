@@ -108,6 +108,14 @@ MSDF_HD void buildRecord(EdgeRec &r, const RawEdge &prev, const RawEdge &cur, co
         st(r.k, 3*ab);
         st(r.k+2, 6*br);
     }
+    V2 lo = cur.p[0], hi = cur.p[0];                                          // culling aids: control-point box, an on-curve sample
+    for (int i = 1; i <= cur.type; ++i) {
+        lo = mk(dmin(lo.x, cur.p[i].x), dmin(lo.y, cur.p[i].y));
+        hi = mk(dmax(hi.x, cur.p[i].x), dmax(hi.y, cur.p[i].y));
+    }
+    st(r.lo, lo);
+    st(r.hi, hi);
+    st(r.mid, rawPoint(cur, .5));
     const int common = prev.color&cur.color;                                  // MSDFErrorCorrection.cpp:127-129
     if (!(common&(common-1)))
         flags |= REC_CORNER;

@@ -83,11 +83,12 @@ def load(build_if_missing=True):
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(_build.LIB):
+        path = os.environ.get("MSDFGEN_HIP_LIB") or _build.LIB   # override: A/B-ing kernel build variants from bench.py
+        if path == _build.LIB and not os.path.exists(path):
             if not build_if_missing:
                 raise MsdfHipError(ERR_NO_DEVICE, "libmsdfgen_hip.so is not built (python -m msdfgen_amd.build)")
             _build.build_lib()
-        lib = C.CDLL(_build.LIB)
+        lib = C.CDLL(path)
         for name, (restype, argtypes) in _PROTOS.items():
             fn = getattr(lib, name)  # AttributeError here == a symbol of include/msdfgen_hip.h is missing from the library
             fn.restype = restype

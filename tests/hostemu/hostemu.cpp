@@ -12,8 +12,12 @@
 #include "../../msdfgen_amd/csrc/msdf_device.hpp"
 #include "../../msdfgen_amd/csrc/msdf_prep.hpp"
 #include "../../msdfgen_amd/csrc/msdf_ec.hpp"
+#include "../../msdfgen_amd/csrc/msdf_ec_fast.hpp"
+#include "../../msdfgen_amd/csrc/msdf_cull.hpp"
 
 using namespace msdfhip;
+
+static long g_lastDeferred = 0;
 
 namespace {
 
@@ -42,10 +46,88 @@ Digest digest(int nC, const int32_t *co, const double *points, const uint8_t *ty
 
 template <int SEL>
 void distanceAt(const Digest &d, const int32_t *co, int nC, bool overlap, V2 p, double *res, double *out) {
+    EdgesAll edges;
+    edges.coff = co;
     if (overlap)
-        shapeDistanceOverlap<SEL>(d.recs.data(), co, d.windings.data(), nC, p, res, 1, out);
+        shapeDistanceOverlap<SEL>(d.recs.data(), edges, d.windings.data(), nC, p, res, 1, out);
     else
-        shapeDistanceSimple<SEL>(d.recs.data(), co, nC, p, out);
+        shapeDistanceSimple<SEL>(d.recs.data(), edges, nC, p, out);
+}
+
+// Phase 1 of k_distance for one 8x8 tile: per-contour channel bounds, cull, ordered compaction (lanes = edges, serialised here).
+struct TileCull {
+    std::vector<int> list, cstart;
+};
+
+template <int SEL>
+TileCull cullTile(const Digest &d, const int32_t *co, int nC, bool overlap, const Xform &t, int tx, int ty, int tile) {
+    TileCull tcull;
+    const V2 tc = unproject(t, mk(tx*tile+.5*tile, ty*tile+.5*tile));
+    const double hx = (.5*tile-.5)/fabs(t.sx), hy = (.5*tile-.5)/fabs(t.sy);
+    const double tr = sqrt(hx*hx+hy*hy);
+    const int groups = overlap ? nC : 1;
+    for (int grp = 0; grp < groups; ++grp) {
+        const int cBegin = overlap ? grp : 0, cEnd = overlap ? grp+1 : nC;
+        const int b = co[cBegin]-co[0], e = co[cEnd]-co[0];
+        double U[3] = { DBL_MAX, DBL_MAX, DBL_MAX };
+        for (int i = b; i < e; ++i) {
+            const double ub = cullUpperDistance(d.recs[i], tc);
+            const int mask = cullMask<SEL>(d.recs[i]);
+            for (int ch = 0; ch < 3; ++ch)
+                if ((mask>>ch)&1)
+                    U[ch] = dmin(U[ch], ub);
+        }
+        for (int c = cBegin; c < cEnd; ++c) {
+            tcull.cstart.push_back((int) tcull.list.size());
+            for (int i = co[c]-co[0]; i < co[c+1]-co[0]; ++i) {
+                const int mask = cullMask<SEL>(d.recs[i]);
+                if (!mask)
+                    continue;
+                double umax = 0;
+                for (int ch = 0; ch < 3; ++ch)
+                    if ((mask>>ch)&1)
+                        umax = dmax(umax, U[ch]);
+                if (cullEdgeSurvives<(SEL >= 2)>(d.recs[i], tc, tr, umax))
+                    tcull.list.push_back(i);
+            }
+        }
+    }
+    tcull.cstart.push_back((int) tcull.list.size());
+    return tcull;
+}
+
+static long g_cullKept = 0, g_cullTotal = 0;
+
+// k_distance for one texel of a tile whose cull result is given (phase 2, lanes = texels).
+template <int SEL>
+void distanceAtCulled(const Digest &d, const TileCull &tcull, int nC, bool overlap, V2 p, double *res, double *out) {
+    EdgesCulled edges;
+    edges.cstart = tcull.cstart.data();
+    edges.list = tcull.list.data();
+    if (overlap)
+        shapeDistanceOverlap<SEL>(d.recs.data(), edges, d.windings.data(), nC, p, res, 1, out);
+    else
+        shapeDistanceSimple<SEL>(d.recs.data(), edges, nC, p, out);
+}
+
+template <int SEL>
+void renderField(const Digest &d, const int32_t *co, int nC, bool overlap, const Xform &t, int w, int h, int flip, int N, double *res, float *tile) {
+    const int T = 8;
+    for (int ty = 0; ty*T < h; ++ty)
+        for (int tx = 0; tx*T < w; ++tx) {
+            TileCull tcull = cullTile<SEL>(d, co, nC, overlap, t, tx, ty, T);
+            g_cullKept += (long) tcull.list.size();
+            g_cullTotal += co[nC]-co[0];
+            for (int y = ty*T; y < ty*T+T && y < h; ++y)
+                for (int x = tx*T; x < tx*T+T && x < w; ++x) {
+                    V2 p = unproject(t, mk(x+.5, y+.5));
+                    double o[4];
+                    distanceAtCulled<SEL>(d, tcull, nC, overlap, p, res, o);
+                    const int yn = flip ? h-1-y : y;
+                    for (int ch = 0; ch < N; ++ch)
+                        tile[((size_t) yn*w+x)*N+ch] = mapDistance(t, o[ch]);
+                }
+        }
 }
 
 void distanceAtSel(int sel, const Digest &d, const int32_t *co, int nC, bool overlap, V2 p, double *res, double *out) {
@@ -73,6 +155,30 @@ struct HostQuery {
 }
 
 extern "C" {
+
+long emu_last_deferred() { return g_lastDeferred; }
+void emu_cull_stats(long *kept, long *total, int reset) { *kept = g_cullKept, *total = g_cullTotal; if (reset) g_cullKept = g_cullTotal = 0; }
+
+// Fuzz of the exact-skip prefilter of the diagonal test: returns the number of coefficient triples for which
+// quadraticMayHaveRootInRange() said "no" although solveQuadratic() yields a root inside (0.01, 0.99). Must be 0.
+long emu_quadratic_prefilter_violations(const float *abc, long n, long *skipped) {
+    long bad = 0, skip = 0;
+    for (long i = 0; i < n; ++i) {
+        const float dA = abc[3*i], dBC = abc[3*i+1], dD = abc[3*i+2];
+        const double qa = dD-dBC+dA, qb = dBC-dA-dA, qc = dA;
+        if (!quadraticMayHaveRootInRange(qa, qb, qc)) {
+            ++skip;
+            double t[2];
+            int m = solveQuadratic(t, qa, qb, qc);
+            for (int k = 0; k < m; ++k)
+                if (t[k] > MSDF_ARTIFACT_T_EPSILON && t[k] < 1-MSDF_ARTIFACT_T_EPSILON)
+                    ++bad;
+        }
+    }
+    if (skipped)
+        *skipped = skip;
+    return bad;
+}
 
 void emu_windings(int nC, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors, int32_t *out) {
     Digest d = digest(nC, co, points, types, colors);
@@ -105,15 +211,12 @@ void emu_generate(int mode, int correctionOnly, float *pixels, int w, int h, int
         for (int y = 0; y < h; ++y)
             memcpy(&tile[(size_t) y*w*N], pixels+(ptrdiff_t) rowStride*y, sizeof(float)*(size_t) w*N);
     } else {
-        for (int y = 0; y < h; ++y)
-            for (int x = 0; x < w; ++x) {
-                V2 p = unproject(t, mk(x+.5, y+.5));
-                double o[4];
-                distanceAtSel(mode, d, co, nC, overlap != 0, p, res.data(), o);
-                const int yn = flip ? h-1-y : y;
-                for (int ch = 0; ch < N; ++ch)
-                    tile[((size_t) yn*w+x)*N+ch] = mapDistance(t, o[ch]);
-            }
+        switch (mode) {
+            case 1: renderField<1>(d, co, nC, overlap != 0, t, w, h, flip, N, res.data(), tile.data()); break;
+            case 2: renderField<2>(d, co, nC, overlap != 0, t, w, h, flip, N, res.data(), tile.data()); break;
+            case 3: renderField<3>(d, co, nC, overlap != 0, t, w, h, flip, N, res.data(), tile.data()); break;
+            default: renderField<4>(d, co, nC, overlap != 0, t, w, h, flip, N, res.data(), tile.data()); break;
+        }
     }
     const bool correct = N >= 3 && ecMode != EC_MODE_DISABLED;
     if (!correct) {
@@ -129,9 +232,36 @@ void emu_generate(int mode, int correctionOnly, float *pixels, int w, int h, int
     SdfView sdf;
     sdf.px = tile.data(), sdf.w = w, sdf.h = h, sdf.N = N, sdf.flip = flip;
     HostQuery q = { &d, co, nC, overlap != 0, res.data() };
+    // k_ec_fast prologue: protectCorners list (lanes = edges, ordered)
+    std::vector<int> corners;
+    if (ecMode == EC_MODE_EDGE_PRIORITY)
+        for (int e = 0; e < nE; ++e)
+            if (d.recs[e].flags&REC_CORNER) {
+                V2 pp = project(t, ld(d.recs[e].p));
+                corners.push_back((int) floor(pp.x-.5));
+                corners.push_back((int) floor(pp.y-.5));
+            }
+    long deferredCount = 0;
     for (int yn = 0; yn < h; ++yn)
         for (int x = 0; x < w; ++x) {
-            const int st = ecTexelStencil(sdf, p, d.recs.data(), nE, x, yn, &q);
+            int st;
+            if (stageLimit != 0)
+                st = ecTexelStencil(sdf, p, d.recs.data(), nE, x, yn, &q);           // k_ec_slow over all texels (stage snapshots)
+            else {
+                struct Cand { double t; int dx, dy; };
+                struct VecSink {
+                    std::vector<Cand> v;
+                    void operator()(double t, int dx, int dy) { Cand c = { t, dx, dy }; v.push_back(c); }
+                } sink;
+                st = ecTexelFast(sdf, p, corners.data(), (int) corners.size()/2, x, yn, sink); // k_ec_fast
+                st &= ~EC_DEFER;
+                const int ys = flip ? h-1-yn : yn;
+                for (size_t k = 0; k < sink.v.size(); ++k) {                              // k_ec_query, one candidate each
+                    ++deferredCount;
+                    if (ecEvaluateCandidate(sdf, p, x, ys, sink.v[k].t, sink.v[k].dx, sink.v[k].dy, q))
+                        st |= EC_ERROR;
+                }
+            }
             const float *in = sdf.native(x, yn);
             float v[4];
             for (int i = 0; i < N; ++i)
@@ -146,6 +276,7 @@ void emu_generate(int mode, int correctionOnly, float *pixels, int w, int h, int
             if (stencil)
                 stencil[(size_t) yn*w+x] = (uint8_t) st;
         }
+    g_lastDeferred = deferredCount;
 }
 
 }

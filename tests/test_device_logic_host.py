@@ -89,3 +89,71 @@ def test_degenerate_inputs(emu, oracle):
     for mode in (1, 2, 3, 4):
         for ov in (True, False):
             assert_bit_equal(emu.generate(s, mode, 20, 16, xf, overlap=ov), oracle.generate(s, mode, 20, 16, xf, overlap=ov), "degenerate mode %d" % mode)
+
+
+def test_quadratic_prefilter_never_skips_a_real_candidate(emu):
+    """msdf_ec_fast.hpp skips solveQuadratic when the quadratic provably has no root in [0.005, 0.995]; fuzz that claim."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    n = 2_000_000
+    abc = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    abc[:n//4] *= rng.choice([1e-3, 1e-6, 1, 10], (n//4, 1)).astype(np.float32)           # mixed magnitudes
+    abc[n//4:n//2, 2] = abc[n//4:n//2, 0]*rng.uniform(.9, 1.1, n//4).astype(np.float32)   # near-degenerate: dD ~ dA
+    abc[n//2:3*n//4, 1] = 2*abc[n//2:3*n//4, 0]                                           # b ~ 0 region, tiny a
+    abc[-1000:] = 0
+    emu.lib.emu_quadratic_prefilter_violations.restype = C.c_long
+    skipped = C.c_long()
+    bad = emu.lib.emu_quadratic_prefilter_violations(abc.ctypes.data_as(C.POINTER(C.c_float)), C.c_long(n), C.byref(skipped))
+    assert bad == 0
+    assert skipped.value > n//4  # the prefilter is actually doing something
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_fast_error_correction_all_configs(emu, oracle, seed):
+    rng = np.random.default_rng(900+seed)
+    s = synth.random_shape(7000+seed, n_contours=1+seed % 4, kinds=(1, 2, 3), holes=bool(seed & 1))
+    s.inverse_y = bool(seed & 2)
+    w, h = int(rng.integers(12, 44)), int(rng.integers(12, 44))
+    xf = autoframe(s.bounds(), w, h, float(rng.uniform(1.5, 6)))
+    for ec_mode in (1, 2, 3):
+        for ec_dist in (0, 1, 2):
+            for mode in (3, 4):
+                a = oracle.generate(s, mode, w, h, xf, ec_mode=ec_mode, ec_dist=ec_dist, y_down=bool(seed & 4))
+                b = emu.generate(s, mode, w, h, xf, ec_mode=ec_mode, ec_dist=ec_dist, y_down=bool(seed & 4))
+                assert_bit_equal(b, a, "seed %d ec %d/%d mode %d" % (seed, ec_mode, ec_dist, mode))
+
+
+def test_full_latin_default_pipeline_checksum(emu, latin):
+    import hashlib
+    batch, xf64, _ = latin
+    z = load_npz("outputs.npz")
+    for mode, key in ((3, "msdf"), (4, "mtsdf")):
+        full = np.stack([emu.generate(batch.shape(g), mode, 64, 64, xf64[g]) for g in range(batch.n_glyphs)])
+        assert hashlib.sha256(full.tobytes()).hexdigest() == str(z["sha_full_%s64" % key]), key
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_tile_culling_is_exact(emu, oracle, seed):
+    """k_distance drops edges per 8x8 tile (msdf_cull.hpp); the result must stay bit-identical for every selector and combiner,
+    also when tiles are small relative to the shape (large bitmaps, tight ranges) and when many contours overlap."""
+    import ctypes as C
+    rng = np.random.default_rng(4000+seed)
+    if seed % 4 == 0:
+        s = synth.cjk_like_shape(100+seed)
+    elif seed % 4 == 1:
+        s = synth.logo_shape(seed, n_blobs=5+seed % 5, edges=(4, 9))
+    else:
+        s = synth.random_shape(9000+seed, n_contours=1+seed % 6, kinds=(1, 2, 3), holes=bool(seed & 1), spread=.9)
+    s.inverse_y = bool(seed & 2)
+    w, h = int(rng.integers(20, 100)), int(rng.integers(20, 100))
+    xf = autoframe(s.bounds(), w, h, float(rng.uniform(.5, 8)))
+    xf[1] *= rng.uniform(.7, 1.4)
+    kept, total = C.c_long(), C.c_long()
+    emu.lib.emu_cull_stats(C.byref(kept), C.byref(total), 1)
+    for mode in (1, 2, 3, 4):
+        for ov in (True, False):
+            a = oracle.generate(s, mode, w, h, xf, overlap=ov, ec_mode=0)
+            b = emu.generate(s, mode, w, h, xf, overlap=ov, ec_mode=0)
+            assert_bit_equal(b, a, "seed %d mode %d overlap %d" % (seed, mode, ov))
+    emu.lib.emu_cull_stats(C.byref(kept), C.byref(total), 1)
+    assert 0 < kept.value <= total.value
