@@ -119,7 +119,7 @@ int msdfhip_generate_mtsdf(float *pixels, int width, int height, int row_stride,
                            const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil);  /* msdfgen.h:53 */
 
 /* msdfErrorCorrection(sdf, shape, transformation, config) on an existing 3- or 4-channel bitmap, in place.
- *   replaces core/msdf-error-correction.cpp:50-65 (declared core/msdf-error-correction.h:15-18). */
+ *   replaces core/msdf-error-correction.cpp:61-72 (declared core/msdf-error-correction.h:15-18). */
 int msdfhip_error_correction(int channels, float *pixels, int width, int height, int row_stride, int flip,
                              const int32_t *contour_offsets, int n_contours, const double *points, const uint8_t *types, const uint8_t *colors,
                              const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil);

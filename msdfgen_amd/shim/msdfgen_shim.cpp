@@ -1,0 +1,181 @@
+// msdfgen_shim.cpp -- C++ drop-in: msdfgen's OWN generator signatures (msdfgen.h:46-69, core/msdf-error-correction.h:15-18),
+// implemented on the MI355X through the C ABI of libmsdfgen_hip.so.
+//
+// Build against the user's msdfgen checkout (headers only; this file includes <msdfgen.h>) and link it INSTEAD of the reference's
+// definitions of the same functions (core/msdfgen.cpp:78-162, core/msdf-error-correction.cpp:61-72) -- see INTEGRATION.md.
+// Callers such as msdf-atlas-gen's glyph generators then run the HIP path unchanged.
+//
+// Differences from the reference that a caller can observe: none in the texels (see tests); the functions can now fail (no
+// device, HIP error) and there is deliberately NO CPU fallback -- failures throw std::runtime_error with the library's message.
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "msdfgen.h"
+#include "msdfgen_hip.h"
+
+namespace msdfgen {
+
+namespace {
+
+struct FlatShape {
+    std::vector<int32_t> contourOffsets;
+    std::vector<double> points;
+    std::vector<uint8_t> types, colors;
+};
+
+// const Shape & -> CSR edge buffer (read-only traversal: contours[i].edges[j]->type()/controlPoints()/color, core/Shape.h:24, core/edge-segments.h:28-31).
+void flatten(const Shape &shape, FlatShape &flat) {
+    const int edges = shape.edgeCount();
+    flat.contourOffsets.reserve(shape.contours.size()+1);
+    flat.points.reserve(8*(size_t) edges);
+    flat.types.reserve(edges);
+    flat.colors.reserve(edges);
+    flat.contourOffsets.push_back(0);
+    for (std::vector<Contour>::const_iterator contour = shape.contours.begin(); contour != shape.contours.end(); ++contour) {
+        for (std::vector<EdgeHolder>::const_iterator edge = contour->edges.begin(); edge != contour->edges.end(); ++edge) {
+            const int type = (*edge)->type();
+            const Point2 *p = (*edge)->controlPoints();
+            for (int i = 0; i < 4; ++i) {
+                flat.points.push_back(i <= type ? p[i].x : 0.);
+                flat.points.push_back(i <= type ? p[i].y : 0.);
+            }
+            flat.types.push_back((uint8_t) type);
+            flat.colors.push_back((uint8_t) (*edge)->color);
+        }
+        flat.contourOffsets.push_back((int32_t) flat.types.size());
+    }
+    if (flat.types.empty()) {            // keep the pointers valid for an empty shape
+        flat.points.resize(8);
+        flat.types.push_back(1);
+        flat.colors.push_back(0);
+    }
+}
+
+// Projection and DistanceMapping keep their members private (core/Projection.h:31-33, core/DistanceMapping.h:28-32).
+// Projection is recovered exactly through its public API; DistanceMapping by its object representation (two doubles, in the
+// order {scale, translate}), verified against its public operator() before use.
+void transformationToXf(const SDFTransformation &t, double xf[6]) {
+    const Vector2 scale = t.projectVector(Vector2(1, 1));          // scale*1, exact (core/Projection.cpp:18-20)
+    const Point2 origin = t.unproject(Point2(0, 0));               // 0/scale-translate = -translate, exact (core/Projection.cpp:14-16)
+    xf[0] = scale.x, xf[1] = scale.y, xf[2] = -origin.x, xf[3] = -origin.y;
+    static_assert(sizeof(DistanceMapping) == 2*sizeof(double), "DistanceMapping layout changed; update the shim");
+    double raw[2];
+    std::memcpy(raw, &t.distanceMapping, sizeof(raw));
+    const double probes[3] = { 0., 1., -.375 };
+    for (int i = 0; i < 3; ++i)
+        if (!(raw[0]*(probes[i]+raw[1]) == t.distanceMapping(probes[i])))
+            throw std::runtime_error("msdfgen_hip shim: DistanceMapping layout does not match {scale, translate}");
+    xf[4] = raw[0], xf[5] = raw[1];
+}
+
+MsdfHipConfig makeConfig(bool overlapSupport, const ErrorCorrectionConfig *ec) {
+    MsdfHipConfig cfg;
+    msdfhip_default_config(&cfg);
+    cfg.overlap_support = overlapSupport ? 1 : 0;
+    if (ec) {
+        cfg.ec_mode = (int) ec->mode;                              // same enumerator order as core/generator-config.h:20-38
+        cfg.ec_distance_check = (int) ec->distanceCheckMode;
+        cfg.min_deviation_ratio = ec->minDeviationRatio;
+        cfg.min_improve_ratio = ec->minImproveRatio;
+    }
+    return cfg;
+}
+
+void check(int rc, const char *what) {
+    if (rc != MSDFHIP_OK)
+        throw std::runtime_error(std::string("msdfgen_hip: ")+what+" failed: "+msdfhip_last_error());
+}
+
+template <int N>
+void generate(int mode, const BitmapSection<float, N> &output, const Shape &shape, const SDFTransformation &transformation, bool overlapSupport, const ErrorCorrectionConfig *ec) {
+    FlatShape flat;
+    flatten(shape, flat);
+    double xf[6];
+    transformationToXf(transformation, xf);
+    const MsdfHipConfig cfg = makeConfig(overlapSupport, ec);
+    const int flip = shape.getYAxisOrientation() != output.yOrientation;   // output.reorient(shape.getYAxisOrientation()), core/msdfgen.cpp:55
+    check(msdfhip_generate(mode, output.pixels, output.width, output.height, output.rowStride, flip, flat.contourOffsets.data(),
+                           (int) shape.contours.size(), flat.points.data(), flat.types.data(), flat.colors.data(), xf, &cfg, ec ? ec->buffer : NULL),
+          "generate");
+}
+
+template <int N>
+void correct(const BitmapSection<float, N> &sdf, const Shape &shape, const SDFTransformation &transformation, const MSDFGeneratorConfig &config) {
+    FlatShape flat;
+    flatten(shape, flat);
+    double xf[6];
+    transformationToXf(transformation, xf);
+    const MsdfHipConfig cfg = makeConfig(config.overlapSupport, &config.errorCorrection);
+    const int flip = shape.getYAxisOrientation() != sdf.yOrientation;
+    check(msdfhip_error_correction(N, sdf.pixels, sdf.width, sdf.height, sdf.rowStride, flip, flat.contourOffsets.data(), (int) shape.contours.size(),
+                                   flat.points.data(), flat.types.data(), flat.colors.data(), xf, &cfg, config.errorCorrection.buffer),
+          "msdfErrorCorrection");
+}
+
+}
+
+// ---- msdfgen.h:46-53
+void generateSDF(const BitmapSection<float, 1> &output, const Shape &shape, const SDFTransformation &transformation, const GeneratorConfig &config) {
+    generate<1>(MSDFHIP_MODE_SDF, output, shape, transformation, config.overlapSupport, NULL);
+}
+void generatePSDF(const BitmapSection<float, 1> &output, const Shape &shape, const SDFTransformation &transformation, const GeneratorConfig &config) {
+    generate<1>(MSDFHIP_MODE_PSDF, output, shape, transformation, config.overlapSupport, NULL);
+}
+void generateMSDF(const BitmapSection<float, 3> &output, const Shape &shape, const SDFTransformation &transformation, const MSDFGeneratorConfig &config) {
+    generate<3>(MSDFHIP_MODE_MSDF, output, shape, transformation, config.overlapSupport, &config.errorCorrection);
+}
+void generateMTSDF(const BitmapSection<float, 4> &output, const Shape &shape, const SDFTransformation &transformation, const MSDFGeneratorConfig &config) {
+    generate<4>(MSDFHIP_MODE_MTSDF, output, shape, transformation, config.overlapSupport, &config.errorCorrection);
+}
+
+// ---- msdfgen.h:59-63 (Projection + Range; the form msdf-atlas-gen calls)
+void generateSDF(const BitmapSection<float, 1> &output, const Shape &shape, const Projection &projection, Range range, const GeneratorConfig &config) {
+    generateSDF(output, shape, SDFTransformation(projection, range), config);
+}
+void generatePSDF(const BitmapSection<float, 1> &output, const Shape &shape, const Projection &projection, Range range, const GeneratorConfig &config) {
+    generatePSDF(output, shape, SDFTransformation(projection, range), config);
+}
+void generatePseudoSDF(const BitmapSection<float, 1> &output, const Shape &shape, const Projection &projection, Range range, const GeneratorConfig &config) {
+    generatePSDF(output, shape, SDFTransformation(projection, range), config);
+}
+void generateMSDF(const BitmapSection<float, 3> &output, const Shape &shape, const Projection &projection, Range range, const MSDFGeneratorConfig &config) {
+    generateMSDF(output, shape, SDFTransformation(projection, range), config);
+}
+void generateMTSDF(const BitmapSection<float, 4> &output, const Shape &shape, const Projection &projection, Range range, const MSDFGeneratorConfig &config) {
+    generateMTSDF(output, shape, SDFTransformation(projection, range), config);
+}
+
+// ---- msdfgen.h:65-69 (legacy Range/scale/translate)
+void generateSDF(const BitmapSection<float, 1> &output, const Shape &shape, Range range, const Vector2 &scale, const Vector2 &translate, bool overlapSupport) {
+    generateSDF(output, shape, Projection(scale, translate), range, GeneratorConfig(overlapSupport));
+}
+void generatePSDF(const BitmapSection<float, 1> &output, const Shape &shape, Range range, const Vector2 &scale, const Vector2 &translate, bool overlapSupport) {
+    generatePSDF(output, shape, Projection(scale, translate), range, GeneratorConfig(overlapSupport));
+}
+void generatePseudoSDF(const BitmapSection<float, 1> &output, const Shape &shape, Range range, const Vector2 &scale, const Vector2 &translate, bool overlapSupport) {
+    generatePSDF(output, shape, Projection(scale, translate), range, GeneratorConfig(overlapSupport));
+}
+void generateMSDF(const BitmapSection<float, 3> &output, const Shape &shape, Range range, const Vector2 &scale, const Vector2 &translate, const ErrorCorrectionConfig &errorCorrectionConfig, bool overlapSupport) {
+    generateMSDF(output, shape, Projection(scale, translate), range, MSDFGeneratorConfig(overlapSupport, errorCorrectionConfig));
+}
+void generateMTSDF(const BitmapSection<float, 4> &output, const Shape &shape, Range range, const Vector2 &scale, const Vector2 &translate, const ErrorCorrectionConfig &errorCorrectionConfig, bool overlapSupport) {
+    generateMTSDF(output, shape, Projection(scale, translate), range, MSDFGeneratorConfig(overlapSupport, errorCorrectionConfig));
+}
+
+// ---- core/msdf-error-correction.h:15-18
+void msdfErrorCorrection(const BitmapSection<float, 3> &sdf, const Shape &shape, const SDFTransformation &transformation, const MSDFGeneratorConfig &config) {
+    correct<3>(sdf, shape, transformation, config);
+}
+void msdfErrorCorrection(const BitmapSection<float, 4> &sdf, const Shape &shape, const SDFTransformation &transformation, const MSDFGeneratorConfig &config) {
+    correct<4>(sdf, shape, transformation, config);
+}
+void msdfErrorCorrection(const BitmapSection<float, 3> &sdf, const Shape &shape, const Projection &projection, Range range, const MSDFGeneratorConfig &config) {
+    correct<3>(sdf, shape, SDFTransformation(projection, range), config);
+}
+void msdfErrorCorrection(const BitmapSection<float, 4> &sdf, const Shape &shape, const Projection &projection, Range range, const MSDFGeneratorConfig &config) {
+    correct<4>(sdf, shape, SDFTransformation(projection, range), config);
+}
+
+}

@@ -1,0 +1,36 @@
+"""The C++ drop-in (msdfgen_amd/shim/msdfgen_shim.cpp): a client written against msdfgen's own headers (tests/shim/shim_check.cpp,
+after README.md:114-142) calls msdfgen::generateSDF/PSDF/MSDF/MTSDF with the reference's signatures and gets the HIP path.
+The client binary is built in the authoring container (needs the msdfgen headers + the reference's non-hot-path objects) and
+travels to the GPU box; the test is skipped where it does not exist."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import load_npz, bits
+from msdfgen_amd.shape import FlatShape
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+BIN = os.path.join(HERE, "shim", "shim_check")
+
+
+@pytest.mark.parametrize("mode,ydown", [(1, 0), (2, 0), (3, 0), (4, 0), (3, 1)])
+def test_reference_client_through_cpp_shim(tmp_path, oracle, mode, ydown):
+    if not os.path.exists(BIN):
+        pytest.skip("tests/shim/shim_check not built (needs the msdfgen headers)")
+    z = load_npz("shape_a.npz")
+    s = FlatShape(z["contour_offsets"], z["points"], z["types"], z["colors"])
+    desc = tmp_path/"a.txt"
+    desc.write_text(str(z["desc"]))
+    out = tmp_path/"a.bin"
+    w, h = 40, 32
+    scale, tx, ty, rng = 2.75, .625, .71875, 1.5   # exactly representable / round-trip safe
+    r = subprocess.run([BIN, str(desc), str(out), str(mode), str(w), str(h), repr(scale), repr(tx), repr(ty), repr(rng), str(ydown)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    n = {1: 1, 2: 1, 3: 3, 4: 4}[mode]
+    got = np.fromfile(out, np.float32).reshape(h, w, n)
+    want = oracle.generate(s, mode, w, h, [scale, scale, tx, ty, -.5*rng, .5*rng], y_down=bool(ydown))
+    assert np.abs(got.astype(np.float64)-want).max() <= 1e-5
+    print("bitwise differing:", int((bits(got) != bits(want)).sum()))
