@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -130,8 +131,12 @@ int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan) {
     if (resBytes+idxBytes > limit)
         return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours / %d edges: the combiner state needs %zu B of LDS per wavefront, device limit is %zu B",
                     b->maxContours, b->maxEdges, resBytes+idxBytes, limit);
-    // Staging the surviving records pays while several workgroups still fit on a CU: keep the total within 40 KB (>= 4 per CU).
-    plan.ldsRec = resBytes+recBytes+idxBytes <= 40*1024;
+    // Measured on MI355X (profiles/): reading the surviving records straight from global memory with wave-uniform
+    // (scalar) loads beats staging them in LDS, because the LDS footprint of the worst-case glyph caps occupancy. Staging stays
+    // available as an experiment knob (MSDFHIP_LDSREC=1) while it fits in 40 KB.
+    plan.ldsRec = false;
+    if (const char *force = getenv("MSDFHIP_LDSREC"))
+        plan.ldsRec = force[0] == '1' && resBytes+recBytes+idxBytes <= 40*1024;
     plan.bytes = resBytes+(plan.ldsRec ? recBytes : 0)+idxBytes;
     return MSDFHIP_OK;
 }

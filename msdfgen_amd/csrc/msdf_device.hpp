@@ -18,11 +18,17 @@
 #define MSDF_NOINLINE __attribute__((noinline))
 #define MSDF_NOUNROLL _Pragma("clang loop unroll(disable)")
 #define MSDF_UNROLL _Pragma("unroll")
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MSDF_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // value is identical in every active lane: keep it in an SGPR
+#else
+#define MSDF_UNIFORM(x) (x)
+#endif
 #else
 #define MSDF_HD inline
 #define MSDF_NOINLINE
 #define MSDF_NOUNROLL
 #define MSDF_UNROLL
+#define MSDF_UNIFORM(x) (x)
 #endif
 
 namespace msdfhip {
@@ -493,9 +499,9 @@ struct EdgesAll {                       // every edge, straight from the CSR off
 struct EdgesCulled {                    // survivors of the per-tile cull (msdf_cull.hpp), still grouped by contour and in visit order
     const int *cstart;                  // C+1 compacted offsets
     const int *list;                    // record index per position, or NULL if the surviving records were copied in this order
-    MSDF_HD int begin(int c) const { return cstart[c]; }
-    MSDF_HD int end(int c) const { return cstart[c+1]; }
-    MSDF_HD int at(int k) const { return list ? list[k] : k; }
+    MSDF_HD int begin(int c) const { return MSDF_UNIFORM(cstart[c]); }
+    MSDF_HD int end(int c) const { return MSDF_UNIFORM(cstart[c+1]); }
+    MSDF_HD int at(int k) const { return list ? MSDF_UNIFORM(list[k]) : k; }   // uniform index -> scalar loads of the record
 };
 
 template <int SEL, class Edges>

@@ -100,13 +100,29 @@ __device__ inline void stageRecords(double *dst, const EdgeRec *src, int n) {
 
 // ----------------------------------------------------------------------------------------------------- distance field
 
-// Wave-wide minimum of a double (all 64 lanes receive it).
-__device__ inline double waveMin(double v) {
-    for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_xor(v, off, WAVE);
-        v = o < v ? o : v;
-    }
-    return v;
+// Wave-wide minimum of non-negative floats via DPP row shifts / broadcasts (VALU speed; a shuffle-based reduction costs an LDS
+// round trip per step). Non-negative IEEE floats order like their bit patterns, so the reduction runs on ints.
+// All 64 lanes must be active. Result is broadcast to every lane.
+__device__ inline float waveMinNonNegative(float v) {
+    int x = __float_as_int(v);
+    const int inf = 0x7f800000;
+#define MSDF_DPP_MIN(ctrl, rowmask) { const int y = __builtin_amdgcn_update_dpp(inf, x, ctrl, rowmask, 0xf, false); x = y < x ? y : x; }
+    MSDF_DPP_MIN(0x111, 0xf)   // row_shr:1
+    MSDF_DPP_MIN(0x112, 0xf)   // row_shr:2
+    MSDF_DPP_MIN(0x114, 0xf)   // row_shr:4
+    MSDF_DPP_MIN(0x118, 0xf)   // row_shr:8   -> lane 15 of every row holds the row minimum
+    MSDF_DPP_MIN(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+    MSDF_DPP_MIN(0x143, 0xc)   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave minimum
+#undef MSDF_DPP_MIN
+    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+
+// Smallest float >= d (d >= 0): the culling bounds only need to be conservative, so they travel as fp32 rounded up.
+__device__ inline float floatAbove(double d) {
+    float f = (float) d;
+    if ((double) f < d)
+        f = __int_as_float(__float_as_int(f)+1);
+    return f;
 }
 
 // dst: tile-major destination. If toScratch, texels go to the tightly packed pre-correction buffer [g][h][w][N] (native rows),
@@ -120,7 +136,7 @@ template <int SEL, bool OVERLAP, bool LDSREC>
 __global__ void __launch_bounds__(WAVE, MSDF_DISTANCE_WAVES_PER_SIMD)
 k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges, float *dst, int toScratch) {
     enum { NCH = SelTraits<SEL>::NCH };
-    extern __shared__ double smem[];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     const GlyphWork wk = decodeBlock(batch.nGlyphs, tilesPerGlyph);
     if (!wk.valid)
         return;
@@ -154,14 +170,15 @@ k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, i
         U[0] = U[1] = U[2] = DBL_MAX;
         for (int base = b; base < e; base += WAVE) {
             const int i = base+lane;
-            double ub = DBL_MAX;
+            double ub = 0;
             int mask = 0;
             if (i < e) {
                 ub = cullUpperDistance(recGlobal[i], tc);
                 mask = cullMask<SEL>(recGlobal[i]);
             }
+            const float ubf = floatAbove(ub);
             for (int ch = 0; ch < (SEL <= 2 ? 1 : 3); ++ch)
-                U[ch] = dmin(U[ch], waveMin((mask>>ch)&1 ? ub : DBL_MAX));
+                U[ch] = dmin(U[ch], (double) waveMinNonNegative((mask>>ch)&1 ? ubf : __int_as_float(0x7f800000)));
         }
         for (int c = cBegin; c < cEnd; ++c) {
             const int cb = coff[c]-e0, ce = coff[c+1]-e0;
@@ -197,7 +214,7 @@ k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, i
             if (lane < REC_DOUBLES)
                 recLds[(size_t) k*REC_DOUBLES+lane] = src[lane];
         }
-        rec = reinterpret_cast<const EdgeRec *>(recLds);
+        rec = reinterpret_cast<const EdgeRec *>(__builtin_assume_aligned(recLds, 16));
         __syncthreads();
     }
 
