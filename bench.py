@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--glyphs", type=int, default=8192, help="glyph tiles per GPU per step")
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--simple-combiner", action="store_true", help="experiment: overlapSupport=false (NOT the headline config)")
     args = ap.parse_args()
 
     import torch
@@ -114,9 +115,11 @@ def main():
     out = torch.empty((batch.n_glyphs, h, w, 3), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
 
+    cfg = M.MSDFGeneratorConfig(overlap_support=not args.simple_combiner)
+
     def step():
         gb.digest(stream)
-        gb.generate(M.MODE_MSDF, w, h, descriptors=desc, out=out, stream=stream)
+        gb.generate(M.MODE_MSDF, w, h, descriptors=desc, out=out, stream=stream, config=cfg)
 
     def fence():
         torch.cuda.synchronize(dev)

@@ -89,6 +89,7 @@ struct MsdfHipBatch {
     mutable float *dScratch;
     mutable size_t scratchFloats;
     mutable EcCandidate *dDeferred;   // [0] = header (count), [1..cap] = distance checks deferred to k_ec_query
+    mutable EcGlyphParams *dEcParams; // per-glyph constants of the error-correction pass
     mutable size_t deferredCap;
     mutable std::mutex scratchMutex;
 };
@@ -184,6 +185,8 @@ int ensureDeferred(const MsdfHipBatch *b, size_t cap, EcCandidate **out) {
         HIPCHK(hipMalloc((void **) &b->dDeferred, (cap+1)*sizeof(EcCandidate)));
         b->deferredCap = cap;
     }
+    if (!b->dEcParams)
+        HIPCHK(hipMalloc((void **) &b->dEcParams, sizeof(EcGlyphParams)*(size_t) (b->nGlyphs > 0 ? b->nGlyphs : 1)));
     *out = b->dDeferred;
     return MSDFHIP_OK;
 }
@@ -223,8 +226,9 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     rc = setLds(k_ec_fast<N>, fastLds);
     if (rc != MSDFHIP_OK)
         return rc;
+    hipLaunchKernelGGL(k_ec_params, dim3((b->nGlyphs+255)/256), dim3(256), 0, stream, b->dEcParams, dGlyphs, b->nGlyphs, cfg);
     hipLaunchKernelGGL((k_ec_fast<N>), dim3(blocks), dim3(WAVE), fastLds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, src, out, stencil, cfg,
-                       deferred, (unsigned) cap);
+                       (const EcGlyphParams *) b->dEcParams, deferred, (unsigned) cap);
     hipLaunchKernelGGL((k_ec_query<N, OVERLAP>), dim3(1024), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
                        (const EcCandidate *) deferred, (unsigned) cap);
     hipLaunchKernelGGL((k_ec_slow<N, OVERLAP>), dim3(2048), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
@@ -341,7 +345,7 @@ int msdfhip_batch_create_device(MsdfHipBatch **batch, int n_glyphs, int n_contou
     b->dPoints = const_cast<double *>(d_points);
     b->dTypes = const_cast<uint8_t *>(d_types);
     b->dColors = const_cast<uint8_t *>(d_colors);
-    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0;
+    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0, b->dEcParams = NULL;
     rc = digest(b, (hipStream_t) stream);
     if (rc != MSDFHIP_OK) {
         msdfhip_batch_destroy(b);
@@ -378,7 +382,7 @@ int msdfhip_batch_create(MsdfHipBatch **batch, int n_glyphs, const int32_t *gco,
     b->nGlyphs = n_glyphs, b->nContours = nC, b->nEdges = nE, b->maxContours = maxC, b->maxEdges = maxE;
     b->ownsInputs = true;
     b->dGlyphContourOffsets = NULL, b->dContourOffsets = NULL, b->dPoints = NULL, b->dTypes = NULL, b->dColors = NULL;
-    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0;
+    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0, b->dEcParams = NULL;
     const size_t eAlloc = nE > 0 ? nE : 1;
     #define ALLOC_COPY(dst, src, bytes, used) do { \
         hipError_t e_ = hipMalloc((void **) &(dst), (bytes) ? (bytes) : 16); \
@@ -424,6 +428,7 @@ void msdfhip_batch_destroy(MsdfHipBatch *b) {
     hipFree(b->dWindings);
     hipFree(b->dScratch);
     hipFree(b->dDeferred);
+    hipFree(b->dEcParams);
     delete b;
 }
 

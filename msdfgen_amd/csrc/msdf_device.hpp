@@ -39,7 +39,8 @@ enum : int32_t {
     REC_A_ZERO = 1,   // direction(0) has zero length: normalize() yields (0,1), normalize(true) yields (0,0) (Vector2.hpp:42-46)
     REC_B_ZERO = 2,   // same for direction(1)
     REC_NORMED = 4,   // quadratic: a != 0 && |b/a| < 1e6 -> solveCubicNormed, else solveQuadratic (equation-solver.cpp:63-70)
-    REC_CORNER = 8    // colour changes between the previous edge and this one (MSDFErrorCorrection.cpp:127-129)
+    REC_CORNER = 8,   // colour changes between the previous edge and this one (MSDFErrorCorrection.cpp:127-129)
+    REC_FASTDIV = 16  // every pixel-independent divisor of this edge has an exactly usable reciprocal in rcp[] (see divExact)
 };
 
 struct alignas(16) EdgeRec {
@@ -61,12 +62,13 @@ struct alignas(16) EdgeRec {
     double lo[2];     // bounding box of the control points (tile culling only, msdf_cull.hpp)
     double hi[2];
     double mid[2];    // point(0.5): an on-curve sample (tile culling only)
+    double rcp[4];    // RN(1/divisor) of the pixel-independent divisors: linear {ab.ab}; quadratic {a, e0dot, e1dot}; cubic {-, e0dot, e1dot}
     int32_t type;     // 1, 2, 3
     int32_t color;    // EdgeColor bitmask
     int32_t flags;    // REC_*
     int32_t contour;  // contour index within the batch
 };
-static_assert(sizeof(EdgeRec) == 336, "EdgeRec layout");
+static_assert(sizeof(EdgeRec) == 368, "EdgeRec layout");
 
 struct V2 { double x, y; };
 
@@ -104,6 +106,26 @@ MSDF_HD float fmax_(float a, float b) { return a < b ? b : a; }
 MSDF_HD float medianf(float a, float b, float c) { return fmax_(fmin_(a, b), fmin_(fmax_(a, b), c)); }
 MSDF_HD float mixf(float a, float b, double w) { return (float) ((1.-w)*a+w*b); } // arithmetics.hpp:27-31 (T=float, S=double)
 
+// Correctly rounded quotient a/b from y = RN(1/b) with two FMAs (Markstein, "Computation of elementary functions on the IBM RISC
+// System/6000 processor", 1990, Thm 4.? / Cornea-Harrison-Tang: q = RN(a*y), r = a-b*q exactly, q' = RN(q+r*y) == RN(a/b) when y
+// is the correctly rounded reciprocal, b's significand is not all ones, and nothing over/underflows). divSafe() is evaluated per
+// divisor at digestion time; edges with an unsafe divisor keep the IEEE division. ~3 instructions instead of ~28 on gfx950.
+// tests/test_device_logic_host.py fuzzes the identity against true division.
+MSDF_HD double divExact(double a, double b, double y) {
+    const double q = a*y;
+    const double r = fma(-b, q, a);
+    return fma(r, y, q);
+}
+
+MSDF_HD bool divSafe(double b) {
+    const double m = fabs(b);
+    if (!(m > 1e-100 && m < 1e100))                  // also rejects 0, inf, nan
+        return false;
+    int e;
+    const double f = frexp(m, &e);                   // f in [0.5, 1)
+    return f != 1-0x1p-53;                           // significand all ones: RN(1/b) is not close enough
+}
+
 // ------------------------------------------------------------------------------------------------- equation solver
 
 MSDF_HD int solveQuadratic(double x[2], double a, double b, double c) {      // equation-solver.cpp:9-32
@@ -129,6 +151,113 @@ MSDF_HD int solveQuadratic(double x[2], double a, double b, double c) {      // 
         return 0;
 }
 
+// ---- lean transcendentals for solveCubicNormed ------------------------------------------------------------------------------
+// The reference calls glibc's acos / cos / pow there (equation-solver.cpp:41-60); neither glibc nor OCML is correctly rounded, so
+// the contract is "< 1 ulp", not bit equality. OCML's generic cos (full range reduction) and pow (log + exp in extended precision)
+// cost ~100 and ~250 instructions and many VGPRs each; the arguments here live in tiny, known ranges, which allows equally
+// accurate (< 1 ulp, checked in tests/test_device_logic_host.py against 80-bit references) but far cheaper evaluations:
+//   cos(1/3.*t), cos(1/3.*(t+2pi)), cos(1/3.*(t-2pi)) with t = acos(.) in [0, pi]  -> arguments in [0, pi/3], [2pi/3, pi],
+//   [-2pi/3, -pi/3]: exact reductions pi-x and pi/2-|x| (Sterbenz, with a tail) onto [-pi/4, pi/4], then fdlibm's kernels.
+//   pow(x, 1/3.) with x >= 0 -> a division-free cbrt with an exactly evaluated residual, times x^((1/3.)-1/3) = 1-1.85e-17*ln x.
+// The host walk of tests/hostemu keeps libm (to stay bit-comparable with the oracle) unless MSDF_LEAN_MATH is defined.
+#if defined(__HIP_DEVICE_COMPILE__) || defined(MSDF_LEAN_MATH)
+#define MSDF_USE_LEAN_MATH 1
+#endif
+
+// fdlibm's __kernel_cos / __kernel_sin (public domain, Sun Microsystems 1993): cos / sin of x+y for |x| <= pi/4, y the tail of x;
+// error < 1 ulp. Written without FMA, exactly as designed.
+MSDF_HD double cosKernel(double x, double y) {
+    const double z = x*x;
+    const double r = z*(4.16666666666666019037e-02+z*(-1.38888888888741095749e-03+z*(2.48015872894767294178e-05+
+                     z*(-2.75573143513906633035e-07+z*(2.08757232129817482790e-09+z*-1.13596475577881948265e-11)))));
+    if (fabs(x) < .3)
+        return 1-(.5*z-(z*r-x*y));
+    const double qx = fabs(x) > .78125 ? .28125 : (double) (float) (.25*fabs(x));
+    const double hz = .5*z-qx, a = 1-qx;
+    return a-(hz-(z*r-x*y));
+}
+
+MSDF_HD double sinKernel(double x, double y) {
+    const double z = x*x, v = z*x;
+    const double r = 8.33333333332248946124e-03+z*(-1.98412698298579493134e-04+z*(2.75573137070700676789e-06+
+                     z*(-2.50507602534068634195e-08+z*1.58969099521155010221e-10)));
+    return x-((z*(.5*y-v*r)-y)-v*-1.66666666666666324348e-01);
+}
+
+// hi+lo = (c_hi-x)+c_lo where c_hi-x is exact (Sterbenz: c_hi/2 <= x <= 2*c_hi) and c_hi+c_lo is pi or pi/2 to ~107 bits.
+MSDF_HD void reduceFrom(double cHi, double cLo, double x, double &hi, double &lo) {
+    const double d = cHi-x;
+    hi = d+cLo;
+    lo = (d-hi)+cLo;
+    if (fabs(d) < fabs(cLo)) {                       // (never for the ranges used unless d == 0) keep the two-sum exact
+        hi = cLo+d;
+        lo = (cLo-hi)+d;
+    }
+}
+
+#define MSDF_PI_HI 3.141592653589793116
+#define MSDF_PI_LO 1.2246467991473532e-16
+#define MSDF_PIO2_HI 1.5707963267948965580
+#define MSDF_PIO2_LO 6.123233995736766e-17
+
+// cos(x) for x in [0, pi], < 1 ulp: every case reduces exactly onto [-pi/4, pi/4].
+MSDF_HD double cosZeroToPi(double x) {
+    double hi, lo;
+    if (x <= .78539816339744830962)
+        return cosKernel(x, 0);
+    if (x < 2.35619449019234492885) {                // (pi/4, 3pi/4): cos x = sin(pi/2-x)
+        reduceFrom(MSDF_PIO2_HI, MSDF_PIO2_LO, x, hi, lo);
+        return sinKernel(hi, lo);
+    }
+    reduceFrom(MSDF_PI_HI, MSDF_PI_LO, x, hi, lo);   // [3pi/4, pi]: cos x = -cos(pi-x)
+    return -cosKernel(hi, lo);
+}
+
+// cos of the three arguments of equation-solver.cpp:50-52, given t in [0, pi].
+MSDF_HD void cosThirds(double t, double &c0, double &c1, double &c2) {
+    const double a0 = 1/3.*t, a1 = 1/3.*(t+2*M_PI), a2 = 1/3.*(t-2*M_PI);     // the reference's own argument arithmetic
+#if defined(MSDF_USE_LEAN_MATH)
+    c0 = cosZeroToPi(a0);                            // a0 in [0, pi/3]
+    c1 = cosZeroToPi(a1);                            // a1 in [2pi/3, pi]
+    c2 = cosZeroToPi(fabs(a2));                      // a2 in [-2pi/3, -pi/3], cos is even
+#else
+    c0 = cos(a0), c1 = cos(a1), c2 = cos(a2);
+#endif
+}
+
+// pow(x, 1/3.) for x >= 0, error < 1 ulp. x = a*2^(3k), a in [0.5, 4): r ~ a^(-1/3) from an fp32 exp2/log2 seed refined by two
+// division-free Newton steps; y = a*r^2 ~ cbrt(a); one correction with the residual a-y^3 evaluated exactly (FMA, double-double)
+// and the factor x^((1/3.)-1/3) = 1-1.85e-17*ln x folded into the same, single final rounding.
+MSDF_HD double powThirdLean(double x) {
+    if (!(x > 0 && x < DBL_MAX))
+        return x == 0 ? 0. : pow(x, 1/3.);           // 0, inf, nan (x < 0 cannot occur: fabs(r)+sqrt(.)); denormals take the slow road too
+    int e;
+    const double m = frexp(x, &e);                   // x = m*2^e, m in [0.5, 1)
+    const int k = (e >= 0 ? e : e-2)/3, j = e-3*k;   // floor division: j in {0, 1, 2}
+    const double a = ldexp(m, j);                    // [0.5, 4)
+    double r = (double) exp2f(-.333333333f*log2f((float) a));
+    for (int it = 0; it < 2; ++it) {                 // Newton on r^-3 = a: r <- r*(4-a*r^3)/3
+        const double r3 = r*r*r;
+        r = r*fma(-a, r3, 4.)*.33333333333333333;
+    }
+    const double r2 = r*r;
+    const double y = a*r2;
+    const double t = y*y, tl = fma(y, y, -t);        // y^2 = t+tl exactly
+    const double u = t*y, ul = fma(t, y, -u)+tl*y;   // y^3 = u+ul to ~2^-104
+    const double resid = (a-u)-ul;
+    const double lnx = .6931471805599453*(e+2*(m-1));                  // ln x to within 0.06: only scales a 1.85e-17 correction
+    const double corr = fma(y, -1.850371707708594e-17*lnx, resid*(r2*.33333333333333333));
+    return ldexp(y+corr, k);
+}
+
+MSDF_HD double powThird(double x) {
+#if defined(MSDF_USE_LEAN_MATH)
+    return powThirdLean(x);
+#else
+    return pow(x, 1/3.);
+#endif
+}
+
 // solveCubicNormed (equation-solver.cpp:34-61) with the pixel-independent a, a*a and a*(1/3.) taken from the edge record.
 MSDF_HD int solveCubicNormedPre(double x[3], double a, double a2, double a3, double b, double c) {
     double q = 1/9.*(a2-3*b);
@@ -141,12 +270,14 @@ MSDF_HD int solveCubicNormedPre(double x[3], double a, double a2, double a3, dou
         if (t > 1) t = 1;
         t = acos(t);
         q = -2*sqrt(q);
-        x[0] = q*cos(1/3.*t)-a3;
-        x[1] = q*cos(1/3.*(t+2*M_PI))-a3;
-        x[2] = q*cos(1/3.*(t-2*M_PI))-a3;
+        double c0, c1, c2;
+        cosThirds(t, c0, c1, c2);
+        x[0] = q*c0-a3;
+        x[1] = q*c1-a3;
+        x[2] = q*c2-a3;
         return 3;
     } else {
-        double u = (r < 0 ? 1. : -1.)*pow(fabs(r)+sqrt(r2-q3), 1/3.);
+        double u = (r < 0 ? 1. : -1.)*powThird(fabs(r)+sqrt(r2-q3));
         double v = u == 0 ? 0 : q/u;
         x[0] = (u+v)-a3;
         if (u == v || fabs(u-v) < 1e-12*fabs(u+v)) {
@@ -171,7 +302,7 @@ MSDF_HD V2 dirN1(const EdgeRec &e) { return (e.flags&REC_B_ZERO) ? mk(0, 1) : ld
 MSDF_HD SD sdLinear(const EdgeRec &e, V2 o, double &param) {                 // edge-segments.cpp:173-185
     V2 p0 = ld(e.p), p1 = ld(e.p+2), ab = ld(e.ab);
     V2 aq = o-p0;
-    param = dot(aq, ab)/e.k[0];
+    param = (e.flags&REC_FASTDIV) ? divExact(dot(aq, ab), e.k[0], e.rcp[0]) : dot(aq, ab)/e.k[0];
     V2 eq = (param > .5 ? p1 : p0)-o;
     double endpointDistance = vlen(eq);
     if (param > 0 && param < 1) {
@@ -192,21 +323,24 @@ MSDF_HD SD sdQuadratic(const EdgeRec &e, V2 o, double &param) {              // 
     double d = dot(qa, ab);
     double t[3] = { 0, 0, 0 };
     int solutions;
-    if (e.flags&REC_NORMED)                                                   // solveCubic, equation-solver.cpp:63-70
-        solutions = solveCubicNormedPre(t, e.k[3], e.k[4], e.k[5], c/e.k[0], d/e.k[0]);
-    else
+    const bool fast = (e.flags&REC_FASTDIV) != 0;
+    if (e.flags&REC_NORMED) {                                                 // solveCubic, equation-solver.cpp:63-70
+        const double cn = fast ? divExact(c, e.k[0], e.rcp[0]) : c/e.k[0];
+        const double dn = fast ? divExact(d, e.k[0], e.rcp[0]) : d/e.k[0];
+        solutions = solveCubicNormedPre(t, e.k[3], e.k[4], e.k[5], cn, dn);
+    } else
         solutions = solveQuadratic(t, e.k[1], c, d);
 
     V2 epDir = ld(e.ep0);
     double minDistance = nonZeroSign(cross(epDir, qa))*vlen(qa);
-    param = -dot(qa, epDir)/e.e0dot;
+    param = fast ? divExact(-dot(qa, epDir), e.e0dot, e.rcp[1]) : -dot(qa, epDir)/e.e0dot;
     {
         V2 qb = p2-o;
         double distance = vlen(qb);
         if (distance < fabs(minDistance)) {
             epDir = ld(e.ep1);
             minDistance = nonZeroSign(cross(epDir, qb))*distance;
-            param = dot(o-p1, epDir)/e.e1dot;
+            param = fast ? divExact(dot(o-p1, epDir), e.e1dot, e.rcp[2]) : dot(o-p1, epDir)/e.e1dot;
         }
     }
     MSDF_UNROLL
@@ -235,16 +369,17 @@ MSDF_HD SD sdCubic(const EdgeRec &e, V2 o, double &param) {                  // 
     V2 p0 = ld(e.p), p3 = ld(e.p+6), ab = ld(e.ab), br = ld(e.br), as = ld(e.as_);
     V2 ab3 = mk(e.k[0], e.k[1]), br6 = mk(e.k[2], e.k[3]);
     V2 qa = p0-o;
+    const bool fast = (e.flags&REC_FASTDIV) != 0;
     V2 epDir = ld(e.ep0);
     double minDistance = nonZeroSign(cross(epDir, qa))*vlen(qa);
-    param = -dot(qa, epDir)/e.e0dot;
+    param = fast ? divExact(-dot(qa, epDir), e.e0dot, e.rcp[1]) : -dot(qa, epDir)/e.e0dot;
     {
         V2 qb = p3-o;
         double distance = vlen(qb);
         if (distance < fabs(minDistance)) {
             epDir = ld(e.ep1);
             minDistance = nonZeroSign(cross(epDir, qb))*distance;
-            param = dot(epDir-qb, epDir)/e.e1dot;
+            param = fast ? divExact(dot(epDir-qb, epDir), e.e1dot, e.rcp[2]) : dot(epDir-qb, epDir)/e.e1dot;
         }
     }
     for (int i = 0; i <= 4; ++i) {                                            // MSDFGEN_CUBIC_SEARCH_STARTS, edge-segments.h:11
@@ -444,6 +579,58 @@ MSDF_HD void selAddEdge(Selector<SEL> &s, const EdgeRec &e, int idx, V2 o) {
     }
 }
 
+// Per-texel relevance of an edge given the selector's CURRENT state (second-level, dynamic cull; the first level is per tile,
+// msdf_cull.hpp). Skipping the edge is exact when this returns false:
+//  * its distance to the texel is at least LB (control-box distance) > |current minimum true distance| of every channel it
+//    carries, and minima only decrease -> it can never become the nearest edge, ties included (1e-9 relative slack);
+//  * for each end, either the reference's own domain tests fail (add <= 0 or ts <= 0: same expressions as selAddEdge, so the same
+//    values) or the perpendicular distance exceeds that bound, in which case it cannot survive computeDistance()/merge() because
+//    the nearest edge's own (pseudo-)distance is smaller (see msdf_cull.hpp).
+// The kernel evaluates the edge if ANY lane of the wavefront needs it (wave-uniform control flow); evaluating more is harmless.
+template <int SEL>
+MSDF_HD bool selEdgeRelevant(const Selector<SEL> &s, const EdgeRec &e, V2 o) {
+    double bound2;                                   // squared bound, inflated
+    if (SEL == 1)
+        bound2 = s.m.d*s.m.d;
+    else {
+        const int mask = SEL == 2 ? 1 : (e.color&7);
+        if (!mask)
+            return false;
+        bound2 = 0;
+        for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
+            if (mask&(1<<i))
+                bound2 = dmax(bound2, s.c[i].td*s.c[i].td);
+    }
+    bound2 *= 1+1e-9;                                // (-DBL_MAX)^2 = inf: nothing is skipped until a channel has a candidate
+    const double dx = dmax(dmax(e.lo[0]-o.x, o.x-e.hi[0]), 0.);
+    const double dy = dmax(dmax(e.lo[1]-o.y, o.y-e.hi[1]), 0.);
+    if (!(dx*dx+dy*dy > bound2))
+        return true;
+    if (SEL >= 2) {
+        const V2 ap = o-ld(e.p), aDir = ld(e.aDirN);
+        if (dot(ap, ld(e.na)) > 0 && dot(ap, -aDir) > 0) {             // add > 0 && ts > 0 (edge-selectors.cpp:199-202, :43-44)
+            const double perp = cross(ap, aDir);
+            if (!(perp*perp > bound2))
+                return true;
+        }
+        const V2 bp = o-endPoint(e), bDir = ld(e.bDirN);
+        if (-dot(bp, ld(e.nb)) > 0 && dot(bp, bDir) > 0) {             // bdd > 0 && ts > 0 (:212-215)
+            const double perp = cross(bp, bDir);
+            if (!(perp*perp > bound2))
+                return true;
+        }
+    }
+    return false;
+}
+
+#if defined(MSDF_NO_DYNAMIC_CULL)
+#define MSDF_WAVE_ANY(pred) (true)
+#elif defined(__HIP_DEVICE_COMPILE__)
+#define MSDF_WAVE_ANY(pred) (__any((int) (pred)) != 0)
+#else
+#define MSDF_WAVE_ANY(pred) (pred)                   // host walk: one "lane" at a time, i.e. the most aggressive skipping
+#endif
+
 template <int SEL>
 MSDF_HD void selMerge(Selector<SEL> &s, const Selector<SEL> &o) {            // edge-selectors.cpp:31-34, 229-233
     if (SEL == 1) {
@@ -512,7 +699,8 @@ MSDF_HD void shapeDistanceSimple(const EdgeRec *rec, const Edges &edges, int C, 
         const int e = edges.end(c);
         for (int k = edges.begin(c); k < e; ++k) {
             const int i = edges.at(k);
-            selAddEdge(sel, rec[i], i, o);
+            if (MSDF_WAVE_ANY(selEdgeRelevant(sel, rec[i], o)))
+                selAddEdge(sel, rec[i], i, o);
         }
     }
     selDistance(sel, rec, o, out);
@@ -537,7 +725,8 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
         const int e = edges.end(c);
         for (int k = edges.begin(c); k < e; ++k) {
             const int i = edges.at(k);
-            selAddEdge(sel, rec[i], i, o);
+            if (MSDF_WAVE_ANY(selEdgeRelevant(sel, rec[i], o)))
+                selAddEdge(sel, rec[i], i, o);
         }
         double d[NCH];
         selDistance(sel, rec, o, d);

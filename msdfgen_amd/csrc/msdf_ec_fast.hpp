@@ -124,31 +124,81 @@ MSDF_HD int diagonalPairFast(const FastCtx &cx, float am, float dm, const float 
     return verdict;
 }
 
-// Fused findErrors for texel (x, ys) in shape orientation. Returns bit0: ERROR decided, bit1: some candidate needs the distance check;
-// every such candidate is reported as sink(t, dx, dy) (interpolation parameter and neighbour direction, MSDFErrorCorrection.cpp:65).
+// 3x3 neighbourhood of a texel in NATIVE row order, loaded once into registers: v[dy+1][dx+1][channel]; valid bit (dy+1)*3+(dx+1).
+struct Neighbourhood {
+    float v[3][3][3];
+    unsigned valid;
+};
+
+MSDF_HD void loadNeighbourhood(Neighbourhood &nb, const SdfView &sdf, int x, int yn) {
+    nb.valid = 0;
+    MSDF_UNROLL
+    for (int dy = -1; dy <= 1; ++dy) {
+        MSDF_UNROLL
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int nx = x+dx, ny = yn+dy;
+            const bool in = nx >= 0 && ny >= 0 && nx < sdf.w && ny < sdf.h;
+            const float *t = sdf.native(in ? nx : x, in ? ny : yn);
+            nb.v[dy+1][dx+1][0] = t[0], nb.v[dy+1][dx+1][1] = t[1], nb.v[dy+1][dx+1][2] = t[2];
+            if (in)
+                nb.valid |= 1u<<((dy+1)*3+(dx+1));
+        }
+    }
+}
+
+// protectEdges (MSDFErrorCorrection.cpp:189-250) as a gather, from the register neighbourhood; see protectedByEdges in msdf_ec.hpp.
+MSDF_HD bool protectedByEdgesNb(const Neighbourhood &nb, const EcParams &p) {
+    const float *self = nb.v[1][1];
+    const float sm = medianf(self[0], self[1], self[2]);
+    const float sdev = fabsf(sm-.5f);
+    bool prot = false;
+    MSDF_UNROLL
+    for (int dy = -1; dy <= 1; ++dy) {
+        MSDF_UNROLL
+        for (int dx = -1; dx <= 1; ++dx) {
+            if (!dx && !dy)
+                continue;
+            if (!(nb.valid&(1u<<((dy+1)*3+(dx+1)))))
+                continue;
+            const float radius = dy == 0 ? p.radiusH : dx == 0 ? p.radiusV : p.radiusD;
+            const float *other = nb.v[dy+1][dx+1];
+            const float om = medianf(other[0], other[1], other[2]);
+            const bool selfIsA = dy > 0 || (dy == 0 && dx > 0);
+            const float sum = selfIsA ? sdev+fabsf(om-.5f) : fabsf(om-.5f)+sdev;     // fabsf(am-.5f)+fabsf(bm-.5f)
+            if (!prot && sum < radius) {
+                const int mask = selfIsA ? edgeBetweenTexels(self, other) : edgeBetweenTexels(other, self);
+                prot = extremeChannelInMask(self, sm, mask);
+            }
+        }
+    }
+    return prot;
+}
+
+// Fused findErrors for the texel at the centre of `nb`, enumerated in native row order (the set of neighbour tests and their operands
+// is the same in either orientation). Returns bit0: ERROR decided, bit1: some candidate needs the distance check; every such
+// candidate is reported as sink(t, dx, dyShape) with the neighbour direction in SHAPE orientation (MSDFErrorCorrection.cpp:446-453).
 template <class Sink>
-MSDF_HD int texelFindFast(const SdfView &sdf, const EcParams &p, int x, int ys, bool p1, Sink &sink) {
+MSDF_HD int texelFindFast(const Neighbourhood &nb, const EcParams &p, bool p1, int flip, Sink &sink) {
     FastCtx cx;
     cx.basePass = ecHasBasePass(p);
     cx.shapePass = ecHasShapePass(p);
     cx.p1 = p1;
     cx.pShape = (p.distanceCheck == EC_CHECK_AT_EDGE) ? true : p1;   // protectAll() precedes the shape pass only in that mode (:38-39, :33)
-    const int w = sdf.w, h = sdf.h;
-    const float *c = sdf.shape(x, ys);
+    const float *c = nb.v[1][1];
     const float cm = medianf(c[0], c[1], c[2]);
     const float cdev = fabsf(cm-.5f);
     int verdict = 0;
-    MSDF_NOUNROLL
-    for (int k = 0; k < 4; ++k) {                        // l, b, r, t
+    MSDF_UNROLL
+    for (int k = 0; k < 4; ++k) {                        // horizontal / vertical neighbours
         const int dx = k == 0 ? -1 : k == 2 ? 1 : 0, dy = k == 1 ? -1 : k == 3 ? 1 : 0;
-        const int nx = x+dx, ny = ys+dy;
-        if (nx < 0 || ny < 0 || nx >= w || ny >= h)
+        if (!(nb.valid&(1u<<((dy+1)*3+(dx+1)))) || (verdict&1))
             continue;
-        const float *b = sdf.shape(nx, ny);
+        const float *b = nb.v[dy+1][dx+1];
         const float bm = medianf(b[0], b[1], b[2]);
         if (!(cdev >= fabsf(bm-.5f)))                    // :335
             continue;
         cx.span = dy == 0 ? p.hSpan : p.vSpan;
+        MSDF_UNROLL
         for (int j = 0; j < 3; ++j) {                    // channel pairs (1,0), (2,1), (0,2)
             const int i0 = j, i1 = j == 2 ? 0 : j+1;
             const float dA = c[i1]-c[i0], dB = b[i1]-b[i0];
@@ -159,25 +209,22 @@ MSDF_HD int texelFindFast(const SdfView &sdf, const EcParams &p, int x, int ys, 
                 const float xm = interpolatedMedianLin(c, b, t);
                 const int v = judge(rangeTest2(cx, 0, 1, t, cm, bm, xm));
                 if (v&2)
-                    sink(t, dx, dy);
+                    sink(t, dx, flip ? -dy : dy);
                 verdict |= v;
-                if (verdict&1)
-                    return verdict;
             }
         }
     }
     cx.span = p.dSpan;
-    MSDF_NOUNROLL
-    for (int k = 0; k < 4; ++k) {                        // (l,b) (r,b) (l,t) (r,t)
+    MSDF_UNROLL
+    for (int k = 0; k < 4; ++k) {                        // diagonal neighbours
         const int dx = (k&1) ? 1 : -1, dy = (k&2) ? 1 : -1;
-        const int nx = x+dx, ny = ys+dy;
-        if (nx < 0 || ny < 0 || nx >= w || ny >= h)
+        if (!(nb.valid&(1u<<((dy+1)*3+(dx+1)))) || (verdict&1))
             continue;
-        const float *d = sdf.shape(nx, ny);
+        const float *d = nb.v[dy+1][dx+1];
         const float dm = medianf(d[0], d[1], d[2]);
         if (!(cdev >= fabsf(dm-.5f)))                    // :349
             continue;
-        const float *a = c, *b = sdf.shape(nx, ys), *cc = sdf.shape(x, ny);
+        const float *a = c, *b = nb.v[1][dx+1], *cc = nb.v[dy+1][1];   // (texel, horizontal, vertical, diagonal neighbour), :404-407
         const float abc[3] = { a[0]-b[0]-cc[0], a[1]-b[1]-cc[1], a[2]-b[2]-cc[2] };
         const float l[3] = { -a[0]-abc[0], -a[1]-abc[1], -a[2]-abc[2] };
         const float q[3] = { d[0]+abc[0], d[1]+abc[1], d[2]+abc[2] };
@@ -185,12 +232,15 @@ MSDF_HD int texelFindFast(const SdfView &sdf, const EcParams &p, int x, int ys, 
             Sink &sink;
             int dx, dy;
             MSDF_HD void operator()(double t) { sink(t, dx, dy); }
-        } dirSink = { sink, dx, dy };
+        } dirSink = { sink, dx, flip ? -dy : dy };
+        MSDF_UNROLL
         for (int j = 0; j < 3; ++j) {
             const int i0 = j, i1 = j == 2 ? 0 : j+1;
-            verdict |= diagonalPairFast(cx, cm, dm, a, l, q, a[i1]-a[i0], b[i1]-b[i0]+cc[i1]-cc[i0], d[i1]-d[i0], i0, i1, dirSink);
-            if (verdict&1)
-                return verdict;
+            const float dA = a[i1]-a[i0], dBC = b[i1]-b[i0]+cc[i1]-cc[i0], dD = d[i1]-d[i0];
+            if (dA == 0 && dBC == 0 && dD == 0)
+                continue;                                // 0 == 0: solveQuadratic reports no usable root (equation-solver.cpp:13-17)
+            if (!(verdict&1))
+                verdict |= diagonalPairFast(cx, cm, dm, a, l, q, dA, dBC, dD, i0, i1, dirSink);
         }
     }
     return verdict;
@@ -202,6 +252,8 @@ MSDF_HD int texelFindFast(const SdfView &sdf, const EcParams &p, int x, int ys, 
 template <class Sink>
 MSDF_HD int ecTexelFast(const SdfView &sdf, const EcParams &p, const int *corners, int nCorners, int x, int yn, Sink &sink) {
     const int ys = sdf.flip ? sdf.h-1-yn : yn;
+    Neighbourhood nb;
+    loadNeighbourhood(nb, sdf, x, yn);
     int st = 0;
     if (p.mode == EC_MODE_EDGE_PRIORITY) {
         for (int i = 0; i < nCorners; ++i) {
@@ -211,11 +263,11 @@ MSDF_HD int ecTexelFast(const SdfView &sdf, const EcParams &p, const int *corner
                 break;
             }
         }
-        if (!(st&EC_PROTECTED) && protectedByEdges(sdf, p, x, yn))
+        if (!(st&EC_PROTECTED) && protectedByEdgesNb(nb, p))
             st |= EC_PROTECTED;
     } else if (p.mode == EC_MODE_EDGE_ONLY)
         st |= EC_PROTECTED;
-    const int verdict = texelFindFast(sdf, p, x, ys, (st&EC_PROTECTED) != 0, sink);
+    const int verdict = texelFindFast(nb, p, (st&EC_PROTECTED) != 0, sdf.flip, sink);
     if (ecHasBasePass(p) && p.distanceCheck == EC_CHECK_AT_EDGE)
         st |= EC_PROTECTED;                              // protectAll (:38-39)
     if (verdict&1)

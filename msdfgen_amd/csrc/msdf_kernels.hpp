@@ -26,7 +26,8 @@
 namespace msdfhip {
 
 #ifndef MSDF_DISTANCE_WAVES_PER_SIMD
-#define MSDF_DISTANCE_WAVES_PER_SIMD 2   // caps k_distance at 256 VGPRs so that two wavefronts share a SIMD and hide fp64 latency
+#define MSDF_DISTANCE_WAVES_PER_SIMD 3   // caps k_distance at 168 VGPRs: three wavefronts per SIMD hide the fp64 / scalar-load latency
+                                         // (measured on MI355X, ms per 8192 glyphs: 1 wave 8.7, 2 waves 4.4, 3 waves 3.7, 4 waves 3.9)
 #endif
 constexpr int TILE = 8;          // 8x8 texels per wavefront
 constexpr int WAVE = 64;
@@ -100,6 +101,14 @@ __device__ inline void stageRecords(double *dst, const EdgeRec *src, int n) {
 
 // ----------------------------------------------------------------------------------------------------- distance field
 
+// LDS hand-off between lanes of ONE wavefront: a wavefront's LDS operations complete in issue order, so only the compiler has to be
+// kept from reordering them across this point; no workgroup barrier is involved (the wavefronts of a workgroup are independent).
+__device__ inline void waveSync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Wave-wide minimum of non-negative floats via DPP row shifts / broadcasts (VALU speed; a shuffle-based reduction costs an LDS
 // round trip per step). Non-negative IEEE floats order like their bit patterns, so the reduction runs on ints.
 // All 64 lanes must be active. Result is broadcast to every lane.
@@ -156,8 +165,10 @@ k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, i
     const int tx = wk.tile%tilesX, ty = wk.tile/tilesX;
 
     // ---- phase 1: cull + compact (lanes = edges)
-    const V2 tc = unproject(t, mk(tx*TILE+.5*TILE, ty*TILE+.5*TILE));
-    const double hx = (.5*TILE-.5)/fabs(t.sx), hy = (.5*TILE-.5)/fabs(t.sy);
+    const double rsx = 1/t.sx, rsy = 1/t.sy;                        // two divisions per wavefront; texel positions below use divExact
+    const bool fastXf = divSafe(t.sx) && divSafe(t.sy);
+    const V2 tc = mk((tx*TILE+.5*TILE)*rsx-t.tx, (ty*TILE+.5*TILE)*rsy-t.ty);   // tile centre: only has to be accurate to within the cull slack
+    const double hx = (.5*TILE-.5)*fabs(rsx), hy = (.5*TILE-.5)*fabs(rsy);
     const double tr = sqrt(hx*hx+hy*hy);
     int nSurv = 0;
     // The bounds U[ch] are per contour for the overlapping combiner (one selector per contour, every contour's own distance is
@@ -194,7 +205,11 @@ k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, i
                         for (int ch = 0; ch < (SEL <= 2 ? 1 : 3); ++ch)
                             if ((mask>>ch)&1)
                                 umax = dmax(umax, U[ch]);
+#if defined(MSDF_NO_TILE_CULL)
+                        keep = true;
+#else
                         keep = cullEdgeSurvives<(SEL >= 2)>(recGlobal[i], tc, tr, umax);
+#endif
                     }
                 }
                 const unsigned long long ballot = __ballot(keep);
@@ -206,7 +221,7 @@ k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, i
     }
     if (lane == 0)
         cstart[C] = nSurv;
-    __syncthreads();
+    waveSync();
     const EdgeRec *rec = recGlobal;
     if (LDSREC) {                                                   // stage the surviving records, in list order
         for (int k = 0; k < nSurv; ++k) {
@@ -215,14 +230,15 @@ k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, i
                 recLds[(size_t) k*REC_DOUBLES+lane] = src[lane];
         }
         rec = reinterpret_cast<const EdgeRec *>(__builtin_assume_aligned(recLds, 16));
-        __syncthreads();
+        waveSync();
     }
 
     // ---- phase 2: per-texel selection over the survivors (lanes = texels)
     const int x = tx*TILE+(lane&(TILE-1)), y = ty*TILE+(lane>>3);
     if (x >= width || y >= height)
         return;
-    const V2 p = unproject(t, mk(x+.5, y+.5));                      // msdfgen.cpp:68
+    const V2 p = fastXf ? mk(divExact(x+.5, t.sx, rsx)-t.tx, divExact(y+.5, t.sy, rsy)-t.ty)
+                        : unproject(t, mk(x+.5, y+.5));             // msdfgen.cpp:68 (coord/scale-translate, correctly rounded either way)
     EdgesCulled edges;
     edges.cstart = cstart;
     edges.list = LDSREC ? (const int *) 0 : list;
@@ -281,6 +297,30 @@ struct CandidateSink {
     }
 };
 
+// Per-glyph constants of the error-correction pass (protectEdges radii, findErrors spans, texel size: MSDFErrorCorrection.cpp:90,
+// 194-226, 387-389): 3 sqrt + 8 divisions that every texel of a glyph shares, computed once per glyph instead of once per wavefront.
+struct EcGlyphParams {
+    double hSpan, vSpan, dSpan, texelX, texelY;
+    float radiusH, radiusV, radiusD;
+    int pad;
+};
+static_assert(sizeof(EcGlyphParams) == 56, "EcGlyphParams layout");
+
+__global__ void k_ec_params(EcGlyphParams *out, const MsdfHipGlyph *glyphs, int nGlyphs, MsdfHipConfig cfg) {
+    const int g = blockIdx.x*blockDim.x+threadIdx.x;
+    if (g >= nGlyphs)
+        return;
+    EcParams p;
+    p.t = loadXform(glyphs[g]);
+    p.minDeviationRatio = cfg.min_deviation_ratio;
+    p.minImproveRatio = cfg.min_improve_ratio;
+    ecDerive(p);
+    EcGlyphParams o;
+    o.hSpan = p.hSpan, o.vSpan = p.vSpan, o.dSpan = p.dSpan, o.texelX = p.texelX, o.texelY = p.texelY;
+    o.radiusH = p.radiusH, o.radiusV = p.radiusV, o.radiusD = p.radiusD, o.pad = 0;
+    out[g] = o;
+}
+
 // Error correction, fast sweep over ALL texels (msdf_ec_fast.hpp). src: pre-correction field, packed [g][h][w][N] in native row order.
 // Writes corrected texels to the caller's bitmap (msdfErrorCorrectionInner, core/msdf-error-correction.cpp:12-48) and, if stencilOut,
 // the stencil byte [g][h][w] (native rows). Candidates whose verdict needs an exact shape-distance query are appended to `cands`
@@ -288,7 +328,7 @@ struct CandidateSink {
 template <int N>
 __global__ void __launch_bounds__(WAVE)
 k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph,
-          const float *src, float *out, uint8_t *stencilOut, MsdfHipConfig cfg, EcCandidate *cands, unsigned capacity) {
+          const float *src, float *out, uint8_t *stencilOut, MsdfHipConfig cfg, const EcGlyphParams *glyphParams, EcCandidate *cands, unsigned capacity) {
     extern __shared__ int smemCorners[];                            // (l, b) per colour-change corner of the glyph
     const GlyphWork wk = decodeBlock(batch.nGlyphs, tilesPerGlyph);
     if (!wk.valid)
@@ -303,7 +343,9 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
     p.minDeviationRatio = cfg.min_deviation_ratio;
     p.minImproveRatio = cfg.min_improve_ratio;
     p.mode = cfg.ec_mode, p.distanceCheck = cfg.ec_distance_check, p.overlap = cfg.overlap_support, p.stageLimit = 0;
-    ecDerive(p);
+    const EcGlyphParams gp = glyphParams[wk.g];
+    p.hSpan = gp.hSpan, p.vSpan = gp.vSpan, p.dSpan = gp.dSpan, p.texelX = gp.texelX, p.texelY = gp.texelY;
+    p.radiusH = gp.radiusH, p.radiusV = gp.radiusV, p.radiusD = gp.radiusD;
 
     int nCorners = 0;
     if (p.mode == EC_MODE_EDGE_PRIORITY) {                          // protectCorners (MSDFErrorCorrection.cpp:121-151): lanes = edges, ordered compaction

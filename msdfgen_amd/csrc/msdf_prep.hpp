@@ -116,6 +116,20 @@ MSDF_HD void buildRecord(EdgeRec &r, const RawEdge &prev, const RawEdge &cur, co
     st(r.lo, lo);
     st(r.hi, hi);
     st(r.mid, rawPoint(cur, .5));
+    for (int i = 0; i < 4; ++i)                                              // reciprocals of the pixel-independent divisors (divExact)
+        r.rcp[i] = 0;
+    bool fast;
+    if (cur.type == 1) {
+        fast = divSafe(r.k[0]);
+        r.rcp[0] = 1/r.k[0];
+    } else {
+        fast = divSafe(r.e0dot) && divSafe(r.e1dot) && (cur.type == 3 || !(flags&REC_NORMED) || divSafe(r.k[0]));
+        r.rcp[0] = cur.type == 2 ? 1/r.k[0] : 0;
+        r.rcp[1] = 1/r.e0dot;
+        r.rcp[2] = 1/r.e1dot;
+    }
+    if (fast)
+        flags |= REC_FASTDIV;
     const int common = prev.color&cur.color;                                  // MSDFErrorCorrection.cpp:127-129
     if (!(common&(common-1)))
         flags |= REC_CORNER;

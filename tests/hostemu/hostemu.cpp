@@ -157,6 +157,36 @@ struct HostQuery {
 extern "C" {
 
 long emu_last_deferred() { return g_lastDeferred; }
+
+// The lean transcendentals of the device build (cosKernel/sinKernel based cosThirds, cbrt based powThird), exported for accuracy tests.
+void emu_lean_cos_thirds(const double *t, long n, double *out) {
+    for (long i = 0; i < n; ++i) {
+        const double a0 = 1/3.*t[i], a1 = 1/3.*(t[i]+2*M_PI), a2 = 1/3.*(t[i]-2*M_PI);
+        out[3*i] = cosZeroToPi(a0);
+        out[3*i+1] = cosZeroToPi(a1);
+        out[3*i+2] = cosZeroToPi(fabs(a2));
+    }
+}
+void emu_lean_pow_third(const double *x, long n, double *out) {
+    for (long i = 0; i < n; ++i)
+        out[i] = powThirdLean(x[i]);
+}
+
+// divExact (reciprocal + 2 FMA) against IEEE division: returns the number of (a, b) pairs with divSafe(b) whose quotients differ.
+long emu_div_exact_violations(const double *a, const double *b, long n, long *safeCount) {
+    long bad = 0, safe = 0;
+    for (long i = 0; i < n; ++i)
+        if (divSafe(b[i])) {
+            ++safe;
+            const double y = 1/b[i];
+            const double q1 = divExact(a[i], b[i], y), q2 = a[i]/b[i];
+            if (memcmp(&q1, &q2, sizeof(double)) && !(q1 != q1 && q2 != q2))
+                ++bad;
+        }
+    if (safeCount)
+        *safeCount = safe;
+    return bad;
+}
 void emu_cull_stats(long *kept, long *total, int reset) { *kept = g_cullKept, *total = g_cullTotal; if (reset) g_cullKept = g_cullTotal = 0; }
 
 // Fuzz of the exact-skip prefilter of the diagonal test: returns the number of coefficient triples for which

@@ -157,3 +157,48 @@ def test_fuzz_tile_culling_is_exact(emu, oracle, seed):
             assert_bit_equal(b, a, "seed %d mode %d overlap %d" % (seed, mode, ov))
     emu.lib.emu_cull_stats(C.byref(kept), C.byref(total), 1)
     assert 0 < kept.value <= total.value
+
+
+def test_reciprocal_fma_division_is_correctly_rounded(emu):
+    """divExact (msdf_device.hpp) must equal IEEE division for every divisor that divSafe() admits."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    n = 3_000_000
+    a = rng.standard_normal(n)*np.exp(rng.uniform(-30, 30, n))
+    b = rng.standard_normal(n)*np.exp(rng.uniform(-30, 30, n))
+    a[:1000] = 0
+    a[1000:2000] = b[1000:2000]*rng.integers(1, 9, 1000)                 # exact quotients
+    b[2000:3000] = np.ldexp(2-2.0**-52, rng.integers(-20, 20, 1000))     # all-ones significands must be rejected by divSafe
+    a[3000:4000] = np.nextafter(b[3000:4000]*3, np.inf)                  # quotients next to ties
+    emu.lib.emu_div_exact_violations.restype = C.c_long
+    safe = C.c_long()
+    bad = emu.lib.emu_div_exact_violations(a.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)), C.c_long(n), C.byref(safe))
+    assert bad == 0
+    assert n-1500 < safe.value < n
+
+
+def test_lean_transcendentals_are_within_one_ulp(emu):
+    """The device build replaces OCML's generic cos/pow inside solveCubicNormed by range-specific kernels (msdf_device.hpp).
+    Check them against 80-bit long double evaluations of exactly the reference's expressions: < 1 ulp, like glibc/OCML."""
+    import ctypes as C
+    rng = np.random.default_rng(17)
+    n = 400_000
+    t = np.concatenate([rng.uniform(0, np.pi, n-4), [0., np.pi, np.pi/2, 1e-9]])
+    out = np.zeros((len(t), 3))
+    emu.lib.emu_lean_cos_thirds(t.ctypes.data_as(C.POINTER(C.c_double)), C.c_long(len(t)), out.ctypes.data_as(C.POINTER(C.c_double)))
+    third = np.float64(1)/np.float64(3)
+    twopi = np.float64(2)*np.float64(np.pi)
+    args = np.stack([third*t, third*(t+twopi), third*(t-twopi)], 1)            # the reference's fp64 argument arithmetic
+    ref = np.cos(args.astype(np.longdouble))
+    ulp = np.spacing(np.abs(ref.astype(np.float64)))
+    err = np.abs(out.astype(np.longdouble)-ref)/ulp
+    assert err.max() < 1.0, err.max(axis=0)
+    glibc = np.abs(np.cos(args).astype(np.longdouble)-ref)/ulp
+    print("cos thirds max ulp error: lean %.3f, libm %.3f" % (err.max(), glibc.max()))
+    x = np.exp(rng.uniform(-40, 40, n))
+    outp = np.zeros(n)
+    emu.lib.emu_lean_pow_third(x.ctypes.data_as(C.POINTER(C.c_double)), C.c_long(n), outp.ctypes.data_as(C.POINTER(C.c_double)))
+    refp = np.power(x.astype(np.longdouble), np.longdouble(third))              # x^(1/3.) with the fp64-rounded exponent
+    errp = np.abs(outp.astype(np.longdouble)-refp)/np.spacing(refp.astype(np.float64))
+    assert errp.max() < 1.0, errp.max()
+    print("pow third max ulp error: lean %.3f" % errp.max())
