@@ -63,14 +63,30 @@ def cpu_baseline(batch, xfs, w, h, budget_s=15.):
         impl = Ref() if Ref.available() else Oracle()
     except Exception:  # noqa: BLE001
         impl = Oracle()
-    shapes = batch.shapes()
-    probe = min(len(shapes), 94)
+    shapes = batch.shapes()[:94*8]                   # the batch is the 94 Basic-Latin shapes tiled: cycle through a slice of it
+    probe = min(len(shapes), 4*cores)
     _, secs = impl.generate_batch_timed(shapes[:probe], 3, w, h, xfs[:probe], threads=cores)
     rate = probe/max(secs, 1e-9)
-    n = int(max(probe, min(len(shapes), rate*budget_s)))
-    _, secs = impl.generate_batch_timed(shapes[:n], 3, w, h, xfs[:n], threads=cores)
+    n = int(min(max(probe, rate*budget_s), 200000))
+    idx = [i % len(shapes) for i in range(n)]
+    _, secs = impl.generate_batch_timed([shapes[i] for i in idx], 3, w, h, xfs[idx], threads=cores)
     return {"value": n/secs, "unit": "glyphs/s", "cores": cores, "kind": impl.kind,
-            "sample": "%d glyphs of the same batch (msdf 64x64, default error correction), glyph-parallel on %d threads, %.1f s" % (n, cores, secs)}
+            "sample": "%d glyphs of the same workload (Basic-Latin shapes cycled, msdf %dx%d, default error correction) through %s, "
+                      "glyph-parallel thread pool on %d threads, %.1f s" % (n, w, h, "the compiled reference (oracle/_ref)" if impl.kind == "reference" else "the plain-C oracle", cores, secs)}
+
+
+def pmc_traffic(args, w, h):
+    """HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
+    command (tools/pmc_traffic.py writes profiles/pmc_traffic.json; counters cannot be collected from inside the timed process).
+    None when no profile of this exact workload is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        t = json.load(open(path))
+        if t.get("glyphs_per_gpu") == args.glyphs and t.get("tile") == [w, h]:
+            return t["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def main():
@@ -161,8 +177,8 @@ def main():
                                    "overlapSupport=true, error correction EDGE_PRIORITY+CHECK_DISTANCE_AT_EDGE (library defaults); "
                                    "step = digest + distance field + error correction, inputs/outputs resident in HBM" % (w, h, args.glyphs),
                        "glyphs_per_gpu": args.glyphs, "tile": [w, h], "mode": "msdf", "parallelism": "glyph-sharded x%d, no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_distance<3,overlap>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved/HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_distance<3,true,false> (msdf, overlapping combiner)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved/HBM_PEAK_GBS, "traffic": pmc_traffic(args, w, h),
                          "algorithmic_bytes_per_launch": ab, "avg_launch_ms": dist_ms, "launches_timed": kn.value,
                          "note": "arithmetic intensity ~400 fp64 flop/B: the kernel is fp64-VALU bound, not HBM bound (SURVEY.md 8d); "
                                  "the HBM fraction is reported as the contract asks, the binding resource is in `valu_fp64`"},

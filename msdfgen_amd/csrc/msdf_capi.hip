@@ -516,6 +516,49 @@ int msdfhip_batch_generate_host(const MsdfHipBatch *b, int mode, int w, int h, c
 
 // ------------------------------------------------------------------------------------------- single-shape host calls
 
+// Per-thread resources of the single-shape host-pointer calls: one stream, one device arena, one pinned staging buffer. They grow
+// on demand and are reused, so a steady stream of generate*() calls from a host thread (the way msdf-atlas-gen's workers call the
+// reference) performs no allocation: stage -> async H2D -> kernels -> async D2H -> one stream sync. Never freed (thread exit /
+// process teardown order makes that unsafe); bounded by the largest call the thread ever made.
+struct ThreadArena {
+    int device;
+    hipStream_t stream;
+    char *dev, *pinned;
+    size_t devCap, pinnedCap;
+};
+static thread_local ThreadArena tlsArena = { -1, NULL, NULL, NULL, 0, 0 };
+
+static int arenaReserve(ThreadArena &a, size_t devBytes, size_t pinnedBytes) {
+    const int device = gDevice.load();
+    if (a.device != device) {                                    // first use on this thread, or the process switched device
+        a.device = device, a.stream = NULL, a.dev = a.pinned = NULL, a.devCap = a.pinnedCap = 0;
+        HIPCHK(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
+    }
+    if (a.devCap < devBytes) {
+        if (a.dev)
+            HIPCHK(hipFree(a.dev));
+        a.dev = NULL, a.devCap = 0;
+        const size_t cap = devBytes+devBytes/2+4096;
+        HIPCHK(hipMalloc((void **) &a.dev, cap));
+        a.devCap = cap;
+    }
+    if (a.pinnedCap < pinnedBytes) {
+        if (a.pinned)
+            HIPCHK(hipHostFree(a.pinned));
+        a.pinned = NULL, a.pinnedCap = 0;
+        const size_t cap = pinnedBytes+pinnedBytes/2+4096;
+        HIPCHK(hipHostMalloc((void **) &a.pinned, cap, hipHostMallocDefault));
+        a.pinnedCap = cap;
+    }
+    return MSDFHIP_OK;
+}
+
+struct Carver {                                                  // 256-byte aligned sub-allocation inside an arena
+    size_t off;
+    Carver() : off(0) { }
+    size_t take(size_t bytes) { const size_t at = off; off += (bytes+255)/256*256; return at; }
+};
+
 static int singleShape(int mode, int channels, bool correctionOnly, float *pixels, int w, int h, int rowStride, int flip,
                        const int32_t *co, int nC, const double *points, const uint8_t *types, const uint8_t *colors,
                        const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil) {
@@ -528,51 +571,95 @@ static int singleShape(int mode, int channels, bool correctionOnly, float *pixel
         return MSDFHIP_OK;
     if (correctionOnly && cfg->ec_mode == MSDFHIP_EC_DISABLED)
         return MSDFHIP_OK;
-    const int32_t gco[2] = { 0, nC };
-    MsdfHipBatch *b = NULL;
-    rc = msdfhip_batch_create(&b, 1, gco, co, points, types, colors);
+    rc = ensureDevice();
     if (rc != MSDFHIP_OK)
         return rc;
-    MsdfHipGlyph gd;
-    memcpy(gd.xf, xf, sizeof(gd.xf));
-    gd.out_offset = 0;
-    gd.row_stride = w*channels;                                  // device tile is tightly packed in memory-row order
-    gd.flip = flip ? 1 : 0;
-    const size_t n = (size_t) w*h*channels;
-    std::vector<float> tile(n);
-    std::vector<uint8_t> st(stencil ? (size_t) w*h : 0);
-    if (correctionOnly) {
+    if (co[0] != 0)
+        return fail(MSDFHIP_ERR_INVALID, "contour_offsets must start at 0");
+    for (int c = 0; c < nC; ++c)
+        if (co[c+1] < co[c])
+            return fail(MSDFHIP_ERR_INVALID, "contour_offsets not monotonic at %d", c);
+    const int nE = co[nC];
+    for (int e = 0; e < nE; ++e)
+        if (types[e] < 1 || types[e] > 3)
+            return fail(MSDFHIP_ERR_INVALID, "edge %d has type %d (must be 1, 2 or 3)", e, (int) types[e]);
+    const bool correct = channels >= 3 && cfg->ec_mode != MSDFHIP_EC_DISABLED;
+    const size_t texels = (size_t) w*h, tileBytes = texels*channels*sizeof(float);
+    const size_t eAlloc = nE > 0 ? nE : 1, cAlloc = nC > 0 ? nC : 1;
+    const size_t candCap = texels/16 > 4096 ? texels/16 : 4096;
+
+    // host staging layout (inputs first: one H2D copy; then the results: one D2H copy)
+    Carver hc;
+    const size_t hGco = hc.take(2*sizeof(int32_t)), hCo = hc.take((nC+1)*sizeof(int32_t)), hPts = hc.take(eAlloc*8*sizeof(double));
+    const size_t hTypes = hc.take(eAlloc), hColors = hc.take(eAlloc), hGlyph = hc.take(sizeof(MsdfHipGlyph));
+    const size_t hSrc = correctionOnly ? hc.take(tileBytes) : hc.off;
+    const size_t inputBytes = hc.off;
+    const size_t hOut = hc.take(tileBytes), hStencil = hc.take(texels);
+    const size_t resultBytes = hc.off-hOut;
+    // device layout: mirror of the staging area, then device-only work buffers
+    Carver dc;
+    dc.off = hc.off;
+    const size_t dRecs = dc.take(eAlloc*sizeof(EdgeRec)), dWind = dc.take(cAlloc), dScratch = dc.take(correct && !correctionOnly ? tileBytes : 0);
+    const size_t dCands = dc.take(correct ? (candCap+1)*sizeof(EcCandidate) : 0), dParams = dc.take(sizeof(EcGlyphParams));
+    ThreadArena &a = tlsArena;
+    rc = arenaReserve(a, dc.off, hc.off);
+    if (rc != MSDFHIP_OK)
+        return rc;
+
+    int32_t *gco = reinterpret_cast<int32_t *>(a.pinned+hGco);
+    gco[0] = 0, gco[1] = nC;
+    memcpy(a.pinned+hCo, co, (nC+1)*sizeof(int32_t));
+    if (nE) {
+        memcpy(a.pinned+hPts, points, (size_t) nE*8*sizeof(double));
+        memcpy(a.pinned+hTypes, types, nE);
+        memcpy(a.pinned+hColors, colors, nE);
+    }
+    MsdfHipGlyph *gd = reinterpret_cast<MsdfHipGlyph *>(a.pinned+hGlyph);
+    memcpy(gd->xf, xf, sizeof(gd->xf));
+    gd->out_offset = 0;
+    gd->row_stride = w*channels;                                 // the device tile is tightly packed in memory-row order
+    gd->flip = flip ? 1 : 0;
+    if (correctionOnly)
         for (int y = 0; y < h; ++y)
-            memcpy(&tile[(size_t) y*w*channels], pixels+(ptrdiff_t) rowStride*y, sizeof(float)*(size_t) w*channels);
-        MsdfHipGlyph *dGlyph = NULL;
-        float *dSrc = NULL, *dOut = NULL;
-        uint8_t *dSt = NULL;
-        hipError_t e = hipMalloc((void **) &dGlyph, sizeof(gd));
-        if (e == hipSuccess) e = hipMalloc((void **) &dSrc, n*sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void **) &dOut, n*sizeof(float));
-        if (e == hipSuccess && stencil) e = hipMalloc((void **) &dSt, (size_t) w*h);
-        if (e == hipSuccess) e = hipMemcpy(dGlyph, &gd, sizeof(gd), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(dSrc, tile.data(), n*sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) {
-            rc = runCorrection(b, channels, w, h, dGlyph, dSrc, dOut, dSt, *cfg, NULL);
-            if (rc == MSDFHIP_OK) {
-                e = hipStreamSynchronize(NULL);
-                if (e == hipSuccess) e = hipMemcpy(tile.data(), dOut, n*sizeof(float), hipMemcpyDeviceToHost);
-                if (e == hipSuccess && stencil) e = hipMemcpy(st.data(), dSt, (size_t) w*h, hipMemcpyDeviceToHost);
-            }
-        }
-        hipFree(dGlyph), hipFree(dSrc), hipFree(dOut), hipFree(dSt);
-        if (e != hipSuccess)
-            rc = fail(MSDFHIP_ERR_HIP, "msdfhip_error_correction: %s", hipGetErrorString(e));
-    } else
-        rc = msdfhip_batch_generate_host(b, mode, w, h, &gd, tile.data(), n, stencil ? st.data() : NULL, cfg);
-    msdfhip_batch_destroy(b);
-    if (rc != MSDFHIP_OK)
+            memcpy(a.pinned+hSrc+(size_t) y*w*channels*sizeof(float), pixels+(ptrdiff_t) rowStride*y, sizeof(float)*(size_t) w*channels);
+    HIPCHK(hipMemcpyAsync(a.dev, a.pinned, inputBytes, hipMemcpyHostToDevice, a.stream));
+
+    MsdfHipBatch b;                                              // non-owning view into the arena
+    b.nGlyphs = 1, b.nContours = nC, b.nEdges = nE, b.maxContours = nC, b.maxEdges = nE;
+    b.ownsInputs = false;
+    b.dGlyphContourOffsets = reinterpret_cast<int32_t *>(a.dev+hGco);
+    b.dContourOffsets = reinterpret_cast<int32_t *>(a.dev+hCo);
+    b.dPoints = reinterpret_cast<double *>(a.dev+hPts);
+    b.dTypes = reinterpret_cast<uint8_t *>(a.dev+hTypes);
+    b.dColors = reinterpret_cast<uint8_t *>(a.dev+hColors);
+    b.dRecs = reinterpret_cast<EdgeRec *>(a.dev+dRecs);
+    b.dWindings = reinterpret_cast<int8_t *>(a.dev+dWind);
+    b.dScratch = NULL, b.scratchFloats = 0;
+    b.dDeferred = correct ? reinterpret_cast<EcCandidate *>(a.dev+dCands) : NULL;
+    b.deferredCap = correct ? candCap : 0;
+    b.dEcParams = reinterpret_cast<EcGlyphParams *>(a.dev+dParams);
+    const MsdfHipGlyph *dGlyph = reinterpret_cast<const MsdfHipGlyph *>(a.dev+hGlyph);
+    float *dOut = reinterpret_cast<float *>(a.dev+hOut);
+    uint8_t *dStencil = stencil ? reinterpret_cast<uint8_t *>(a.dev+hStencil) : NULL;
+
+    rc = digest(&b, a.stream);
+    if (rc == MSDFHIP_OK) {
+        if (correctionOnly)
+            rc = runCorrection(&b, channels, w, h, dGlyph, reinterpret_cast<const float *>(a.dev+hSrc), dOut, dStencil, *cfg, a.stream);
+        else
+            rc = msdfhip_batch_generate(&b, mode, w, h, dGlyph, dOut, dStencil, correct ? reinterpret_cast<float *>(a.dev+dScratch) : NULL, cfg, a.stream);
+    }
+    if (rc != MSDFHIP_OK) {
+        hipStreamSynchronize(a.stream);
         return rc;
+    }
+    HIPCHK(hipMemcpyAsync(a.pinned+hOut, a.dev+hOut, stencil ? resultBytes : tileBytes, hipMemcpyDeviceToHost, a.stream));
+    HIPCHK(hipStreamSynchronize(a.stream));
+    const float *tile = reinterpret_cast<const float *>(a.pinned+hOut);
     for (int y = 0; y < h; ++y)
-        memcpy(pixels+(ptrdiff_t) rowStride*y, &tile[(size_t) y*w*channels], sizeof(float)*(size_t) w*channels);
+        memcpy(pixels+(ptrdiff_t) rowStride*y, tile+(size_t) y*w*channels, sizeof(float)*(size_t) w*channels);
     if (stencil)
-        memcpy(stencil, st.data(), st.size());
+        memcpy(stencil, a.pinned+hStencil, texels);
     return MSDFHIP_OK;
 }
 
