@@ -90,6 +90,8 @@ struct MsdfHipBatch {
     mutable size_t scratchFloats;
     mutable EcCandidate *dDeferred;   // [0] = header (count), [1..cap] = distance checks deferred to k_ec_query
     mutable EcGlyphParams *dEcParams; // per-glyph constants of the error-correction pass
+    mutable double *dGres;            // global combiner scratch for glyphs whose contour count exceeds what LDS can hold
+    mutable size_t gresBytes;
     mutable size_t deferredCap;
     mutable std::mutex scratchMutex;
 };
@@ -122,16 +124,24 @@ int digest(MsdfHipBatch *b, hipStream_t stream) {
 }
 
 // LDS plan for a launch: bytes of dynamic LDS and whether the records are staged in LDS or read from global memory.
-struct LdsPlan { size_t bytes; bool ldsRec; };
+struct LdsPlan { size_t bytes; bool ldsRec; bool globalRes; size_t resBytes; };
+const size_t GRES_WORKSPACE_CAP = (size_t) 1<<30;   // bound of the global combiner scratch; larger launches are chunked
 
 int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan) {
     const size_t resBytes = overlap ? (size_t) b->maxContours*nch*WAVE*sizeof(double) : 0;
     const size_t recBytes = (size_t) b->maxEdges*sizeof(EdgeRec);
     const size_t idxBytes = ((size_t) b->maxEdges+(size_t) b->maxContours+2)*sizeof(int);   // survivor list + per-contour offsets
     const size_t limit = (size_t) gLdsLimit.load();
-    if (resBytes+idxBytes > limit)
-        return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours / %d edges: the combiner state needs %zu B of LDS per wavefront, device limit is %zu B",
-                    b->maxContours, b->maxEdges, resBytes+idxBytes, limit);
+    plan.resBytes = resBytes;
+    plan.globalRes = overlap && resBytes+idxBytes > 96*1024;     // beyond 96 KB a workgroup would own most of the CU's LDS: spill the scratch to HBM
+    if (idxBytes > limit)
+        return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours / %d edges: the survivor list needs %zu B of LDS per wavefront, device limit is %zu B",
+                    b->maxContours, b->maxEdges, idxBytes, limit);
+    if (plan.globalRes) {
+        plan.ldsRec = false;
+        plan.bytes = idxBytes;
+        return MSDFHIP_OK;
+    }
     // Measured on MI355X (profiles/): reading the surviving records straight from global memory with wave-uniform
     // (scalar) loads beats staging them in LDS, because the LDS footprint of the worst-case glyph caps occupancy. Staging stays
     // available as an experiment knob (MSDFHIP_LDSREC=1) while it fits in 40 KB.
@@ -149,15 +159,47 @@ int setLds(K kernel, size_t bytes) {
     return MSDFHIP_OK;
 }
 
-template <int SEL, bool OVERLAP, bool LDSREC>
-int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, size_t lds, hipStream_t stream) {
+int ensureGres(const MsdfHipBatch *b, size_t bytes, double **out) {
+    std::lock_guard<std::mutex> lock(b->scratchMutex);
+    if (b->gresBytes < bytes) {
+        if (b->dGres)
+            hipFree(b->dGres);
+        b->dGres = NULL, b->gresBytes = 0;
+        HIPCHK(hipMalloc((void **) &b->dGres, bytes));
+        b->gresBytes = bytes;
+    }
+    *out = b->dGres;
+    return MSDFHIP_OK;
+}
+
+template <int SEL, bool OVERLAP, bool LDSREC, bool GRES>
+int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, const LdsPlan &plan, hipStream_t stream) {
     const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE, tiles = tilesX*tilesY;
-    const unsigned blocks = (unsigned) ((b->nGlyphs+7)/8)*8u*(unsigned) tiles;
-    int rc = setLds(k_distance<SEL, OVERLAP, LDSREC>, lds);
+    const size_t blocks = (size_t) ((b->nGlyphs+7)/8)*8u*(size_t) tiles;
+    if (blocks > 0x7fffffffull)
+        return fail(MSDFHIP_ERR_INVALID, "launch of %zu tiles exceeds the grid limit; split the batch", blocks);
+    int rc = setLds(k_distance<SEL, OVERLAP, LDSREC, GRES>, plan.bytes);
     if (rc != MSDFHIP_OK)
         return rc;
+    double *gres = NULL;
+    size_t chunk = blocks, stride = 0;
+    if (GRES) {
+        stride = plan.resBytes/sizeof(double);
+        chunk = GRES_WORKSPACE_CAP/plan.resBytes;
+        if (chunk < 256)
+            chunk = 256;
+        if (chunk > blocks)
+            chunk = blocks;
+        rc = ensureGres(b, chunk*plan.resBytes, &gres);
+        if (rc != MSDFHIP_OK)
+            return rc;
+    }
     ScopedTimer timer(stream, 0);
-    hipLaunchKernelGGL((k_distance<SEL, OVERLAP, LDSREC>), dim3(blocks), dim3(WAVE), lds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, b->maxEdges, dst, toScratch);
+    for (size_t base = 0; base < blocks; base += chunk) {
+        const size_t n = blocks-base < chunk ? blocks-base : chunk;
+        hipLaunchKernelGGL((k_distance<SEL, OVERLAP, LDSREC, GRES>), dim3((unsigned) n), dim3(WAVE), plan.bytes, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles,
+                           b->maxEdges, dst, toScratch, (unsigned) base, gres, stride);
+    }
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
 }
@@ -168,11 +210,13 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     int rc = planLds(b, SelTraits<SEL>::NCH, overlap, plan);
     if (rc != MSDFHIP_OK)
         return rc;
+    if (plan.globalRes)
+        return launchDistance<SEL, true, false, true>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
     if (overlap)
-        return plan.ldsRec ? launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, plan.bytes, stream)
-                           : launchDistance<SEL, true, false>(b, dGlyphs, w, h, dst, toScratch, plan.bytes, stream);
-    return plan.ldsRec ? launchDistance<SEL, false, true>(b, dGlyphs, w, h, dst, toScratch, plan.bytes, stream)
-                       : launchDistance<SEL, false, false>(b, dGlyphs, w, h, dst, toScratch, plan.bytes, stream);
+        return plan.ldsRec ? launchDistance<SEL, true, true, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream)
+                           : launchDistance<SEL, true, false, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
+    return plan.ldsRec ? launchDistance<SEL, false, true, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream)
+                       : launchDistance<SEL, false, false, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
 }
 
 int ensureDeferred(const MsdfHipBatch *b, size_t cap, EcCandidate **out) {
@@ -191,7 +235,7 @@ int ensureDeferred(const MsdfHipBatch *b, size_t cap, EcCandidate **out) {
     return MSDFHIP_OK;
 }
 
-template <int N, bool OVERLAP>
+template <int N, bool OVERLAP, bool GRES>
 int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, const float *src, float *out, uint8_t *stencil,
              const MsdfHipConfig &cfg, hipStream_t stream) {
     const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE, tiles = tilesX*tilesY;
@@ -199,17 +243,26 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     const size_t allTexels = (size_t) b->nGlyphs*w*h;
     if (allTexels >= 0xffffffffull)
         return fail(MSDFHIP_ERR_INVALID, "batch of %zu texels exceeds the 32-bit texel index of the error-correction pass; split the batch", allTexels);
-    const size_t slowLds = OVERLAP ? (size_t) b->maxContours*WAVE*sizeof(double) : 0;
-    if (slowLds > (size_t) gLdsLimit.load())
-        return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours: the distance check needs %zu B of LDS per wavefront", b->maxContours, slowLds);
-    int rc = setLds(k_ec_slow<N, OVERLAP>, slowLds);
+    const size_t resBytes = OVERLAP ? (size_t) b->maxContours*WAVE*sizeof(double) : 0;   // combiner scratch of the PSDF distance checks
+    const size_t slowLds = GRES ? 0 : resBytes;
+    const unsigned slowGrid = 2048, queryGrid = 1024;
+    double *gres = NULL;
+    int rc;
+    if (GRES) {
+        rc = ensureGres(b, (size_t) slowGrid*resBytes, &gres);
+        if (rc != MSDFHIP_OK)
+            return rc;
+    }
+    const size_t gresStride = resBytes/sizeof(double);
+    rc = setLds(k_ec_slow<N, OVERLAP, GRES>, slowLds);
     if (rc != MSDFHIP_OK)
         return rc;
     ScopedTimer timer(stream, 1);
     if (cfg.ec_stage_limit != 0) {                               // test hook: stencil snapshots through the full pipeline for every texel
-        const unsigned slowBlocks = (unsigned) ((allTexels+WAVE-1)/WAVE < 16384 ? (allTexels+WAVE-1)/WAVE : 16384);
-        hipLaunchKernelGGL((k_ec_slow<N, OVERLAP>), dim3(slowBlocks), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
-                           (const EcCandidate *) NULL, 0u, 0);
+        const unsigned cap = GRES ? slowGrid : 16384u;
+        const unsigned slowBlocks = (unsigned) ((allTexels+WAVE-1)/WAVE < cap ? (allTexels+WAVE-1)/WAVE : cap);
+        hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowBlocks), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
+                           (const EcCandidate *) NULL, 0u, 0, gres, gresStride);
         HIPCHK(hipGetLastError());
         return MSDFHIP_OK;
     }
@@ -218,7 +271,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     rc = ensureDeferred(b, cap, &deferred);
     if (rc != MSDFHIP_OK)
         return rc;
-    rc = setLds(k_ec_query<N, OVERLAP>, slowLds);
+    rc = setLds(k_ec_query<N, OVERLAP, GRES>, slowLds);
     if (rc != MSDFHIP_OK)
         return rc;
     HIPCHK(hipMemsetAsync(deferred, 0, sizeof(EcCandidate), stream));
@@ -229,10 +282,10 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     hipLaunchKernelGGL(k_ec_params, dim3((b->nGlyphs+255)/256), dim3(256), 0, stream, b->dEcParams, dGlyphs, b->nGlyphs, cfg);
     hipLaunchKernelGGL((k_ec_fast<N>), dim3(blocks), dim3(WAVE), fastLds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, src, out, stencil, cfg,
                        (const EcGlyphParams *) b->dEcParams, deferred, (unsigned) cap);
-    hipLaunchKernelGGL((k_ec_query<N, OVERLAP>), dim3(1024), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
-                       (const EcCandidate *) deferred, (unsigned) cap);
-    hipLaunchKernelGGL((k_ec_slow<N, OVERLAP>), dim3(2048), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
-                       (const EcCandidate *) deferred, (unsigned) cap, 1);
+    hipLaunchKernelGGL((k_ec_query<N, OVERLAP, GRES>), dim3(queryGrid), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
+                       (const EcCandidate *) deferred, (unsigned) cap, gres, gresStride);
+    hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowGrid), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
+                       (const EcCandidate *) deferred, (unsigned) cap, 1, gres, gresStride);
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
 }
@@ -240,8 +293,11 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
 template <int N>
 int dispatchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, const float *src, float *out, uint8_t *stencil,
                const MsdfHipConfig &cfg, hipStream_t stream) {
-    return cfg.overlap_support ? launchEc<N, true>(b, dGlyphs, w, h, src, out, stencil, cfg, stream)
-                               : launchEc<N, false>(b, dGlyphs, w, h, src, out, stencil, cfg, stream);
+    if (!cfg.overlap_support)
+        return launchEc<N, false, false>(b, dGlyphs, w, h, src, out, stencil, cfg, stream);
+    const bool globalRes = (size_t) b->maxContours*WAVE*sizeof(double) > 96*1024;
+    return globalRes ? launchEc<N, true, true>(b, dGlyphs, w, h, src, out, stencil, cfg, stream)
+                     : launchEc<N, true, false>(b, dGlyphs, w, h, src, out, stencil, cfg, stream);
 }
 
 int checkConfig(const MsdfHipConfig *cfg) {
@@ -345,7 +401,7 @@ int msdfhip_batch_create_device(MsdfHipBatch **batch, int n_glyphs, int n_contou
     b->dPoints = const_cast<double *>(d_points);
     b->dTypes = const_cast<uint8_t *>(d_types);
     b->dColors = const_cast<uint8_t *>(d_colors);
-    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0, b->dEcParams = NULL;
+    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0, b->dEcParams = NULL, b->dGres = NULL, b->gresBytes = 0;
     rc = digest(b, (hipStream_t) stream);
     if (rc != MSDFHIP_OK) {
         msdfhip_batch_destroy(b);
@@ -382,7 +438,7 @@ int msdfhip_batch_create(MsdfHipBatch **batch, int n_glyphs, const int32_t *gco,
     b->nGlyphs = n_glyphs, b->nContours = nC, b->nEdges = nE, b->maxContours = maxC, b->maxEdges = maxE;
     b->ownsInputs = true;
     b->dGlyphContourOffsets = NULL, b->dContourOffsets = NULL, b->dPoints = NULL, b->dTypes = NULL, b->dColors = NULL;
-    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0, b->dEcParams = NULL;
+    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0, b->dEcParams = NULL, b->dGres = NULL, b->gresBytes = 0;
     const size_t eAlloc = nE > 0 ? nE : 1;
     #define ALLOC_COPY(dst, src, bytes, used) do { \
         hipError_t e_ = hipMalloc((void **) &(dst), (bytes) ? (bytes) : 16); \
@@ -429,6 +485,7 @@ void msdfhip_batch_destroy(MsdfHipBatch *b) {
     hipFree(b->dScratch);
     hipFree(b->dDeferred);
     hipFree(b->dEcParams);
+    hipFree(b->dGres);
     delete b;
 }
 
@@ -638,6 +695,7 @@ static int singleShape(int mode, int channels, bool correctionOnly, float *pixel
     b.dDeferred = correct ? reinterpret_cast<EcCandidate *>(a.dev+dCands) : NULL;
     b.deferredCap = correct ? candCap : 0;
     b.dEcParams = reinterpret_cast<EcGlyphParams *>(a.dev+dParams);
+    b.dGres = NULL, b.gresBytes = 0;
     const MsdfHipGlyph *dGlyph = reinterpret_cast<const MsdfHipGlyph *>(a.dev+hGlyph);
     float *dOut = reinterpret_cast<float *>(a.dev+hOut);
     uint8_t *dStencil = stencil ? reinterpret_cast<uint8_t *>(a.dev+hStencil) : NULL;

@@ -74,9 +74,9 @@ struct GlyphWork {
 };
 
 // XCD-aware decode of blockIdx -> (glyph, tile): glyphs are dealt round-robin to the 8 XCDs, every tile of a glyph to the same XCD.
-__device__ inline GlyphWork decodeBlock(int nGlyphs, int tilesPerGlyph) {
+__device__ inline GlyphWork decodeBlock(int nGlyphs, int tilesPerGlyph, unsigned blockBase = 0) {
     GlyphWork w;
-    const unsigned b = blockIdx.x;
+    const unsigned b = blockIdx.x+blockBase;
     const unsigned xcd = b&7u, slot = b>>3;
     w.g = (int) ((slot/(unsigned) tilesPerGlyph)*8u+xcd);
     w.tile = (int) (slot%(unsigned) tilesPerGlyph);
@@ -141,12 +141,15 @@ __device__ inline float floatAbove(double d) {
 // the tile (msdf_cull.hpp), and compact the survivors -- in visit order -- into LDS.  Phase 2 (lanes = texels): every lane runs
 // the reference's per-contour nearest-edge selection over the survivors with wave-uniform (broadcast) record reads.
 // LDS: [res: C*NCH*64 doubles (overlap)] [records: maxEdges (LDSREC)] [list: maxEdges ints] [cstart: C+1 ints].
-template <int SEL, bool OVERLAP, bool LDSREC>
+// GRES: the combiner scratch of glyphs with very many contours does not fit the CU's LDS; it then lives in a global workspace
+// (gres, one slice per workgroup of the launch chunk) and the launch is chunked (blockBase) to bound that workspace.
+template <int SEL, bool OVERLAP, bool LDSREC, bool GRES = false>
 __global__ void __launch_bounds__(WAVE, MSDF_DISTANCE_WAVES_PER_SIMD)
-k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges, float *dst, int toScratch) {
+k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges, float *dst, int toScratch,
+           unsigned blockBase, double *gres, size_t gresStride) {
     enum { NCH = SelTraits<SEL>::NCH };
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const GlyphWork wk = decodeBlock(batch.nGlyphs, tilesPerGlyph);
+    const GlyphWork wk = decodeBlock(batch.nGlyphs, tilesPerGlyph, blockBase);
     if (!wk.valid)
         return;
     const int c0 = batch.glyphContourOffsets[wk.g], C = batch.glyphContourOffsets[wk.g+1]-c0;
@@ -155,8 +158,8 @@ k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, i
     const int lane = threadIdx.x;
     const EdgeRec *recGlobal = batch.recs+e0;
 
-    double *res = smem;                                             // [C][NCH][64] (overlap only)
-    double *recLds = smem+(OVERLAP ? (size_t) C*NCH*WAVE : 0);
+    double *res = GRES ? gres+(size_t) blockIdx.x*gresStride : smem; // [C][NCH][64] (overlap only)
+    double *recLds = smem+(OVERLAP && !GRES ? (size_t) C*NCH*WAVE : 0);
     int *list = reinterpret_cast<int *>(recLds+(LDSREC ? (size_t) maxEdges*REC_DOUBLES : 0));
     int *cstart = list+maxEdges;
 
@@ -395,11 +398,12 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
 // The deferred distance checks, one lane per candidate (all lanes run exactly one PSDF query: convergent). A candidate that
 // turns out to be an artifact flags its texel: rgb := median (apply, MSDFErrorCorrection.cpp:459-479), stencil |= ERROR. Several
 // candidates of one texel write identical values.
-template <int N, bool OVERLAP>
+template <int N, bool OVERLAP, bool GRES = false>
 __global__ void __launch_bounds__(WAVE)
 k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, const float *src, float *out, uint8_t *stencilOut,
-           MsdfHipConfig cfg, const EcCandidate *cands, unsigned capacity) {
-    extern __shared__ double smem[];                                // [maxContours][64] combiner scratch (overlap only)
+           MsdfHipConfig cfg, const EcCandidate *cands, unsigned capacity, double *gres, size_t gresStride) {
+    extern __shared__ double smemLds[];                             // [maxContours][64] combiner scratch (overlap only)
+    double *smem = GRES ? gres+(size_t) blockIdx.x*gresStride : smemLds;
     const unsigned count = cands[0].texel;
     if (count > capacity)
         return;                                                     // overflow: k_ec_slow redoes every texel
@@ -438,11 +442,12 @@ k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, c
 
 // Full per-texel pipeline incl. the exact shape-distance check (msdf_ec.hpp) for EVERY texel of the batch: used for the stage
 // snapshots of the tests (overflowOnly == 0) and as the safety net when the candidate list overflowed (overflowOnly != 0).
-template <int N, bool OVERLAP>
+template <int N, bool OVERLAP, bool GRES = false>
 __global__ void __launch_bounds__(WAVE)
 k_ec_slow(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, const float *src, float *out, uint8_t *stencilOut,
-          MsdfHipConfig cfg, const EcCandidate *cands, unsigned capacity, int overflowOnly) {
-    extern __shared__ double smem[];                                // [maxContours][64] combiner scratch (overlap only)
+          MsdfHipConfig cfg, const EcCandidate *cands, unsigned capacity, int overflowOnly, double *gres, size_t gresStride) {
+    extern __shared__ double smemLds[];                             // [maxContours][64] combiner scratch (overlap only)
+    double *smem = GRES ? gres+(size_t) blockIdx.x*gresStride : smemLds;
     const size_t texelsPerGlyph = (size_t) width*height;
     const size_t allTexels = texelsPerGlyph*batch.nGlyphs;
     if (overflowOnly && cands[0].texel <= capacity)

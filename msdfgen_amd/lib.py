@@ -83,6 +83,12 @@ def load(build_if_missing=True):
     with _lock:
         if _lib is not None:
             return _lib
+        try:
+            # torch wheels bundle their own libamdhip64; if our library pulls in /opt/rocm's first, a later `import torch` no longer
+            # sees the GPU (two HIP runtimes in one process). Importing torch first makes both share torch's runtime.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         path = os.environ.get("MSDFGEN_HIP_LIB") or _build.LIB   # override: A/B-ing kernel build variants from bench.py
         if path == _build.LIB and not os.path.exists(path):
             if not build_if_missing:

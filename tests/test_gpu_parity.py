@@ -220,6 +220,56 @@ def test_many_contours_cjk_like_48(oracle):
     gb.close()
 
 
+def test_config4_full_size_atlas_8192_glyphs_48(oracle):
+    """BASELINE config 4 at FULL size: an 8 192-glyph atlas, msdf 48x48, rendered in one batched launch (CJK-like synthetic glyphs
+    stand in for NotoSansCJK, which is not on the box: 8-20 contours, 60-150 edges each). The oracle cannot render 8 192 such glyphs
+    in test time, so: a random sample of tiles is compared exactly with the oracle, the batch is re-rendered as 8 glyph-sharded
+    parts (what 8 GPUs would do) and must be byte-identical, and duplicated glyphs must produce identical tiles."""
+    import torch
+    from msdfgen_amd.shard import shard
+    base = [synth.cjk_like_shape(20000+i) for i in range(512)]
+    shapes = [base[i % 512] for i in range(8192)]
+    xfs512 = np.stack([autoframe(s.bounds(), 48, 48, 4) for s in base])
+    xfs = xfs512[np.arange(8192) % 512]
+    batch = ShapeBatch.from_shapes(shapes)
+    gb = M.GlyphBatch(batch)
+    tiles = gb.generate(3, 48, 48, xfs)
+    torch.cuda.synchronize()
+    got = tiles.cpu().numpy()
+    gb.close()
+    assert got.shape == (8192, 48, 48, 3) and np.isfinite(got).all()
+    rng = np.random.default_rng(4)
+    worst = 0
+    for g in rng.choice(8192, 24, replace=False):
+        worst += close(got[g], oracle.generate(shapes[g], 3, 48, 48, xfs[g]), "atlas glyph %d" % g)
+    assert (bits(got[:512]) == bits(got[512:1024])).all() and (bits(got[:512]) == bits(got[7680:])).all()
+    parts = []
+    for r in range(8):
+        sub, sx, (lo, hi) = shard(batch, xfs, r, 8, 48, 48)
+        parts.append(M.GlyphBatch(sub).generate(3, 48, 48, sx).cpu().numpy())
+    assert (bits(np.concatenate(parts)) == bits(got)).all()
+    print("config 4: 24 sampled tiles, %d texels differing bitwise" % worst)
+
+
+def test_very_many_contours_use_the_global_combiner_scratch(oracle):
+    """Maximum-size edge case: 260 overlapping contours. The overlapping combiner's per-contour scratch (260*3*512 B) exceeds the CU's
+    LDS, so k_distance / k_ec_query keep it in a global workspace; results must not change."""
+    rng = np.random.default_rng(9)
+    contours = []
+    for i in range(260):
+        cx, cy, r = rng.uniform(.05, .95), rng.uniform(.05, .95), rng.uniform(.02, .08)
+        a = rng.uniform(0, 6.28)
+        pts = [(cx+r*np.cos(a+k*2.0944), cy+r*np.sin(a+k*2.0944)) for k in range(3)]
+        if i % 5 == 0:
+            pts = pts[::-1]
+        contours.append([((3, 5, 6)[k], pts[k], pts[(k+1) % 3]) if (i+k) % 2 else ((3, 5, 6)[k], pts[k], (cx, cy), pts[(k+1) % 3]) for k in range(3)])
+    s = FlatShape.from_contours(contours)
+    xf = autoframe((0, 0, 1, 1), 64, 56, 3)
+    for mode in (3, 4, 2):
+        close(gen(mode, s, 64, 56, xf), oracle.generate(s, mode, 64, 56, xf), "260 contours mode %d" % mode)
+    close(gen(3, s, 64, 56, xf, cfg(ec_dist=M.ALWAYS_CHECK_DISTANCE)), oracle.generate(s, 3, 64, 56, xf, ec_dist=2), "260 contours, always check distance")
+
+
 def test_sharding_is_byte_invariant(latin):
     """Glyph-sharded execution: the bytes of every tile are identical whether the batch is rendered whole or in parts."""
     from msdfgen_amd.shard import shard
