@@ -77,6 +77,37 @@ MSDF_HD bool quadraticMayHaveRootInRange(double a, double b, double c) {
     return !(4*as*cs-bs*bs > 1e-9*mag*mag);             // minimum value cs-bs^2/(4as) not clearly positive -> may have roots
 }
 
+// Cheapest necessary condition for a diagonal candidate, in fp32: along the diagonal the channel difference is the quadratic with
+// Bernstein coefficients (dA, dBC/2, dD) on [0, 1] (f(0) = dA, f(1) = dD). If all three have the same sign with a margin that
+// dwarfs the rounding of the reference's float coefficients (dD-dBC+dA, dBC-dA-dA: <= 5e-7*M), the quadratic has no real root in
+// [0, 1], so solveQuadratic cannot return one in (0.01, 0.99). False = "cannot have a root".
+MSDF_HD bool bernsteinMayHaveRoot(float dA, float dBC, float dD) {
+    const float m = fmaxf(fmaxf(fabsf(dA), fabsf(dBC)), fabsf(dD));
+    const float eps = 1e-5f*m;
+    const float h = .5f*dBC;
+    return !((dA > eps && h > eps && dD > eps) || (dA < -eps && h < -eps && dD < -eps));
+}
+
+// edgeBetweenTexelsChannel (MSDFErrorCorrection.cpp:154-168) with the fp64 division skipped when t = (a-.5)/(a-b) cannot lie in
+// (0, 1): numerator n = a-.5 (exact in fp64) and denominator d = fl32(a-b) must have the same sign and |n| < |d|; both are
+// fp32-derived, so n/d < 1 implies n/d <= 1-2^-26 and the rounded quotient is < 1 as well -- the predicate is exact.
+MSDF_HD bool edgeBetweenTexelsChannelFast(const float *a, const float *b, int channel) {
+    const double n = a[channel]-.5;
+    const double d = a[channel]-b[channel];
+    if (!((n > 0 && d > 0 && n < d) || (n < 0 && d < 0 && n > d)))
+        return false;
+    const double t = n/d;
+    if (t > 0 && t < 1) {
+        float c[3] = { mixf(a[0], b[0], t), mixf(a[1], b[1], t), mixf(a[2], b[2], t) };
+        return medianf(c[0], c[1], c[2]) == c[channel];
+    }
+    return false;
+}
+
+MSDF_HD int edgeBetweenTexelsFast(const float *a, const float *b) {
+    return 1*(int) edgeBetweenTexelsChannelFast(a, b, 0)+2*(int) edgeBetweenTexelsChannelFast(a, b, 1)+4*(int) edgeBetweenTexelsChannelFast(a, b, 2);
+}
+
 // One diagonal channel pair (:291-327) with lazy extremum parameters. Returns judge() of the accumulated flags, OR-ed over roots;
 // candidates that need the distance check are handed to `sink(t)`.
 template <class Sink>
@@ -166,7 +197,7 @@ MSDF_HD bool protectedByEdgesNb(const Neighbourhood &nb, const EcParams &p) {
             const bool selfIsA = dy > 0 || (dy == 0 && dx > 0);
             const float sum = selfIsA ? sdev+fabsf(om-.5f) : fabsf(om-.5f)+sdev;     // fabsf(am-.5f)+fabsf(bm-.5f)
             if (!prot && sum < radius) {
-                const int mask = selfIsA ? edgeBetweenTexels(self, other) : edgeBetweenTexels(other, self);
+                const int mask = selfIsA ? edgeBetweenTexelsFast(self, other) : edgeBetweenTexelsFast(other, self);
                 prot = extremeChannelInMask(self, sm, mask);
             }
         }
@@ -239,6 +270,8 @@ MSDF_HD int texelFindFast(const Neighbourhood &nb, const EcParams &p, bool p1, i
             const float dA = a[i1]-a[i0], dBC = b[i1]-b[i0]+cc[i1]-cc[i0], dD = d[i1]-d[i0];
             if (dA == 0 && dBC == 0 && dD == 0)
                 continue;                                // 0 == 0: solveQuadratic reports no usable root (equation-solver.cpp:13-17)
+            if (!bernsteinMayHaveRoot(dA, dBC, dD))
+                continue;
             if (!(verdict&1))
                 verdict |= diagonalPairFast(cx, cm, dm, a, l, q, dA, dBC, dD, i0, i1, dirSink);
         }

@@ -196,7 +196,7 @@ long emu_quadratic_prefilter_violations(const float *abc, long n, long *skipped)
     for (long i = 0; i < n; ++i) {
         const float dA = abc[3*i], dBC = abc[3*i+1], dD = abc[3*i+2];
         const double qa = dD-dBC+dA, qb = dBC-dA-dA, qc = dA;
-        if (!quadraticMayHaveRootInRange(qa, qb, qc)) {
+        if (!bernsteinMayHaveRoot(dA, dBC, dD) || !quadraticMayHaveRootInRange(qa, qb, qc)) {
             ++skip;
             double t[2];
             int m = solveQuadratic(t, qa, qb, qc);
