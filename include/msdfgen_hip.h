@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MSDFHIP_ABI_VERSION 1
+#define MSDFHIP_ABI_VERSION 2
 
 /* mode: which generator (msdfgen.h:46-56) */
 #define MSDFHIP_MODE_SDF   1 /* generateSDF   msdfgen.h:47  (TrueDistanceSelector)          1 channel  */
@@ -71,6 +71,12 @@ typedef struct MsdfHipConfig {
                                     4 +protectAll+findErrors(sdf,shape)) and do not apply; used by the parity tests */
     double min_deviation_ratio;  /* default 1.11111111111111111 (core/MSDFErrorCorrection.cpp:22) */
     double min_improve_ratio;    /* default 1.11111111111111111 (core/MSDFErrorCorrection.cpp:23) */
+    /* Optional scanline pass between the distance field and the error correction, as the reference CLI does in no-Skia builds
+     * (main.cpp:1281-1298): distanceSignCorrection (core/rasterization.h:17-19). Default off (the library functions do not do it). */
+    int32_t sign_correction;     /* 0 / 1 */
+    int32_t fill_rule;           /* FillRule, core/Scanline.h:10-15: 0 NONZERO (default), 1 ODD, 2 POSITIVE, 3 NEGATIVE */
+    float sdf_zero_value;        /* default 0.5 */
+    int32_t reserved;
 } MsdfHipConfig;
 
 /* Per-glyph descriptor of a batch (one output tile per glyph). Lives in device memory for the *_device entry points. */
@@ -124,6 +130,20 @@ int msdfhip_error_correction(int channels, float *pixels, int width, int height,
                              const int32_t *contour_offsets, int n_contours, const double *points, const uint8_t *types, const uint8_t *colors,
                              const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil);
 
+/* distanceSignCorrection(sdf, shape, projection, sdfZeroValue, fillRule) on an existing 1-, 3- or 4-channel bitmap, in place.
+ *   replaces core/rasterization.cpp:19-92 (declared core/rasterization.h:17-19; the legacy overloads :21-27 forward).
+ * xf: only the Projection part {sx, sy, tx, ty} is read. fill_rule: FillRule (core/Scanline.h:10-15). */
+int msdfhip_distance_sign_correction(int channels, float *pixels, int width, int height, int row_stride, int flip,
+                                     const int32_t *contour_offsets, int n_contours, const double *points, const uint8_t *types, const uint8_t *colors,
+                                     const double *xf, float sdf_zero_value, int fill_rule);
+
+/* rasterize(output, shape, projection, fillRule): 1-channel coverage bitmap, 1.f where the texel centre is filled.
+ *   replaces core/rasterization.cpp:8-16 (declared core/rasterization.h:13, legacy overload :22) -- the same scanline fill
+ *   test as the sign correction; provided so that a build can drop the reference's rasterization.cpp as a whole. */
+int msdfhip_rasterize(float *pixels, int width, int height, int row_stride, int flip,
+                      const int32_t *contour_offsets, int n_contours, const double *points, const uint8_t *types, const uint8_t *colors,
+                      const double *xf, int fill_rule);
+
 /* ShapeDistanceFinder<CC<Selector>>::oneShotDistance at n shape-space points (core/ShapeDistanceFinder.hpp:36-58; the
  * per-pixel engine under generate*).  selector = mode 1..4; out receives n*4 doubles (unused channels 0). */
 int msdfhip_shape_distance(int selector, int overlap_support, const int32_t *contour_offsets, int n_contours, const double *points,
@@ -155,8 +175,8 @@ int msdfhip_batch_windings(const MsdfHipBatch *batch, int32_t *windings);
 
 /* Generates all tiles of the batch: glyph g's tile is written at d_out + d_glyphs[g].out_offset with d_glyphs[g].row_stride.
  * d_glyphs (device, MsdfHipGlyph[n_glyphs]), d_out (device floats), d_stencil (device, n_glyphs*width*height bytes, or NULL),
- * d_scratch: device floats, same extent as the tiles (n_glyphs*width*height*N), needed only when error correction runs
- * (pre-correction distance field); may be NULL, then an internal buffer is used.
+ * d_scratch: device floats for the intermediate fields: one tile extent (n_glyphs*width*height*N) if error correction OR sign
+ * correction runs, two if both do; may be NULL, then internal buffers are used.
  * Asynchronous on `stream` (hipStream_t or NULL = default stream). Replaces a loop of msdfgen.h:46-53 calls. */
 int msdfhip_batch_generate(const MsdfHipBatch *batch, int mode, int width, int height, const MsdfHipGlyph *d_glyphs,
                            float *d_out, uint8_t *d_stencil, float *d_scratch, const MsdfHipConfig *cfg, void *stream);

@@ -4,6 +4,8 @@ on top of the C ABI.  Same names, argument meaning and defaults as the reference
 
     generate_sdf / generate_psdf / generate_msdf / generate_mtsdf (output, shape, transformation, config)
     msdf_error_correction(sdf, shape, transformation, config)
+    distance_sign_correction(sdf, shape, projection, sdf_zero_value, fill_rule)
+    rasterize(output, shape, projection, fill_rule)
     shape_distance(shape, selector, overlap_support, points)      -- ShapeDistanceFinder::oneShotDistance
 
 `GlyphBatch` is the batched, device-resident front door (one launch for thousands of glyph tiles); it uses torch only to own
@@ -17,7 +19,8 @@ import numpy as np
 
 from . import lib as _lib
 from .lib import (MODE_SDF, MODE_PSDF, MODE_MSDF, MODE_MTSDF, CHANNELS, EC_DISABLED, EC_INDISCRIMINATE, EC_EDGE_PRIORITY, EC_EDGE_ONLY,
-                  DO_NOT_CHECK_DISTANCE, CHECK_DISTANCE_AT_EDGE, ALWAYS_CHECK_DISTANCE, MsdfHipError)
+                  DO_NOT_CHECK_DISTANCE, CHECK_DISTANCE_AT_EDGE, ALWAYS_CHECK_DISTANCE, FILL_NONZERO, FILL_ODD, FILL_POSITIVE, FILL_NEGATIVE,
+                  MsdfHipError)
 from .shape import FlatShape, ShapeBatch, distance_mapping
 
 DEFAULT_MIN_DEVIATION_RATIO = 1.11111111111111111  # ErrorCorrectionConfig::defaultMinDeviationRatio (MSDFErrorCorrection.cpp:22)
@@ -111,6 +114,13 @@ def _c_config(config) -> _lib.Config:
     return cfg
 
 
+def _with_scanline_pass(cfg, scanline_pass, fill_rule, sdf_zero_value):
+    cfg.sign_correction = 1 if scanline_pass else 0
+    cfg.fill_rule = int(fill_rule)
+    cfg.sdf_zero_value = float(sdf_zero_value)
+    return cfg
+
+
 def _shape_args(shape: FlatShape):
     co = np.ascontiguousarray(shape.contour_offsets, np.int32)
     pts = np.ascontiguousarray(shape.points, np.float64)
@@ -183,6 +193,34 @@ def msdf_error_correction(sdf, shape, transformation, config: Optional[MSDFGener
                                             _lib.ptr(stencil, _lib._bp) if stencil is not None else None))
     del keep
     return sdf
+
+
+def distance_sign_correction(sdf, shape, projection, sdf_zero_value=.5, fill_rule=FILL_NONZERO, y_orientation=Y_UPWARD):
+    """distanceSignCorrection (core/rasterization.h:15-19), in place on a 1-, 3- or 4-channel bitmap. `projection` is a Projection
+    (or anything with one: SDFTransformation)."""
+    lib = _lib.load()
+    n = sdf.shape[2]
+    px, w, h, stride = _bitmap_args(sdf, n)
+    keep, sargs = _shape_args(shape)
+    proj = getattr(projection, "projection", projection)
+    xf = np.array([proj.scale[0], proj.scale[1], proj.translate[0], proj.translate[1], 1, 0], np.float64)
+    flip = int(bool(shape.inverse_y) != (y_orientation == Y_DOWNWARD))
+    _lib.check(lib.msdfhip_distance_sign_correction(n, px, w, h, stride, flip, *sargs, _lib.ptr(xf, _lib._dp), float(sdf_zero_value), int(fill_rule)))
+    del keep
+    return sdf
+
+
+def rasterize(output, shape, projection, fill_rule=FILL_NONZERO, y_orientation=Y_UPWARD):
+    """rasterize (core/rasterization.h:13): 1-channel coverage, 1.0 where the texel centre is inside under `fill_rule`."""
+    lib = _lib.load()
+    px, w, h, stride = _bitmap_args(output, 1)
+    keep, sargs = _shape_args(shape)
+    proj = getattr(projection, "projection", projection)
+    xf = np.array([proj.scale[0], proj.scale[1], proj.translate[0], proj.translate[1], 1, 0], np.float64)
+    flip = int(bool(shape.inverse_y) != (y_orientation == Y_DOWNWARD))
+    _lib.check(lib.msdfhip_rasterize(px, w, h, stride, flip, *sargs, _lib.ptr(xf, _lib._dp), int(fill_rule)))
+    del keep
+    return output
 
 
 def shape_distance(shape, selector, overlap_support, points):
@@ -287,9 +325,13 @@ class GlyphBatch:
         d["flip"] = (self.shapes.inverse_y.astype(bool) != (y_orientation == Y_DOWNWARD)).astype(np.int32)
         return self.torch.from_numpy(d.view(np.uint8).reshape(self.n_glyphs, 64)).to(self.device)
 
-    def generate(self, mode, width, height, xfs=None, config=None, out=None, stencil=None, descriptors=None, stream=None, y_orientation=Y_UPWARD):
+    def generate(self, mode, width, height, xfs=None, config=None, out=None, stencil=None, descriptors=None, stream=None, y_orientation=Y_UPWARD,
+                 scanline_pass=False, fill_rule=FILL_NONZERO, sdf_zero_value=.5):
         """Renders every glyph of the batch into its tile; returns the float32 device tensor (G, height, width, N).
-        Asynchronous on `stream` (torch.cuda.Stream) or torch's current stream."""
+        Asynchronous on `stream` (torch.cuda.Stream) or torch's current stream.
+        scanline_pass: run distanceSignCorrection(field, shape, projection, sdf_zero_value, fill_rule) between distance generation
+        and error correction, the order of the reference's -scanline flow (main.cpp:1281-1298) -- the field stays on the device.
+        The caller picks the configs that flow uses (overlap_support False, distance_check_mode DO_NOT_CHECK_DISTANCE)."""
         torch = self.torch
         n = CHANNELS[mode]
         if descriptors is None:
@@ -297,9 +339,11 @@ class GlyphBatch:
         if out is None:
             out = torch.empty((self.n_glyphs, height, width, n), dtype=torch.float32, device=self.device)
         cfg = _c_config(config if config is not None else (MSDFGeneratorConfig() if mode >= 3 else GeneratorConfig()))
+        _with_scanline_pass(cfg, scanline_pass, fill_rule, sdf_zero_value)
         scratch_ptr = None
-        if mode >= 3 and cfg.ec_mode != EC_DISABLED:
-            need = self.n_glyphs*height*width*n
+        stages = int(mode >= 3 and cfg.ec_mode != EC_DISABLED)+int(bool(scanline_pass))   # intermediate fields, msdfgen_hip.h
+        if stages:
+            need = stages*self.n_glyphs*height*width*n
             if self._scratch is None or self._scratch.numel() < need:
                 self._scratch = torch.empty(need, dtype=torch.float32, device=self.device)
             scratch_ptr = self._scratch.data_ptr()

@@ -328,6 +328,41 @@ int runCorrection(const MsdfHipBatch *b, int channels, int w, int h, const MsdfH
     return channels == 3 ? dispatchEc<3>(b, dGlyphs, w, h, src, out, stencil, cfg, stream) : dispatchEc<4>(b, dGlyphs, w, h, src, out, stencil, cfg, stream);
 }
 
+// distanceSignCorrection: src (packed tiles) -> out (packed if dstPacked, else the caller's bitmaps).
+template <int N>
+int launchSign(const MsdfHipBatch *b, int w, int h, const MsdfHipGlyph *dGlyphs, const float *src, float *out, int dstPacked, float zero, int fillRule,
+               int rasterizeOnly, hipStream_t stream) {
+    const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE, tiles = tilesX*tilesY;
+    const size_t blocks = (size_t) ((b->nGlyphs+7)/8)*8u*(size_t) tiles;
+    if (blocks > 0x7fffffffull)
+        return fail(MSDFHIP_ERR_INVALID, "launch of %zu tiles exceeds the grid limit; split the batch", blocks);
+    const size_t cap = 3*(size_t) (b->maxEdges > 0 ? b->maxEdges : 1);
+    const size_t lds = TILE*cap*(sizeof(double)+sizeof(int))+TILE*sizeof(int);   // per-row intersection lists
+    if (lds > (size_t) gLdsLimit.load())
+        return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d edges: the scanline lists need %zu B of LDS per wavefront, device limit is %d B",
+                    b->maxEdges, lds, gLdsLimit.load());
+    int rc = setLds(k_sign_correction<N>, lds);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    ScopedTimer timer(stream, 1);
+    hipLaunchKernelGGL((k_sign_correction<N>), dim3((unsigned) blocks), dim3(WAVE), lds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, b->maxEdges,
+                       src, out, dstPacked, zero, fillRule, rasterizeOnly);
+    HIPCHK(hipGetLastError());
+    return MSDFHIP_OK;
+}
+
+int runSignCorrection(const MsdfHipBatch *b, int channels, int w, int h, const MsdfHipGlyph *dGlyphs, const float *src, float *out, int dstPacked,
+                      float zero, int fillRule, hipStream_t stream) {
+    if (fillRule < 0 || fillRule > 3)
+        return fail(MSDFHIP_ERR_INVALID, "fill rule %d (must be 0..3)", fillRule);
+    switch (channels) {
+        case 1: return launchSign<1>(b, w, h, dGlyphs, src, out, dstPacked, zero, fillRule, src == NULL, stream);   // no source field: rasterize()
+        case 3: return launchSign<3>(b, w, h, dGlyphs, src, out, dstPacked, zero, fillRule, 0, stream);
+        case 4: return launchSign<4>(b, w, h, dGlyphs, src, out, dstPacked, zero, fillRule, 0, stream);
+    }
+    return fail(MSDFHIP_ERR_INVALID, "channels %d (must be 1, 3 or 4)", channels);
+}
+
 } // namespace
 
 extern "C" {
@@ -341,6 +376,10 @@ void msdfhip_default_config(MsdfHipConfig *cfg) {
     cfg->ec_stage_limit = 0;
     cfg->min_deviation_ratio = 1.11111111111111111;
     cfg->min_improve_ratio = 1.11111111111111111;
+    cfg->sign_correction = 0;
+    cfg->fill_rule = 0;                                          // FILL_NONZERO (core/rasterization.h:17)
+    cfg->sdf_zero_value = .5f;
+    cfg->reserved = 0;
 }
 
 int msdfhip_abi_version(void) { return MSDFHIP_ABI_VERSION; }
@@ -519,24 +558,33 @@ int msdfhip_batch_generate(const MsdfHipBatch *b, int mode, int w, int h, const 
     hipStream_t stream = (hipStream_t) streamPtr;
     const bool overlap = cfg->overlap_support != 0;
     const bool correct = mode >= 3 && cfg->ec_mode != MSDFHIP_EC_DISABLED; // msdf-error-correction.cpp:13-14
-    float *dst = dOut;
-    if (correct) {
-        if (!dScratch) {
-            rc = ensureScratch(b, (size_t) b->nGlyphs*w*h*channelsOf(mode), &dScratch);
-            if (rc != MSDFHIP_OK)
-                return rc;
-        }
-        dst = dScratch;
+    const bool signPass = cfg->sign_correction != 0;                       // main.cpp:1281-1298: generate -> sign correction -> error correction
+    // Intermediate fields (packed [g][h][w][N], native rows): stage A = distance field, stage B = sign-corrected field.
+    const int stages = (correct ? 1 : 0)+(signPass ? 1 : 0);
+    const size_t tileFloats = (size_t) b->nGlyphs*w*h*channelsOf(mode);
+    if (stages && !dScratch) {
+        rc = ensureScratch(b, tileFloats*stages, &dScratch);
+        if (rc != MSDFHIP_OK)
+            return rc;
     }
+    float *stageA = stages ? dScratch : NULL, *stageB = stages == 2 ? dScratch+tileFloats : NULL;
+    float *dst = stages ? stageA : dOut;
     switch (mode) {
-        case 1: rc = dispatchDistance<1>(b, dGlyphs, w, h, dst, 0, overlap, stream); break;
-        case 2: rc = dispatchDistance<2>(b, dGlyphs, w, h, dst, 0, overlap, stream); break;
-        case 3: rc = dispatchDistance<3>(b, dGlyphs, w, h, dst, correct, overlap, stream); break;
-        default: rc = dispatchDistance<4>(b, dGlyphs, w, h, dst, correct, overlap, stream); break;
+        case 1: rc = dispatchDistance<1>(b, dGlyphs, w, h, dst, stages != 0, overlap, stream); break;
+        case 2: rc = dispatchDistance<2>(b, dGlyphs, w, h, dst, stages != 0, overlap, stream); break;
+        case 3: rc = dispatchDistance<3>(b, dGlyphs, w, h, dst, stages != 0, overlap, stream); break;
+        default: rc = dispatchDistance<4>(b, dGlyphs, w, h, dst, stages != 0, overlap, stream); break;
     }
-    if (rc != MSDFHIP_OK || !correct)
+    if (rc != MSDFHIP_OK || !stages)
         return rc;
-    return runCorrection(b, channelsOf(mode), w, h, dGlyphs, dScratch, dOut, dStencil, *cfg, stream);
+    const float *ecSrc = stageA;
+    if (signPass) {
+        rc = runSignCorrection(b, channelsOf(mode), w, h, dGlyphs, stageA, correct ? stageB : dOut, correct ? 1 : 0, cfg->sdf_zero_value, cfg->fill_rule, stream);
+        if (rc != MSDFHIP_OK || !correct)
+            return rc;
+        ecSrc = stageB;
+    }
+    return runCorrection(b, channelsOf(mode), w, h, dGlyphs, ecSrc, dOut, dStencil, *cfg, stream);
 }
 
 int msdfhip_batch_generate_host(const MsdfHipBatch *b, int mode, int w, int h, const MsdfHipGlyph *glyphs, float *out, size_t outFloats,
@@ -616,7 +664,9 @@ struct Carver {                                                  // 256-byte ali
     size_t take(size_t bytes) { const size_t at = off; off += (bytes+255)/256*256; return at; }
 };
 
-static int singleShape(int mode, int channels, bool correctionOnly, float *pixels, int w, int h, int rowStride, int flip,
+enum SingleOp { OP_GENERATE = 0, OP_ERROR_CORRECTION = 1, OP_SIGN_CORRECTION = 2, OP_RASTERIZE = 3 };   // what the single-shape call does to `pixels`
+
+static int singleShape(int mode, int channels, int op, float *pixels, int w, int h, int rowStride, int flip,
                        const int32_t *co, int nC, const double *points, const uint8_t *types, const uint8_t *colors,
                        const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil) {
     if (w < 0 || h < 0 || nC < 0 || !co || !xf || (!pixels && w*h > 0))
@@ -626,7 +676,8 @@ static int singleShape(int mode, int channels, bool correctionOnly, float *pixel
         return rc;
     if (w == 0 || h == 0)
         return MSDFHIP_OK;
-    if (correctionOnly && cfg->ec_mode == MSDFHIP_EC_DISABLED)
+    const bool correctionOnly = op == OP_ERROR_CORRECTION || op == OP_SIGN_CORRECTION;   // the bitmap is an input as well
+    if (op == OP_ERROR_CORRECTION && cfg->ec_mode == MSDFHIP_EC_DISABLED)
         return MSDFHIP_OK;
     rc = ensureDevice();
     if (rc != MSDFHIP_OK)
@@ -640,7 +691,8 @@ static int singleShape(int mode, int channels, bool correctionOnly, float *pixel
     for (int e = 0; e < nE; ++e)
         if (types[e] < 1 || types[e] > 3)
             return fail(MSDFHIP_ERR_INVALID, "edge %d has type %d (must be 1, 2 or 3)", e, (int) types[e]);
-    const bool correct = channels >= 3 && cfg->ec_mode != MSDFHIP_EC_DISABLED;
+    const bool correct = op <= OP_ERROR_CORRECTION && channels >= 3 && cfg->ec_mode != MSDFHIP_EC_DISABLED;
+    const int stages = op == OP_GENERATE ? (correct ? 1 : 0)+(cfg->sign_correction ? 1 : 0) : 0;
     const size_t texels = (size_t) w*h, tileBytes = texels*channels*sizeof(float);
     const size_t eAlloc = nE > 0 ? nE : 1, cAlloc = nC > 0 ? nC : 1;
     const size_t candCap = texels/16 > 4096 ? texels/16 : 4096;
@@ -656,7 +708,7 @@ static int singleShape(int mode, int channels, bool correctionOnly, float *pixel
     // device layout: mirror of the staging area, then device-only work buffers
     Carver dc;
     dc.off = hc.off;
-    const size_t dRecs = dc.take(eAlloc*sizeof(EdgeRec)), dWind = dc.take(cAlloc), dScratch = dc.take(correct && !correctionOnly ? tileBytes : 0);
+    const size_t dRecs = dc.take(eAlloc*sizeof(EdgeRec)), dWind = dc.take(cAlloc), dScratch = dc.take(tileBytes*stages);
     const size_t dCands = dc.take(correct ? (candCap+1)*sizeof(EcCandidate) : 0), dParams = dc.take(sizeof(EcGlyphParams));
     ThreadArena &a = tlsArena;
     rc = arenaReserve(a, dc.off, hc.off);
@@ -702,10 +754,14 @@ static int singleShape(int mode, int channels, bool correctionOnly, float *pixel
 
     rc = digest(&b, a.stream);
     if (rc == MSDFHIP_OK) {
-        if (correctionOnly)
+        if (op == OP_ERROR_CORRECTION)
             rc = runCorrection(&b, channels, w, h, dGlyph, reinterpret_cast<const float *>(a.dev+hSrc), dOut, dStencil, *cfg, a.stream);
+        else if (op == OP_SIGN_CORRECTION)
+            rc = runSignCorrection(&b, channels, w, h, dGlyph, reinterpret_cast<const float *>(a.dev+hSrc), dOut, 0, cfg->sdf_zero_value, cfg->fill_rule, a.stream);
+        else if (op == OP_RASTERIZE)
+            rc = runSignCorrection(&b, 1, w, h, dGlyph, NULL, dOut, 0, 0.f, cfg->fill_rule, a.stream);
         else
-            rc = msdfhip_batch_generate(&b, mode, w, h, dGlyph, dOut, dStencil, correct ? reinterpret_cast<float *>(a.dev+dScratch) : NULL, cfg, a.stream);
+            rc = msdfhip_batch_generate(&b, mode, w, h, dGlyph, dOut, dStencil, stages ? reinterpret_cast<float *>(a.dev+dScratch) : NULL, cfg, a.stream);
     }
     if (rc != MSDFHIP_OK) {
         hipStreamSynchronize(a.stream);
@@ -725,7 +781,7 @@ int msdfhip_generate(int mode, float *pixels, int w, int h, int rowStride, int f
                      const uint8_t *types, const uint8_t *colors, const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil) {
     if (mode < 1 || mode > 4)
         return fail(MSDFHIP_ERR_INVALID, "mode %d (must be 1..4)", mode);
-    return singleShape(mode, channelsOf(mode), false, pixels, w, h, rowStride, flip, co, nC, points, types, colors, xf, cfg, stencil);
+    return singleShape(mode, channelsOf(mode), OP_GENERATE, pixels, w, h, rowStride, flip, co, nC, points, types, colors, xf, cfg, stencil);
 }
 
 int msdfhip_generate_sdf(float *pixels, int w, int h, int rowStride, int flip, const int32_t *co, int nC, const double *points,
@@ -752,7 +808,35 @@ int msdfhip_error_correction(int channels, float *pixels, int w, int h, int rowS
                              const uint8_t *types, const uint8_t *colors, const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil) {
     if (channels != 3 && channels != 4)
         return fail(MSDFHIP_ERR_INVALID, "channels %d (must be 3 or 4)", channels);
-    return singleShape(channels, channels, true, pixels, w, h, rowStride, flip, co, nC, points, types, colors, xf, cfg, stencil);
+    return singleShape(channels, channels, OP_ERROR_CORRECTION, pixels, w, h, rowStride, flip, co, nC, points, types, colors, xf, cfg, stencil);
+}
+
+int msdfhip_distance_sign_correction(int channels, float *pixels, int w, int h, int rowStride, int flip, const int32_t *co, int nC, const double *points,
+                                     const uint8_t *types, const uint8_t *colors, const double *xf, float zero, int fillRule) {
+    if (channels != 1 && channels != 3 && channels != 4)
+        return fail(MSDFHIP_ERR_INVALID, "channels %d (must be 1, 3 or 4)", channels);
+    if (fillRule < 0 || fillRule > 3)
+        return fail(MSDFHIP_ERR_INVALID, "fill rule %d (must be 0..3)", fillRule);
+    if (!xf)
+        return fail(MSDFHIP_ERR_INVALID, "xf is NULL");
+    MsdfHipConfig cfg;
+    msdfhip_default_config(&cfg);
+    cfg.sign_correction = 1, cfg.fill_rule = fillRule, cfg.sdf_zero_value = zero;
+    const double xf6[6] = { xf[0], xf[1], xf[2], xf[3], 1., 0. };  // the distance mapping plays no role here
+    return singleShape(channels, channels, OP_SIGN_CORRECTION, pixels, w, h, rowStride, flip, co, nC, points, types, colors, xf6, &cfg, NULL);
+}
+
+int msdfhip_rasterize(float *pixels, int w, int h, int rowStride, int flip, const int32_t *co, int nC, const double *points,
+                      const uint8_t *types, const uint8_t *colors, const double *xf, int fillRule) {
+    if (fillRule < 0 || fillRule > 3)
+        return fail(MSDFHIP_ERR_INVALID, "fill rule %d (must be 0..3)", fillRule);
+    if (!xf)
+        return fail(MSDFHIP_ERR_INVALID, "xf is NULL");
+    MsdfHipConfig cfg;
+    msdfhip_default_config(&cfg);
+    cfg.fill_rule = fillRule;
+    const double xf6[6] = { xf[0], xf[1], xf[2], xf[3], 1., 0. };
+    return singleShape(1, 1, OP_RASTERIZE, pixels, w, h, rowStride, flip, co, nC, points, types, colors, xf6, &cfg, NULL);
 }
 
 int msdfhip_shape_distance(int selector, int overlap, const int32_t *co, int nC, const double *points, const uint8_t *types, const uint8_t *colors,

@@ -21,6 +21,7 @@
 #include "msdf_ec.hpp"
 #include "msdf_ec_fast.hpp"
 #include "msdf_cull.hpp"
+#include "msdf_scanline.hpp"
 #include "../../include/msdfgen_hip.h"
 
 namespace msdfhip {
@@ -488,6 +489,123 @@ k_ec_slow(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, co
         if (stencilOut)
             stencilOut[texel] = (uint8_t) st;
     }
+}
+
+// ------------------------------------------------------------------------------------------- distance sign correction
+
+// distanceSignCorrection (core/rasterization.cpp:19-88) for one 8x8 tile per wavefront; src -> out (distinct buffers).
+// Phase 1 (lanes = (row, edge) tasks): intersections of every edge with the tile's 8 texel rows, appended per row in LDS
+// (order is irrelevant: the fill test is a sum). Phase 2 (lanes = texels): fill bit = fill rule of the sum of directions left of
+// the texel centre; flip the distances whose sign disagrees. Texels whose median equals the zero value exactly take the
+// reference's neighbour vote (:69-88); the two vertical neighbours' fill bits are then evaluated directly from the records.
+// src: packed [g][h][w][N] native rows. dstPacked != 0: out is packed the same way (a further pass follows), else the caller's bitmap.
+// LDS: [8][cap] doubles (x) + [8][cap] ints (direction) + 8 counters, cap = 3*maxEdges.
+template <int N>
+__global__ void __launch_bounds__(WAVE)
+k_sign_correction(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges,
+                  const float *src, float *out, int dstPacked, float zero, int fillRule, int rasterizeOnly) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const GlyphWork wk = decodeBlock(batch.nGlyphs, tilesPerGlyph);
+    if (!wk.valid)
+        return;
+    const int c0 = batch.glyphContourOffsets[wk.g], C = batch.glyphContourOffsets[wk.g+1]-c0;
+    const int32_t *coff = batch.contourOffsets+c0;
+    const int e0 = coff[0], nE = coff[C]-e0;
+    const EdgeRec *rec = batch.recs+e0;
+    const int lane = threadIdx.x;
+    const int cap = 3*(maxEdges > 0 ? maxEdges : 1);
+    double *rowX = smem;                                            // [8][cap]
+    int *rowDir = reinterpret_cast<int *>(rowX+(size_t) TILE*cap);  // [8][cap]
+    int *rowCount = rowDir+(size_t) TILE*cap;                       // [8]
+    const MsdfHipGlyph gd = glyphs[wk.g];
+    const Xform t = loadXform(gd);
+    const int tx = wk.tile%tilesX, ty = wk.tile/tilesX;
+
+    if (lane < TILE)
+        rowCount[lane] = 0;
+    waveSync();
+    for (int task = lane; task < TILE*nE; task += WAVE) {           // phase 1
+        const int r = task&(TILE-1), e = task>>3;
+        const int ys = ty*TILE+r;
+        if (ys >= height)
+            continue;
+        const double y = (ys+.5)/t.sy-t.ty;                          // projection.unprojectY(y+.5), Projection.cpp:38-40
+        if (!rowMayIntersect(rec[e], y))
+            continue;
+        double x[3];
+        int dy[3];
+        const int n = scanlineIntersections(rec[e], x, dy, y);
+        if (n > 0) {
+            const int slot = atomicAdd(&rowCount[r], n);
+            for (int k = 0; k < 3; ++k)
+                if (k < n) {
+                    rowX[(size_t) r*cap+slot+k] = x[k];
+                    rowDir[(size_t) r*cap+slot+k] = dy[k];
+                }
+        }
+    }
+    waveSync();
+
+    const int lx = lane&(TILE-1), ly = lane>>3;
+    const int x = tx*TILE+lx, ys = ty*TILE+ly;                      // shape orientation (sdf.reorient, rasterization.cpp:39)
+    if (x >= width || ys >= height)
+        return;
+    const int cnt = rowCount[ly];
+    // fill bits of this texel and of its left / right neighbours (same row list)
+    const double px = (x+.5)/t.sx-t.tx, pxl = (x-.5)/t.sx-t.tx, pxr = (x+1.5)/t.sx-t.tx;   // projection.unprojectX(x+.5)
+    int sum = 0, sumL = 0, sumR = 0;
+    for (int i = 0; i < cnt; ++i) {
+        const double xi = rowX[(size_t) ly*cap+i];
+        const int d = rowDir[(size_t) ly*cap+i];
+        if (px >= xi) sum += d;
+        if (pxl >= xi) sumL += d;
+        if (pxr >= xi) sumR += d;
+    }
+    const bool fill = interpretFillRule(sum, fillRule);
+    const int yn = gd.flip ? height-1-ys : ys;
+    const float *tile = src+(size_t) wk.g*height*width*N;
+    const float *in = tile+((size_t) yn*width+x)*N;
+    const float twice = zero+zero;
+    float v[N];
+    if (rasterizeOnly) {                                            // rasterize(), rasterization.cpp:8-16 (N == 1)
+        for (int i = 0; i < N; ++i)
+            v[i] = (float) fill;
+    } else {
+        for (int i = 0; i < N; ++i)
+            v[i] = in[i];
+    }
+    if (rasterizeOnly) {
+    } else if (N == 1) {                                            // :19-33
+        if ((v[0] > zero) != fill)
+            v[0] = twice-v[0];
+    } else {                                                        // :35-88
+        const int match = signMatch(v, fill, zero);
+        bool flipRgb = match < 0;
+        if (match == 0) {                                           // ambiguous texel: neighbour vote (:69-86)
+            int vote = 0;
+            if (x > 0)
+                vote += signMatch(tile+((size_t) yn*width+x-1)*N, interpretFillRule(sumL, fillRule), zero);
+            if (x < width-1)
+                vote += signMatch(tile+((size_t) yn*width+x+1)*N, interpretFillRule(sumR, fillRule), zero);
+            if (ys > 0) {
+                const int ynb = gd.flip ? height-1-(ys-1) : ys-1;
+                vote += signMatch(tile+((size_t) ynb*width+x)*N, filledDirect(rec, nE, px, (ys-.5)/t.sy-t.ty, fillRule), zero);
+            }
+            if (ys < height-1) {
+                const int ynb = gd.flip ? height-1-(ys+1) : ys+1;
+                vote += signMatch(tile+((size_t) ynb*width+x)*N, filledDirect(rec, nE, px, (ys+1.5)/t.sy-t.ty, fillRule), zero);
+            }
+            flipRgb = vote < 0;
+        }
+        if (flipRgb)
+            v[0] = twice-v[0], v[1] = twice-v[1], v[2] = twice-v[2];
+        if (N >= 4 && (v[N >= 4 ? 3 : 0] > zero) != fill)
+            v[N >= 4 ? 3 : 0] = twice-v[N >= 4 ? 3 : 0];
+    }
+    float *px_ = dstPacked ? out+(((size_t) wk.g*height+yn)*width+x)*N
+                           : out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
+    for (int i = 0; i < N; ++i)
+        px_[i] = v[i];
 }
 
 // ------------------------------------------------------------------------------------------------- distance queries

@@ -12,6 +12,7 @@ MODE_SDF, MODE_PSDF, MODE_MSDF, MODE_MTSDF = 1, 2, 3, 4
 CHANNELS = {1: 1, 2: 1, 3: 3, 4: 4}
 EC_DISABLED, EC_INDISCRIMINATE, EC_EDGE_PRIORITY, EC_EDGE_ONLY = 0, 1, 2, 3
 DO_NOT_CHECK_DISTANCE, CHECK_DISTANCE_AT_EDGE, ALWAYS_CHECK_DISTANCE = 0, 1, 2
+FILL_NONZERO, FILL_ODD, FILL_POSITIVE, FILL_NEGATIVE = 0, 1, 2, 3
 ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_TOO_COMPLEX, ERR_NOMEM = -1, -2, -3, -4, -5
 
 _dp = C.POINTER(C.c_double)
@@ -30,7 +31,8 @@ class MsdfHipError(RuntimeError):
 class Config(C.Structure):
     """MsdfHipConfig == MSDFGeneratorConfig + ErrorCorrectionConfig (core/generator-config.h:13-64)."""
     _fields_ = [("overlap_support", C.c_int32), ("ec_mode", C.c_int32), ("ec_distance_check", C.c_int32), ("ec_stage_limit", C.c_int32),
-                ("min_deviation_ratio", C.c_double), ("min_improve_ratio", C.c_double)]
+                ("min_deviation_ratio", C.c_double), ("min_improve_ratio", C.c_double),
+                ("sign_correction", C.c_int32), ("fill_rule", C.c_int32), ("sdf_zero_value", C.c_float), ("reserved", C.c_int32)]
 
 
 class Glyph(C.Structure):
@@ -55,6 +57,8 @@ _PROTOS = {
     "msdfhip_generate_msdf": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int] + _SHAPE_ARGS + [_dp, C.POINTER(Config), _bp]),
     "msdfhip_generate_mtsdf": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int] + _SHAPE_ARGS + [_dp, C.POINTER(Config), _bp]),
     "msdfhip_error_correction": (C.c_int, [C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int] + _SHAPE_ARGS + [_dp, C.POINTER(Config), _bp]),
+    "msdfhip_distance_sign_correction": (C.c_int, [C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int] + _SHAPE_ARGS + [_dp, C.c_float, C.c_int]),
+    "msdfhip_rasterize": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int] + _SHAPE_ARGS + [_dp, C.c_int]),
     "msdfhip_shape_distance": (C.c_int, [C.c_int, C.c_int] + _SHAPE_ARGS + [C.c_int, _dp, _dp]),
     "msdfhip_batch_create": (C.c_int, [C.POINTER(_vp), C.c_int, _ip, _ip, _dp, _bp, _bp]),
     "msdfhip_batch_create_device": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -99,7 +103,7 @@ def load(build_if_missing=True):
             fn = getattr(lib, name)  # AttributeError here == a symbol of include/msdfgen_hip.h is missing from the library
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.msdfhip_abi_version() != 1:
+        if lib.msdfhip_abi_version() != 2:
             raise MsdfHipError(ERR_INVALID, "ABI version mismatch")
         _lib = lib
         return lib

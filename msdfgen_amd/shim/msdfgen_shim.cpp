@@ -1,8 +1,10 @@
-// msdfgen_shim.cpp -- C++ drop-in: msdfgen's OWN generator signatures (msdfgen.h:46-69, core/msdf-error-correction.h:15-18),
+// msdfgen_shim.cpp -- C++ drop-in: msdfgen's OWN generator signatures (msdfgen.h:46-69, core/msdf-error-correction.h:15-18,
+// core/rasterization.h:13-27),
 // implemented on the MI355X through the C ABI of libmsdfgen_hip.so.
 //
 // Build against the user's msdfgen checkout (headers only; this file includes <msdfgen.h>) and link it INSTEAD of the reference's
-// definitions of the same functions (core/msdfgen.cpp:78-162, core/msdf-error-correction.cpp:61-72) -- see INTEGRATION.md.
+// definitions of the same functions (core/msdfgen.cpp:78-162, core/msdf-error-correction.cpp:61-72, core/rasterization.cpp) -- see
+// INTEGRATION.md.
 // Callers such as msdf-atlas-gen's glyph generators then run the HIP path unchanged.
 //
 // Differences from the reference that a caller can observe: none in the texels (see tests); the functions can now fail (no
@@ -114,6 +116,19 @@ void correct(const BitmapSection<float, N> &sdf, const Shape &shape, const SDFTr
           "msdfErrorCorrection");
 }
 
+template <int N>
+void signCorrect(const BitmapSection<float, N> &sdf, const Shape &shape, const Projection &projection, float sdfZeroValue, FillRule fillRule) {
+    FlatShape flat;
+    flatten(shape, flat);
+    const Vector2 one = projection.projectVector(Vector2(1, 1)), origin = projection.unproject(Point2(0, 0));
+    const double xf[6] = { one.x, one.y, -origin.x, -origin.y, 1, 0 };       // scale, translate (Projection.cpp:12-36)
+    const int flip = shape.getYAxisOrientation() != sdf.yOrientation;        // sdf.reorient(...), rasterization.cpp:22,39
+    check(msdfhip_distance_sign_correction(N, sdf.pixels, sdf.width, sdf.height, sdf.rowStride, flip, flat.contourOffsets.data(),
+                                           (int) shape.contours.size(), flat.points.data(), flat.types.data(), flat.colors.data(), xf,
+                                           sdfZeroValue, (int) fillRule),
+          "distanceSignCorrection");
+}
+
 }
 
 // ---- msdfgen.h:46-53
@@ -176,6 +191,48 @@ void msdfErrorCorrection(const BitmapSection<float, 3> &sdf, const Shape &shape,
 }
 void msdfErrorCorrection(const BitmapSection<float, 4> &sdf, const Shape &shape, const Projection &projection, Range range, const MSDFGeneratorConfig &config) {
     correct<4>(sdf, shape, SDFTransformation(projection, range), config);
+}
+
+// ---- core/rasterization.h:13-27: together these replace the whole of core/rasterization.cpp
+void rasterize(BitmapSection<float, 1> output, const Shape &shape, const Projection &projection, FillRule fillRule) {
+    FlatShape flat;
+    flatten(shape, flat);
+    const Vector2 one = projection.projectVector(Vector2(1, 1)), origin = projection.unproject(Point2(0, 0));
+    const double xf[6] = { one.x, one.y, -origin.x, -origin.y, 1, 0 };
+    const int flip = shape.getYAxisOrientation() != output.yOrientation;     // output.reorient(...), rasterization.cpp:9
+    check(msdfhip_rasterize(output.pixels, output.width, output.height, output.rowStride, flip, flat.contourOffsets.data(), (int) shape.contours.size(),
+                            flat.points.data(), flat.types.data(), flat.colors.data(), xf, (int) fillRule),
+          "rasterize");
+}
+void rasterize(const BitmapSection<float, 1> &output, const Shape &shape, const Vector2 &scale, const Vector2 &translate, FillRule fillRule) {
+    rasterize(output, shape, Projection(scale, translate), fillRule);
+}
+void distanceSignCorrection(BitmapSection<float, 1> sdf, const Shape &shape, const Projection &projection, float sdfZeroValue, FillRule fillRule) {
+    signCorrect<1>(sdf, shape, projection, sdfZeroValue, fillRule);
+}
+void distanceSignCorrection(BitmapSection<float, 3> sdf, const Shape &shape, const Projection &projection, float sdfZeroValue, FillRule fillRule) {
+    signCorrect<3>(sdf, shape, projection, sdfZeroValue, fillRule);
+}
+void distanceSignCorrection(BitmapSection<float, 4> sdf, const Shape &shape, const Projection &projection, float sdfZeroValue, FillRule fillRule) {
+    signCorrect<4>(sdf, shape, projection, sdfZeroValue, fillRule);
+}
+void distanceSignCorrection(BitmapSection<float, 1> sdf, const Shape &shape, const Projection &projection, FillRule fillRule) {
+    signCorrect<1>(sdf, shape, projection, .5f, fillRule);
+}
+void distanceSignCorrection(BitmapSection<float, 3> sdf, const Shape &shape, const Projection &projection, FillRule fillRule) {
+    signCorrect<3>(sdf, shape, projection, .5f, fillRule);
+}
+void distanceSignCorrection(BitmapSection<float, 4> sdf, const Shape &shape, const Projection &projection, FillRule fillRule) {
+    signCorrect<4>(sdf, shape, projection, .5f, fillRule);
+}
+void distanceSignCorrection(const BitmapSection<float, 1> &sdf, const Shape &shape, const Vector2 &scale, const Vector2 &translate, FillRule fillRule) {
+    signCorrect<1>(sdf, shape, Projection(scale, translate), .5f, fillRule);
+}
+void distanceSignCorrection(const BitmapSection<float, 3> &sdf, const Shape &shape, const Vector2 &scale, const Vector2 &translate, FillRule fillRule) {
+    signCorrect<3>(sdf, shape, Projection(scale, translate), .5f, fillRule);
+}
+void distanceSignCorrection(const BitmapSection<float, 4> &sdf, const Shape &shape, const Vector2 &scale, const Vector2 &translate, FillRule fillRule) {
+    signCorrect<4>(sdf, shape, Projection(scale, translate), .5f, fillRule);
 }
 
 }

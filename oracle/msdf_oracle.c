@@ -1229,6 +1229,275 @@ void orc_ec_stages(const orc_shape *shape, int channels, const float *pixels, in
     free(buf);
 }
 
+/* ------------------------------------------------------------------------ scanline fill / distanceSignCorrection */
+
+static int scan_linear(const v2 *p, double *x, int *dy, double y) {                /* edge-segments.cpp:279-287 */
+    if ((y >= p[0].y && y < p[1].y) || (y >= p[1].y && y < p[0].y)) {
+        double param = (y-p[0].y)/(p[1].y-p[0].y);
+        x[0] = (1.-param)*p[0].x+param*p[1].x;                                    /* mix(p0.x, p1.x, param), arithmetics.hpp:27-31 */
+        dy[0] = isign(p[1].y-p[0].y);
+        return 1;
+    }
+    return 0;
+}
+
+static int scan_quadratic(const v2 *p, double *x, int *dy, double y) {             /* edge-segments.cpp:289-341 */
+    int total = 0;
+    int nextDY = y > p[0].y ? 1 : -1;
+    x[total] = p[0].x;
+    if (p[0].y == y) {
+        if (p[0].y < p[1].y || (p[0].y == p[1].y && p[0].y < p[2].y))
+            dy[total++] = 1;
+        else
+            nextDY = 1;
+    }
+    {
+        v2 ab = vsub(p[1], p[0]);
+        v2 br = vsub(vsub(p[2], p[1]), ab);
+        double t[2];
+        int solutions = orc_solve_quadratic(t, br.y, 2*ab.y, p[0].y-y);
+        double tmp;
+        if (solutions >= 2 && t[0] > t[1])
+            tmp = t[0], t[0] = t[1], t[1] = tmp;
+        for (int i = 0; i < solutions && total < 2; ++i) {
+            if (t[i] >= 0 && t[i] <= 1) {
+                x[total] = p[0].x+2*t[i]*ab.x+t[i]*t[i]*br.x;
+                if (nextDY*(ab.y+t[i]*br.y) >= 0) {
+                    dy[total++] = nextDY;
+                    nextDY = -nextDY;
+                }
+            }
+        }
+    }
+    if (p[2].y == y) {
+        if (nextDY > 0 && total > 0) {
+            --total;
+            nextDY = -1;
+        }
+        if ((p[2].y < p[1].y || (p[2].y == p[1].y && p[2].y < p[0].y)) && total < 2) {
+            x[total] = p[2].x;
+            if (nextDY < 0) {
+                dy[total++] = -1;
+                nextDY = 1;
+            }
+        }
+    }
+    if (nextDY != (y >= p[2].y ? 1 : -1)) {
+        if (total > 0)
+            --total;
+        else {
+            if (fabs(p[2].y-y) < fabs(p[0].y-y))
+                x[total] = p[2].x;
+            dy[total++] = nextDY;
+        }
+    }
+    return total;
+}
+
+static int scan_cubic(const v2 *p, double *x, int *dy, double y) {                 /* edge-segments.cpp:343-403 */
+    int total = 0;
+    int nextDY = y > p[0].y ? 1 : -1;
+    x[total] = p[0].x;
+    if (p[0].y == y) {
+        if (p[0].y < p[1].y || (p[0].y == p[1].y && (p[0].y < p[2].y || (p[0].y == p[2].y && p[0].y < p[3].y))))
+            dy[total++] = 1;
+        else
+            nextDY = 1;
+    }
+    {
+        v2 ab = vsub(p[1], p[0]);
+        v2 br = vsub(vsub(p[2], p[1]), ab);
+        v2 as = vsub(vsub(vsub(p[3], p[2]), vsub(p[2], p[1])), br);
+        double t[3];
+        int solutions = orc_solve_cubic(t, as.y, 3*br.y, 3*ab.y, p[0].y-y);
+        double tmp;
+        if (solutions >= 2) {
+            if (t[0] > t[1])
+                tmp = t[0], t[0] = t[1], t[1] = tmp;
+            if (solutions >= 3 && t[1] > t[2]) {
+                tmp = t[1], t[1] = t[2], t[2] = tmp;
+                if (t[0] > t[1])
+                    tmp = t[0], t[0] = t[1], t[1] = tmp;
+            }
+        }
+        for (int i = 0; i < solutions && total < 3; ++i) {
+            if (t[i] >= 0 && t[i] <= 1) {
+                x[total] = p[0].x+3*t[i]*ab.x+3*t[i]*t[i]*br.x+t[i]*t[i]*t[i]*as.x;
+                if (nextDY*(ab.y+2*t[i]*br.y+t[i]*t[i]*as.y) >= 0) {
+                    dy[total++] = nextDY;
+                    nextDY = -nextDY;
+                }
+            }
+        }
+    }
+    if (p[3].y == y) {
+        if (nextDY > 0 && total > 0) {
+            --total;
+            nextDY = -1;
+        }
+        if ((p[3].y < p[2].y || (p[3].y == p[2].y && (p[3].y < p[1].y || (p[3].y == p[1].y && p[3].y < p[0].y)))) && total < 3) {
+            x[total] = p[3].x;
+            if (nextDY < 0) {
+                dy[total++] = -1;
+                nextDY = 1;
+            }
+        }
+    }
+    if (nextDY != (y >= p[3].y ? 1 : -1)) {
+        if (total > 0)
+            --total;
+        else {
+            if (fabs(p[3].y-y) < fabs(p[0].y-y))
+                x[total] = p[3].x;
+            dy[total++] = nextDY;
+        }
+    }
+    return total;
+}
+
+static int edge_scanline(const edge_t *e, double *x, int *dy, double y) {
+    switch (e->type) {
+        case 1: return scan_linear(e->p, x, dy, y);
+        case 2: return scan_quadratic(e->p, x, dy, y);
+        default: return scan_cubic(e->p, x, dy, y);
+    }
+}
+
+int orc_scanline_intersections(int type, const double *p, double y, double *x, int32_t *dy) {
+    edge_t e;
+    e.type = type, e.color = 7;
+    for (int i = 0; i < 4; ++i)
+        e.p[i] = V(p[2*i], p[2*i+1]);
+    int d[3] = { 0, 0, 0 };
+    int n = edge_scanline(&e, x, d, y);
+    for (int i = 0; i < 3; ++i)
+        dy[i] = d[i];
+    return n;
+}
+
+static int interpret_fill_rule(int intersections, int rule) {                    /* Scanline.cpp:13-25 */
+    switch (rule) {
+        case 0: return intersections != 0;
+        case 1: return intersections&1;
+        case 2: return intersections > 0;
+        case 3: return intersections < 0;
+    }
+    return 0;
+}
+
+typedef struct { double *x; int *dir; int n, cap; } scanline_t;
+
+/* Shape::scanline (Shape.cpp:117-135). The reference sorts the intersections and prefix-sums the directions (Scanline.cpp:66-77);
+ * filled(x) (Scanline.cpp:120-122) then reads the sum over all intersections with x_i <= x, which needs no ordering. */
+static void shape_scanline(const orc_shape *s, scanline_t *line, double y) {
+    int nE = s->contour_offsets[s->n_contours];
+    line->n = 0;
+    for (int e = 0; e < nE; ++e) {
+        edge_t edge = load_edge(s, e);
+        double x[3];
+        int dy[3];
+        int n = edge_scanline(&edge, x, dy, y);
+        for (int i = 0; i < n; ++i) {
+            line->x[line->n] = x[i];
+            line->dir[line->n++] = dy[i];
+        }
+    }
+}
+
+static int scanline_filled(const scanline_t *line, double x, int rule) {
+    int sum = 0;
+    for (int i = 0; i < line->n; ++i)
+        if (x >= line->x[i])
+            sum += line->dir[i];
+    return interpret_fill_rule(sum, rule);
+}
+
+void orc_rasterize(const orc_shape *shape, float *pixels, int w, int h, int row_stride, int y_down, const double *xf4, int fillRule) {
+    fsection out;                                                                /* rasterization.cpp:8-16 */
+    out.pixels = pixels, out.width = w, out.height = h, out.rowStride = row_stride, out.yDown = y_down, out.N = 1;
+    freorient(&out, shape->inverse_y);
+    int nE = shape->contour_offsets[shape->n_contours];
+    scanline_t line;
+    line.cap = 3*nE+1;
+    line.x = (double *) malloc(sizeof(double)*(size_t) line.cap);
+    line.dir = (int *) malloc(sizeof(int)*(size_t) line.cap);
+    for (int y = 0; y < h; ++y) {
+        shape_scanline(shape, &line, (y+.5)/xf4[1]-xf4[3]);
+        for (int x = 0; x < w; ++x)
+            *fpx(&out, x, y) = (float) scanline_filled(&line, (x+.5)/xf4[0]-xf4[2], fillRule);
+    }
+    free(line.x);
+    free(line.dir);
+}
+
+void orc_sign_correction(const orc_shape *shape, int channels, float *pixels, int w, int h, int row_stride, int y_down, const double *xf4,
+                         float sdfZeroValue, int fillRule) {                   /* rasterization.cpp:19-88 */
+    if (!(w && h))
+        return;
+    fsection sdf;
+    sdf.pixels = pixels, sdf.width = w, sdf.height = h, sdf.rowStride = row_stride, sdf.yDown = y_down, sdf.N = channels;
+    freorient(&sdf, shape->inverse_y);
+    xform t;
+    t.scale = V(xf4[0], xf4[1]), t.translate = V(xf4[2], xf4[3]), t.mapScale = 1, t.mapTranslate = 0;
+    float doubleSdfZeroValue = sdfZeroValue+sdfZeroValue;
+    int nE = shape->contour_offsets[shape->n_contours];
+    scanline_t line;
+    line.cap = 3*nE+1;
+    line.x = (double *) malloc(sizeof(double)*(size_t) line.cap);
+    line.dir = (int *) malloc(sizeof(int)*(size_t) line.cap);
+    char *matchMap = (char *) calloc((size_t) w*h+1, 1);
+    int ambiguous = 0;
+    char *match = matchMap;
+    for (int y = 0; y < h; ++y) {
+        shape_scanline(shape, &line, (y+.5)/t.scale.y-t.translate.y);             /* projection.unprojectY(y+.5), Projection.cpp:38-40 */
+        for (int x = 0; x < w; ++x) {
+            int fill = scanline_filled(&line, (x+.5)/t.scale.x-t.translate.x, fillRule);
+            float *msd = fpx(&sdf, x, y);
+            if (channels == 1) {                                                 /* :19-33 */
+                if ((msd[0] > sdfZeroValue) != fill)
+                    msd[0] = doubleSdfZeroValue-msd[0];
+            } else {                                                             /* :35-88 */
+                float sd = fmedian(msd[0], msd[1], msd[2]);
+                if (sd == sdfZeroValue)
+                    ambiguous = 1;
+                else if ((sd > sdfZeroValue) != fill) {
+                    msd[0] = doubleSdfZeroValue-msd[0];
+                    msd[1] = doubleSdfZeroValue-msd[1];
+                    msd[2] = doubleSdfZeroValue-msd[2];
+                    *match = -1;
+                } else
+                    *match = 1;
+                if (channels >= 4 && (msd[3] > sdfZeroValue) != fill)
+                    msd[3] = doubleSdfZeroValue-msd[3];
+            }
+            ++match;
+        }
+    }
+    if (ambiguous) {
+        match = matchMap;
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                if (!*match) {
+                    int neighborMatch = 0;
+                    if (x > 0) neighborMatch += *(match-1);
+                    if (x < w-1) neighborMatch += *(match+1);
+                    if (y > 0) neighborMatch += *(match-w);
+                    if (y < h-1) neighborMatch += *(match+w);
+                    if (neighborMatch < 0) {
+                        float *msd = fpx(&sdf, x, y);
+                        msd[0] = doubleSdfZeroValue-msd[0];
+                        msd[1] = doubleSdfZeroValue-msd[1];
+                        msd[2] = doubleSdfZeroValue-msd[2];
+                    }
+                }
+                ++match;
+            }
+    }
+    free(matchMap);
+    free(line.x);
+    free(line.dir);
+}
+
 /* ---------------------------------------------------------------------------------------- CPU baseline helper */
 
 typedef struct {

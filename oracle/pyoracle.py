@@ -160,6 +160,35 @@ class Oracle:
         self.lib.orc_ec_stages(C.byref(s), n, _p(px, _fp), w, h, _p(xf, _dp), int(overlap), min_dev, min_imp, _p(stages, _bp))
         return stages
 
+    def sign_correction(self, shape, pixels, xf, zero=.5, fill_rule=0, y_down=False):
+        """distanceSignCorrection (core/rasterization.h:17-19) on a copy of `pixels` (h, w, N)."""
+        f = _flat(shape)
+        px = np.array(pixels, np.float32, order="C")
+        h, w, n = px.shape
+        x4 = _arr(np.asarray(xf, np.float64).reshape(-1)[:4], np.float64)
+        s = f.orc()
+        self.lib.orc_sign_correction.argtypes = [C.POINTER(_OrcShape), C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_float, C.c_int]
+        self.lib.orc_sign_correction(C.byref(s), n, _p(px, _fp), w, h, w*n, int(y_down), _p(x4, _dp), C.c_float(zero), fill_rule)
+        return px
+
+    def rasterize(self, shape, w, h, xf, fill_rule=0, y_down=False):
+        """rasterize (core/rasterization.h:13): (h, w, 1) coverage."""
+        f = _flat(shape)
+        px = np.zeros((h, w, 1), np.float32)
+        x4 = _arr(np.asarray(xf, np.float64).reshape(-1)[:4], np.float64)
+        s = f.orc()
+        self.lib.orc_rasterize.argtypes = [C.POINTER(_OrcShape), _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int]
+        self.lib.orc_rasterize(C.byref(s), _p(px, _fp), w, h, w, int(y_down), _p(x4, _dp), fill_rule)
+        return px
+
+    def scanline_intersections(self, type_, pts8, y):
+        p = _arr(pts8, np.float64)
+        x = np.zeros(3)
+        dy = np.zeros(3, np.int32)
+        self.lib.orc_scanline_intersections.argtypes = [C.c_int, _dp, C.c_double, _dp, _ip]
+        n = self.lib.orc_scanline_intersections(type_, _p(p, _dp), y, _p(x, _dp), _p(dy, _ip))
+        return n, x[:n], dy[:n]
+
     def generate_batch_timed(self, shapes, mode, w, h, xfs, overlap=True, ec_mode=EC_EDGE_PRIORITY, ec_dist=DC_CHECK_AT_EDGE,
                              min_dev=DEFAULT_RATIO, min_imp=DEFAULT_RATIO, threads=1):
         flats = [_flat(s) for s in shapes]
@@ -328,6 +357,37 @@ class Ref:
         if own:
             self.free(hd)
         return out
+
+    def sign_correction(self, shape, pixels, xf, zero=.5, fill_rule=0, y_down=False):
+        """distanceSignCorrection (core/rasterization.h:17-19) on a copy of `pixels` (h, w, N)."""
+        hd, own = self._handle(shape)
+        px = np.array(pixels, np.float32, order="C")
+        h, w, n = px.shape
+        x4 = _arr(np.asarray(xf, np.float64).reshape(-1)[:4], np.float64)
+        self.lib.ref_sign_correction.argtypes = [C.c_void_p, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_float, C.c_int]
+        self.lib.ref_sign_correction(hd, n, _p(px, _fp), w, h, w*n, int(y_down), _p(x4, _dp), C.c_float(zero), fill_rule)
+        if own:
+            self.free(hd)
+        return px
+
+    def rasterize(self, shape, w, h, xf, fill_rule=0, y_down=False):
+        """rasterize (core/rasterization.h:13): (h, w, 1) coverage."""
+        hd, own = self._handle(shape)
+        px = np.zeros((h, w, 1), np.float32)
+        x4 = _arr(np.asarray(xf, np.float64).reshape(-1)[:4], np.float64)
+        self.lib.ref_rasterize.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int]
+        self.lib.ref_rasterize(hd, _p(px, _fp), w, h, w, int(y_down), _p(x4, _dp), fill_rule)
+        if own:
+            self.free(hd)
+        return px
+
+    def scanline_intersections(self, type_, pts8, y):
+        p = _arr(pts8, np.float64)
+        x = np.zeros(3)
+        dy = np.zeros(3, np.int32)
+        self.lib.ref_scanline_intersections.argtypes = [C.c_int, _dp, C.c_double, _dp, _ip]
+        n = self.lib.ref_scanline_intersections(type_, _p(p, _dp), y, _p(x, _dp), _p(dy, _ip))
+        return n, x[:n], dy[:n]
 
     def generate_batch_timed(self, shapes, mode, w, h, xfs, overlap=True, ec_mode=EC_EDGE_PRIORITY, ec_dist=DC_CHECK_AT_EDGE,
                              min_dev=DEFAULT_RATIO, min_imp=DEFAULT_RATIO, threads=1):

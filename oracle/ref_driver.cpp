@@ -190,6 +190,38 @@ void ref_ec_stages(void *s, int channels, const float *pixels, int w, int h, con
     memcpy(stages+3*n, buf.data(), n);
 }
 
+/// distanceSignCorrection (core/rasterization.cpp:19-88; declared core/rasterization.h:17-19), in place. xf = {sx, sy, tx, ty}.
+void ref_sign_correction(void *s, int channels, float *pixels, int w, int h, int rowStride, int yDown, const double *xf, float sdfZeroValue, int fillRule) {
+    const Shape &shape = *(Shape *) s;
+    Projection proj(Vector2(xf[0], xf[1]), Vector2(xf[2], xf[3]));
+    YAxisOrientation yo = yDown ? Y_DOWNWARD : Y_UPWARD;
+    switch (channels) {
+        case 1: distanceSignCorrection(BitmapSection<float, 1>(pixels, w, h, rowStride, yo), shape, proj, sdfZeroValue, (FillRule) fillRule); break;
+        case 3: distanceSignCorrection(BitmapSection<float, 3>(pixels, w, h, rowStride, yo), shape, proj, sdfZeroValue, (FillRule) fillRule); break;
+        case 4: distanceSignCorrection(BitmapSection<float, 4>(pixels, w, h, rowStride, yo), shape, proj, sdfZeroValue, (FillRule) fillRule); break;
+    }
+}
+
+void ref_rasterize(void *s, float *pixels, int w, int h, int rowStride, int yDown, const double *xf, int fillRule) {
+    rasterize(BitmapSection<float, 1>(pixels, w, h, rowStride, yDown ? Y_DOWNWARD : Y_UPWARD), *(Shape *) s, Projection(Vector2(xf[0], xf[1]), Vector2(xf[2], xf[3])), (FillRule) fillRule);
+}
+
+/// EdgeSegment::scanlineIntersections (core/edge-segments.cpp:279-403) on one edge: returns n, fills x[3], dy[3].
+int ref_scanline_intersections(int type, const double *p, double y, double *x, int32_t *dy) {
+    EdgeSegment *edge = NULL;
+    switch (type) {
+        case 1: edge = new LinearSegment(Point2(p[0], p[1]), Point2(p[2], p[3])); break;
+        case 2: edge = new QuadraticSegment(Point2(p[0], p[1]), Point2(p[2], p[3]), Point2(p[4], p[5])); break;
+        default: edge = new CubicSegment(Point2(p[0], p[1]), Point2(p[2], p[3]), Point2(p[4], p[5]), Point2(p[6], p[7])); break;
+    }
+    int d[3] = { 0, 0, 0 };
+    int n = edge->scanlineIntersections(x, d, y);
+    for (int i = 0; i < 3; ++i)
+        dy[i] = d[i];
+    delete edge;
+    return n;
+}
+
 /// EdgeSegment::signedDistance (core/edge-segments.cpp:173/187/228) on one edge. out = {distance, dot, param}
 void ref_signed_distance(int type, const double *p, double ox, double oy, double *out) {
     EdgeSegment *edge = NULL;

@@ -13,7 +13,7 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 
 
 def build():
-    srcs = [os.path.join(HERE, "hostemu.cpp")]+[os.path.join(CSRC, f) for f in ("msdf_device.hpp", "msdf_prep.hpp", "msdf_ec.hpp")]
+    srcs = [os.path.join(HERE, "hostemu.cpp")]+[os.path.join(CSRC, f) for f in ("msdf_device.hpp", "msdf_prep.hpp", "msdf_ec.hpp", "msdf_ec_fast.hpp", "msdf_cull.hpp", "msdf_scanline.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
         subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", SO, srcs[0]], check=True)
     return SO
@@ -61,4 +61,28 @@ class Emu:
         keep, args = self._shape(s)
         self.lib.emu_generate(mode, int(correct_only is not None), _p(out, C.c_float), w, h, w*n, flip, *args, _p(x6, C.c_double), int(overlap),
                               ec_mode, ec_dist, stage, C.c_double(min_dev), C.c_double(min_imp), _p(stencil, C.c_uint8) if stencil is not None else None)
+        return out
+
+    def sign_correction(self, s, field, xf, zero=.5, rule=0, y_down=False):
+        out = np.array(field, np.float32, order="C")
+        h, w, n = out.shape
+        x6 = np.array([xf[0], xf[1], xf[2], xf[3], 1, 0], np.float64)
+        flip = int(bool(s.inverse_y) != bool(y_down))
+        keep, args = self._shape(s)
+        self.lib.emu_sign_correction(n, _p(out, C.c_float), w, h, w*n, flip, *args, _p(x6, C.c_double), C.c_float(zero), int(rule))
+        return out
+
+    def scanline_intersections(self, t, pts, y):
+        pts = np.ascontiguousarray(pts, np.float64)
+        x = np.zeros(3)
+        dy = np.zeros(3, np.int32)
+        self.lib.emu_scanline_intersections.restype = C.c_int
+        n = self.lib.emu_scanline_intersections(int(t), _p(pts, C.c_double), C.c_double(y), _p(x, C.c_double), _p(dy, C.c_int32))
+        return n, x[:n], dy[:n]
+
+    def rasterize(self, s, w, h, xf, rule=0, y_down=False):
+        out = np.zeros((h, w, 1), np.float32)
+        x6 = np.array([xf[0], xf[1], xf[2], xf[3], 1, 0], np.float64)
+        keep, args = self._shape(s)
+        self.lib.emu_rasterize(_p(out, C.c_float), w, h, w, int(bool(s.inverse_y) != bool(y_down)), *args, _p(x6, C.c_double), int(rule))
         return out

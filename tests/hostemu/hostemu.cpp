@@ -14,6 +14,7 @@
 #include "../../msdfgen_amd/csrc/msdf_ec.hpp"
 #include "../../msdfgen_amd/csrc/msdf_ec_fast.hpp"
 #include "../../msdfgen_amd/csrc/msdf_cull.hpp"
+#include "../../msdfgen_amd/csrc/msdf_scanline.hpp"
 
 using namespace msdfhip;
 
@@ -309,4 +310,116 @@ void emu_generate(int mode, int correctionOnly, float *pixels, int w, int h, int
     g_lastDeferred = deferredCount;
 }
 
+}
+
+// Mirrors k_sign_correction (msdf_kernels.hpp): per 8x8 tile, phase 1 builds the per-row intersection lists from the records
+// (lanes = (row, edge) tasks, serialised here; the list order does not matter, only sums over it are taken), phase 2 is per texel.
+template <int N>
+static void signCorrectionEmu(const Digest &d, int nE, const Xform &t, int w, int h, int flip, const float *src, float *pixels, int rowStride,
+                              float zero, int fillRule, int rasterizeOnly = 0) {
+    const EdgeRec *rec = d.recs.data();
+    const int tilesX = (w+7)/8, tilesY = (h+7)/8;
+    for (int tile = 0; tile < tilesX*tilesY; ++tile) {
+        const int tx = tile%tilesX, ty = tile/tilesX;
+        std::vector<double> rowX[8];
+        std::vector<int> rowDir[8];
+        for (int task = 0; task < 8*nE; ++task) {
+            const int r = task&7, e = task>>3;
+            const int ys = ty*8+r;
+            if (ys >= h)
+                continue;
+            const double y = (ys+.5)/t.sy-t.ty;
+            if (!rowMayIntersect(rec[e], y))
+                continue;
+            double x[3];
+            int dy[3];
+            const int n = scanlineIntersections(rec[e], x, dy, y);
+            for (int k = 0; k < n; ++k)
+                rowX[r].push_back(x[k]), rowDir[r].push_back(dy[k]);
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            const int lx = lane&7, ly = lane>>3;
+            const int x = tx*8+lx, ys = ty*8+ly;
+            if (x >= w || ys >= h)
+                continue;
+            const int cnt = (int) rowX[ly].size();
+            const double px = (x+.5)/t.sx-t.tx, pxl = (x-.5)/t.sx-t.tx, pxr = (x+1.5)/t.sx-t.tx;
+            int sum = 0, sumL = 0, sumR = 0;
+            for (int i = 0; i < cnt; ++i) {
+                const double xi = rowX[ly][i];
+                const int dd = rowDir[ly][i];
+                if (px >= xi) sum += dd;
+                if (pxl >= xi) sumL += dd;
+                if (pxr >= xi) sumR += dd;
+            }
+            const bool fill = interpretFillRule(sum, fillRule);
+            const int yn = flip ? h-1-ys : ys;
+            const float *in = src+((size_t) yn*w+x)*N;
+            const float twice = zero+zero;
+            float v[4] = { 0, 0, 0, 0 };
+            for (int i = 0; i < N; ++i)
+                v[i] = rasterizeOnly ? (float) fill : in[i];
+            if (rasterizeOnly) {
+            } else if (N == 1) {
+                if ((v[0] > zero) != fill)
+                    v[0] = twice-v[0];
+            } else {
+                const int match = signMatch(v, fill, zero);
+                bool flipRgb = match < 0;
+                if (match == 0) {
+                    int vote = 0;
+                    if (x > 0)
+                        vote += signMatch(src+((size_t) yn*w+x-1)*N, interpretFillRule(sumL, fillRule), zero);
+                    if (x < w-1)
+                        vote += signMatch(src+((size_t) yn*w+x+1)*N, interpretFillRule(sumR, fillRule), zero);
+                    if (ys > 0) {
+                        const int ynb = flip ? h-1-(ys-1) : ys-1;
+                        vote += signMatch(src+((size_t) ynb*w+x)*N, filledDirect(rec, nE, px, (ys-.5)/t.sy-t.ty, fillRule), zero);
+                    }
+                    if (ys < h-1) {
+                        const int ynb = flip ? h-1-(ys+1) : ys+1;
+                        vote += signMatch(src+((size_t) ynb*w+x)*N, filledDirect(rec, nE, px, (ys+1.5)/t.sy-t.ty, fillRule), zero);
+                    }
+                    flipRgb = vote < 0;
+                }
+                if (flipRgb)
+                    v[0] = twice-v[0], v[1] = twice-v[1], v[2] = twice-v[2];
+                if (N >= 4 && (v[3] > zero) != fill)
+                    v[3] = twice-v[3];
+            }
+            float *o = pixels+(ptrdiff_t) rowStride*yn+(ptrdiff_t) N*x;
+            for (int i = 0; i < N; ++i)
+                o[i] = v[i];
+        }
+    }
+}
+
+extern "C" void emu_sign_correction(int N, float *pixels, int w, int h, int rowStride, int flip, int nC, const int32_t *co, const double *points,
+                                    const uint8_t *types, const uint8_t *colors, const double *xf, float zero, int fillRule) {
+    Digest d = digest(nC, co, points, types, colors);
+    Xform t = { xf[0], xf[1], xf[2], xf[3], 1, 0 };
+    std::vector<float> src((size_t) w*h*N);
+    for (int y = 0; y < h; ++y)
+        memcpy(&src[(size_t) y*w*N], pixels+(ptrdiff_t) rowStride*y, sizeof(float)*(size_t) w*N);
+    switch (N) {
+        case 1: signCorrectionEmu<1>(d, co[nC], t, w, h, flip, src.data(), pixels, rowStride, zero, fillRule); break;
+        case 3: signCorrectionEmu<3>(d, co[nC], t, w, h, flip, src.data(), pixels, rowStride, zero, fillRule); break;
+        default: signCorrectionEmu<4>(d, co[nC], t, w, h, flip, src.data(), pixels, rowStride, zero, fillRule); break;
+    }
+}
+
+extern "C" int emu_scanline_intersections(int type, const double *pts, double y, double *x, int *dy) {
+    const int32_t co[2] = { 0, 1 };
+    const uint8_t t8 = (uint8_t) type, c8 = 7;
+    EdgeRec rec;
+    prepRecord(&rec, 0, 0, co, pts, &t8, &c8);
+    return scanlineIntersections(rec, x, dy, y);
+}
+
+extern "C" void emu_rasterize(float *pixels, int w, int h, int rowStride, int flip, int nC, const int32_t *co, const double *points,
+                              const uint8_t *types, const uint8_t *colors, const double *xf, int fillRule) {
+    Digest d = digest(nC, co, points, types, colors);
+    Xform t = { xf[0], xf[1], xf[2], xf[3], 1, 0 };
+    std::vector<float> src((size_t) w*h);
+    signCorrectionEmu<1>(d, co[nC], t, w, h, flip, src.data(), pixels, rowStride, 0.f, fillRule, 1);
 }

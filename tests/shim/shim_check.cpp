@@ -2,7 +2,9 @@
 // (README.md:114-142): read a shape description, normalize, colour, generateMSDF / generateMTSDF / generateSDF, dump raw floats.
 // It is linked against msdfgen_amd's C++ shim (which provides msdfgen::generate*) plus the reference's remaining objects
 // (shape description parser, Shape, edge colouring ...) -- never against the reference's own msdfgen.o / msdf-error-correction.o.
-//   usage: shim_check <shapedesc-file> <out.bin> <mode 1|2|3|4> <w> <h> <scale> <tx> <ty> <range> [ydown]
+//   usage: shim_check <shapedesc-file> <out.bin> <mode 1|2|3|4> <w> <h> <scale> <tx> <ty> <range> [ydown [scanline-fill-rule+1]]
+// With a fill rule the client follows main.cpp's -scanline flow (main.cpp:1233-1298): generate without correction, simple
+// combiner; distanceSignCorrection; msdfErrorCorrection with DO_NOT_CHECK_DISTANCE.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -26,8 +28,41 @@ int main(int argc, char **argv) {
     const int N = mode <= 2 ? 1 : mode;
     std::vector<float> px((size_t) w*h*N);
     SDFTransformation t(Projection(scale, Vector2(tx, ty)), Range(range));
+    const int scanline = argc > 11 ? atoi(argv[11]) : 0;
     try {
-        switch (mode) {
+        if (scanline) {
+            const FillRule rule = (FillRule) (scanline-1);
+            const Projection proj(scale, Vector2(tx, ty));
+            MSDFGeneratorConfig gen(false, ErrorCorrectionConfig(ErrorCorrectionConfig::DISABLED)), post;
+            post.overlapSupport = false;
+            post.errorCorrection.distanceCheckMode = ErrorCorrectionConfig::DO_NOT_CHECK_DISTANCE;
+            switch (mode) {
+                case 1: {
+                    BitmapSection<float, 1> b(px.data(), w, h, yo);
+                    generateSDF(b, shape, t, GeneratorConfig(false));
+                    distanceSignCorrection(b, shape, proj, .5f, rule);
+                    break;
+                }
+                case 3: {
+                    BitmapSection<float, 3> b(px.data(), w, h, yo);
+                    generateMSDF(b, shape, t, gen);
+                    distanceSignCorrection(b, shape, proj, .5f, rule);
+                    msdfErrorCorrection(b, shape, t, post);
+                    break;
+                }
+                case 4: {
+                    BitmapSection<float, 4> b(px.data(), w, h, yo);
+                    generateMTSDF(b, shape, t, gen);
+                    distanceSignCorrection(b, shape, proj, rule);           // legacy overload (rasterization.h:24)
+                    msdfErrorCorrection(b, shape, t, post);
+                    break;
+                }
+                default: {                                                  // mode 2 here: plain coverage
+                    rasterize(BitmapSection<float, 1>(px.data(), w, h, yo), shape, proj, rule);
+                    break;
+                }
+            }
+        } else switch (mode) {
             case 1: generateSDF(BitmapSection<float, 1>(px.data(), w, h, yo), shape, t); break;
             case 2: generatePSDF(BitmapSection<float, 1>(px.data(), w, h, yo), shape, t); break;
             case 3: generateMSDF(BitmapSection<float, 3>(px.data(), w, h, yo), shape, t); break;

@@ -28,14 +28,14 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "libmsdfgen_hip.so does not export "+s
     assert set(syms) == set(L.EXPORTED_SYMBOLS), set(syms) ^ set(L.EXPORTED_SYMBOLS)
-    assert lib.msdfhip_abi_version() == 1
+    assert lib.msdfhip_abi_version() == 2
 
 
 def test_default_config_matches_reference_defaults():
     cfg = L.default_config()
     assert (cfg.overlap_support, cfg.ec_mode, cfg.ec_distance_check, cfg.ec_stage_limit) == (1, L.EC_EDGE_PRIORITY, L.CHECK_DISTANCE_AT_EDGE, 0)
     assert cfg.min_deviation_ratio == 1.11111111111111111 and cfg.min_improve_ratio == 1.11111111111111111
-    assert C.sizeof(L.Config) == 32 and C.sizeof(L.Glyph) == 64
+    assert C.sizeof(L.Config) == 48 and C.sizeof(L.Glyph) == 64
 
 
 def test_no_device_means_loud_failure_not_fallback():

@@ -320,3 +320,93 @@ def test_concurrent_host_threads(latin, oracle):
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert not errors, errors
+
+
+# ---- distanceSignCorrection (core/rasterization.cpp:19-92) on the device
+
+@pytest.mark.parametrize("seed", range(6))
+def test_distance_sign_correction_standalone_vs_oracle(oracle, seed):
+    """msdfhip_distance_sign_correction in place on 1-, 3- and 4-channel fields: all fill rules, inverted fields (every texel
+    flips), exact zero-value medians (the neighbour vote), Y-down bitmaps and inverse-Y shapes."""
+    rng = np.random.default_rng(1300+seed)
+    s = synth.random_shape(7100+seed, n_contours=1+seed % 4, kinds=(1, 2, 3), holes=bool(seed & 1))
+    s.inverse_y = bool(seed & 2)
+    w, h = int(rng.integers(9, 70)), int(rng.integers(9, 70))
+    xf = autoframe(s.bounds(), w, h, 3)
+    yd = bool(seed & 4)
+    for mode in (1, 3, 4):
+        field = oracle.generate(s, mode, w, h, xf, ec_mode=0, y_down=yd)
+        field = 1-field if seed % 3 == 0 else field
+        if mode >= 3:
+            field[rng.integers(0, h, 10), rng.integers(0, w, 10)] = .5
+            field[0, 0] = field[h-1, w-1] = field[0, w-1] = .5
+        for rule in range(4):
+            want = oracle.sign_correction(s, field, xf, .5, rule, y_down=yd)
+            got = M.distance_sign_correction(field.copy(), s, M.SDFTransformation.from_xf(xf), .5, rule, M.Y_DOWNWARD if yd else M.Y_UPWARD)
+            assert (bits(got) == bits(want)).all(), "seed %d mode %d rule %d: %d texels differ" % (seed, mode, rule, int((bits(got) != bits(want)).sum()))
+        want = oracle.sign_correction(s, field, xf, .25, 0, y_down=yd)
+        got = M.distance_sign_correction(field.copy(), s, M.Projection((xf[0], xf[1]), (xf[2], xf[3])), .25, M.FILL_NONZERO, M.Y_DOWNWARD if yd else M.Y_UPWARD)
+        assert (bits(got) == bits(want)).all()
+
+
+def test_scanline_pass_pipeline_stays_on_device(latin, oracle):
+    """The reference's -scanline flow (main.cpp:1233-1298): generate with the simple combiner and no correction, sign-correct
+    against the scanline fill, then msdfErrorCorrection with DO_NOT_CHECK_DISTANCE -- as one batched call, vs the oracle's
+    composition of the three steps. Also the 1-channel flow (no correction step) and the sign pass with correction disabled."""
+    import torch
+    batch, xf64, _ = latin
+    gb = M.GlyphBatch(batch)
+    G = batch.n_glyphs
+    for mode in (3, 4):
+        for rule in (M.FILL_NONZERO, M.FILL_ODD):
+            c = cfg(overlap=False, ec_mode=M.EC_EDGE_PRIORITY, ec_dist=M.DO_NOT_CHECK_DISTANCE)
+            st = torch.zeros((G, 64, 64), dtype=torch.uint8, device="cuda")
+            got = gb.generate(mode, 64, 64, xf64, config=c, stencil=st, scanline_pass=True, fill_rule=rule).cpu().numpy()
+            want = np.zeros_like(got)
+            for g in range(G):
+                s = batch.shape(g)
+                f = oracle.generate(s, mode, 64, 64, xf64[g], overlap=False, ec_mode=0)
+                f = oracle.sign_correction(s, f, xf64[g], .5, rule)
+                want[g] = oracle.error_correction(s, f, xf64[g], overlap=False, ec_mode=2, ec_dist=0)
+            n = close(got, want, "scanline flow mode %d rule %d" % (mode, rule))
+            print("scanline flow mode %d rule %d: %d of %d texels differ bitwise" % (mode, rule, n, got.size))
+    # correction disabled: distance -> sign pass -> caller's tiles
+    c = cfg(overlap=True, ec_mode=M.EC_DISABLED)
+    got = gb.generate(3, 64, 64, xf64, config=c, scanline_pass=True).cpu().numpy()
+    for g in range(0, G, 7):
+        s = batch.shape(g)
+        want = oracle.sign_correction(s, oracle.generate(s, 3, 64, 64, xf64[g], ec_mode=0), xf64[g], .5, 0)
+        close(got[g], want, "sign pass only, glyph %d" % g)
+    got = gb.generate(1, 64, 64, xf64, config=M.GeneratorConfig(False), scanline_pass=True, sdf_zero_value=.5).cpu().numpy()
+    for g in range(0, G, 7):
+        s = batch.shape(g)
+        want = oracle.sign_correction(s, oracle.generate(s, 1, 64, 64, xf64[g], overlap=False), xf64[g], .5, 0)
+        close(got[g], want, "sdf + sign pass, glyph %d" % g)
+    gb.close()
+
+
+def test_scanline_pass_makes_the_sign_follow_the_fill(oracle):
+    """What the pass is for: whatever the winding of the contours (here: as generated, and with the field inverted as a reversed
+    outline would produce), afterwards `distance > zero value` agrees with the scanline fill at every texel centre."""
+    s = synth.random_shape(7300, n_contours=2, kinds=(1, 2), holes=True)
+    w = h = 48
+    xf = autoframe(s.bounds(), w, h, 4)
+    plain = gen(1, s, w, h, xf, M.GeneratorConfig(False))
+    fill = M.rasterize(np.zeros((h, w, 1), np.float32), s, M.SDFTransformation.from_xf(xf)) > 0
+    assert (fill == (oracle.rasterize(s, w, h, xf) > 0)).all() and 0 < fill.mean() < 1
+    for field in (plain, 1-plain):
+        fixed = M.distance_sign_correction(field.copy(), s, M.SDFTransformation.from_xf(xf))
+        assert (bits(fixed) == bits(oracle.sign_correction(s, field, xf, .5, 0))).all()
+        assert ((fixed > .5) == fill)[fixed != .5].all()
+
+
+def test_rasterize_vs_oracle(oracle):
+    """msdfhip_rasterize (core/rasterization.cpp:8-16): the fill bit of every texel centre, all fill rules."""
+    for seed in range(5):
+        s = synth.random_shape(7400+seed, n_contours=1+seed % 4, kinds=(1, 2, 3), holes=bool(seed & 1))
+        s.inverse_y = bool(seed & 2)
+        w, h = 30+7*seed, 61-5*seed
+        xf = autoframe(s.bounds(), w, h, 2)
+        for rule in range(4):
+            got = M.rasterize(np.full((h, w, 1), -3, np.float32), s, M.Projection((xf[0], xf[1]), (xf[2], xf[3])), rule, M.Y_DOWNWARD if seed & 4 else M.Y_UPWARD)
+            assert (got == oracle.rasterize(s, w, h, xf, rule, y_down=bool(seed & 4))).all(), (seed, rule)

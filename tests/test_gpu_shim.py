@@ -34,3 +34,30 @@ def test_reference_client_through_cpp_shim(tmp_path, oracle, mode, ydown):
     want = oracle.generate(s, mode, w, h, [scale, scale, tx, ty, -.5*rng, .5*rng], y_down=bool(ydown))
     assert np.abs(got.astype(np.float64)-want).max() <= 1e-5
     print("bitwise differing:", int((bits(got) != bits(want)).sum()))
+
+
+@pytest.mark.parametrize("mode,rule", [(1, 0), (3, 0), (4, 1), (2, 0), (3, 2)])
+def test_reference_client_scanline_flow_through_cpp_shim(tmp_path, oracle, mode, rule):
+    """msdfgen::distanceSignCorrection / rasterize (core/rasterization.h:13-27) through the shim: main.cpp's -scanline flow."""
+    if not os.path.exists(BIN):
+        pytest.skip("tests/shim/shim_check not built (needs the msdfgen headers)")
+    z = load_npz("shape_a.npz")
+    s = FlatShape(z["contour_offsets"], z["points"], z["types"], z["colors"])
+    desc = tmp_path/"a.txt"
+    desc.write_text(str(z["desc"]))
+    out = tmp_path/"a.bin"
+    w, h = 40, 32
+    scale, tx, ty, rng = 2.75, .625, .71875, 1.5
+    r = subprocess.run([BIN, str(desc), str(out), str(mode), str(w), str(h), repr(scale), repr(tx), repr(ty), repr(rng), "0", str(rule+1)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    n = {1: 1, 2: 1, 3: 3, 4: 4}[mode]
+    got = np.fromfile(out, np.float32).reshape(h, w, n)
+    xf = [scale, scale, tx, ty, -.5*rng, .5*rng]
+    if mode == 2:
+        want = oracle.rasterize(s, w, h, xf, rule)
+    else:
+        want = oracle.sign_correction(s, oracle.generate(s, mode, w, h, xf, overlap=False, ec_mode=0), xf, .5, rule)
+        if mode >= 3:
+            want = oracle.error_correction(s, want, xf, overlap=False, ec_mode=2, ec_dist=0)
+    assert np.abs(got.astype(np.float64)-want).max() <= 1e-5
+    assert (bits(got) == bits(want)).all()

@@ -1,0 +1,98 @@
+"""distanceSignCorrection (core/rasterization.cpp:19-88) + Shape::scanline + EdgeSegment::scanlineIntersections
+(core/edge-segments.cpp:279-403).  The plain-C oracle against the compiled reference, bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+from emu import Emu
+from msdfgen_amd import synth
+from msdfgen_amd.shape import autoframe
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return Emu()
+
+
+def test_scanline_intersections_kat(oracle, ref):
+    rng = np.random.default_rng(5)
+    for t in (1, 2, 3):
+        for i in range(400):
+            pts = np.zeros(8)
+            pts[:2*(t+1)] = np.round(rng.uniform(-1, 1, 2*(t+1)), 2) if i % 3 == 0 else rng.uniform(-1, 1, 2*(t+1))
+            ys = [rng.uniform(-1.2, 1.2), pts[1], pts[2*t+1], pts[3]]          # incl. rows through control points (the == branches)
+            for y in ys:
+                na, xa, da = ref.scanline_intersections(t, pts, y)
+                nb, xb, db = oracle.scanline_intersections(t, pts, y)
+                assert na == nb and (da == db).all(), (t, i, y)
+                assert_bit_equal(xb, xa, "scanlineIntersections type %d" % t)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_sign_correction_vs_reference(oracle, ref, seed):
+    rng = np.random.default_rng(300+seed)
+    s = synth.random_shape(6000+seed, n_contours=1+seed % 4, kinds=(1, 2, 3), holes=bool(seed & 1))
+    s.inverse_y = bool(seed & 2)
+    w, h = int(rng.integers(12, 40)), int(rng.integers(12, 40))
+    xf = autoframe(s.bounds(), w, h, 3)
+    for mode, n in ((1, 1), (3, 3), (4, 4)):
+        field = ref.generate(s, mode, w, h, xf, ec_mode=0, y_down=bool(seed & 4))
+        field = 1-field if seed % 3 == 0 else field                         # a wholly inverted field exercises every texel
+        if n >= 3:
+            field[rng.integers(0, h, 6), rng.integers(0, w, 6)] = .5           # exact zero-value medians: the ambiguity pass (:69-88)
+        for rule in range(4):
+            a = ref.sign_correction(s, field, xf, .5, rule, y_down=bool(seed & 4))
+            b = oracle.sign_correction(s, field, xf, .5, rule, y_down=bool(seed & 4))
+            assert_bit_equal(b, a, "seed %d mode %d rule %d" % (seed, mode, rule))
+        a = ref.sign_correction(s, field, xf, .25, 0)
+        assert_bit_equal(oracle.sign_correction(s, field, xf, .25, 0), a, "zero value .25")
+
+
+# ---- the product's device code (msdf_scanline.hpp + the k_sign_correction walk) compiled for the host, against the oracle
+
+def test_device_scanline_intersections_host(oracle, emu):
+    rng = np.random.default_rng(6)
+    for t in (1, 2, 3):
+        for i in range(600):
+            pts = np.zeros(8)
+            pts[:2*(t+1)] = np.round(rng.uniform(-1, 1, 2*(t+1)), 2) if i % 3 == 0 else rng.uniform(-1, 1, 2*(t+1))
+            if i % 7 == 0:
+                pts[2*t:2*t+2] = pts[0:2]+[rng.uniform(-1, 1), 0]             # end point level with the start
+            for y in (rng.uniform(-1.2, 1.2), pts[1], pts[2*t+1], pts[3]):
+                na, xa, da = oracle.scanline_intersections(t, pts, y)
+                nb, xb, db = emu.scanline_intersections(t, pts, y)
+                assert na == nb and (da == db).all(), (t, i, y)
+                assert_bit_equal(xb, xa, "device scanlineIntersections type %d" % t)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_device_sign_correction_host(oracle, emu, seed):
+    rng = np.random.default_rng(900+seed)
+    s = synth.random_shape(6100+seed, n_contours=1+seed % 4, kinds=(1, 2, 3), holes=bool(seed & 1))
+    s.inverse_y = bool(seed & 2)
+    w, h = int(rng.integers(9, 40)), int(rng.integers(9, 40))
+    xf = autoframe(s.bounds(), w, h, 3)
+    for mode in (1, 3, 4):
+        field = oracle.generate(s, mode, w, h, xf, ec_mode=0, y_down=bool(seed & 4))
+        field = 1-field if seed % 3 == 0 else field
+        if mode >= 3:
+            field[rng.integers(0, h, 8), rng.integers(0, w, 8)] = .5
+            field[0, 0] = field[h-1, w-1] = .5                                  # ambiguous texels on the border: fewer neighbours
+        for rule in range(4):
+            a = oracle.sign_correction(s, field, xf, .5, rule, y_down=bool(seed & 4))
+            b = emu.sign_correction(s, field, xf, .5, rule, y_down=bool(seed & 4))
+            assert_bit_equal(b, a, "seed %d mode %d rule %d" % (seed, mode, rule))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_rasterize_oracle_reference_and_device_host(oracle, ref, emu, seed):
+    """rasterize (core/rasterization.cpp:8-16): oracle == reference == the product's scanline code on the host."""
+    s = synth.random_shape(6200+seed, n_contours=1+seed % 4, kinds=(1, 2, 3), holes=bool(seed & 1))
+    s.inverse_y = bool(seed & 2)
+    w, h = 21+seed, 37-seed
+    xf = autoframe(s.bounds(), w, h, 2)
+    for rule in range(4):
+        a = ref.rasterize(s, w, h, xf, rule, y_down=bool(seed & 4))
+        assert (oracle.rasterize(s, w, h, xf, rule, y_down=bool(seed & 4)) == a).all()
+        assert (emu.rasterize(s, w, h, xf, rule, y_down=bool(seed & 4)) == a).all()
+    assert 0 < ref.rasterize(s, w, h, xf, 1).mean() < 1
