@@ -184,8 +184,9 @@ int msdfhip_batch_generate(const MsdfHipBatch *batch, int mode, int width, int h
 int msdfhip_batch_generate_host(const MsdfHipBatch *batch, int mode, int width, int height, const MsdfHipGlyph *glyphs,
                                 float *out, size_t out_floats, uint8_t *stencil, const MsdfHipConfig *cfg);
 
-/* Timing hook for bench.py: average device time in milliseconds of the dominant kernel (the distance-field kernel) over
- * the launches recorded since the last call with reset != 0, measured with hipEvents on the launching stream.
+/* Timing hook for bench.py: average device time in milliseconds of the dominant kernel (the distance-field kernel) and of
+ * the passes after it (sign correction + error correction, per error-correction launch) over the launches recorded since the
+ * last call with reset != 0, measured with hipEvents on the launching stream.
  * Enable with msdfhip_set_kernel_timing(1) (adds two event records per launch). */
 int msdfhip_set_kernel_timing(int enable);
 int msdfhip_kernel_timing(double *avg_ms_distance, double *avg_ms_correction, int *launches, int reset);

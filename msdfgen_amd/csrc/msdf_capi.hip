@@ -332,20 +332,28 @@ int runCorrection(const MsdfHipBatch *b, int channels, int w, int h, const MsdfH
 template <int N>
 int launchSign(const MsdfHipBatch *b, int w, int h, const MsdfHipGlyph *dGlyphs, const float *src, float *out, int dstPacked, float zero, int fillRule,
                int rasterizeOnly, hipStream_t stream) {
-    const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE, tiles = tilesX*tilesY;
-    const size_t blocks = (size_t) ((b->nGlyphs+7)/8)*8u*(size_t) tiles;
+    const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE;
+    // Tiles of one tile row share the per-row intersection lists: one wavefront takes `span` of them, as many as still leaves
+    // >= 16 wavefronts per CU in the launch (a single huge bitmap keeps span small, an atlas batch takes whole rows).
+    int span = tilesX;
+    while (span > 1 && (size_t) b->nGlyphs*tilesY*((tilesX+span-1)/span) < 4096)
+        span = (span+1)/2;
+    const int spansX = (tilesX+span-1)/span, spans = spansX*tilesY;
+    const size_t blocks = (size_t) ((b->nGlyphs+7)/8)*8u*(size_t) spans;
     if (blocks > 0x7fffffffull)
-        return fail(MSDFHIP_ERR_INVALID, "launch of %zu tiles exceeds the grid limit; split the batch", blocks);
-    const size_t cap = 3*(size_t) (b->maxEdges > 0 ? b->maxEdges : 1);
-    const size_t lds = TILE*cap*(sizeof(double)+sizeof(int))+TILE*sizeof(int);   // per-row intersection lists
-    if (lds > (size_t) gLdsLimit.load())
-        return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d edges: the scanline lists need %zu B of LDS per wavefront, device limit is %d B",
-                    b->maxEdges, lds, gLdsLimit.load());
+        return fail(MSDFHIP_ERR_INVALID, "launch of %zu tile rows exceeds the grid limit; split the batch", blocks);
+    // Row-list capacity: every edge yields at most 3 intersections per row. Up to SIGN_CAP_LIMIT entries per row the lists of the
+    // whole shape fit (46 KB per wavefront at the limit); beyond, the kernel walks the edges in chunks of cap/3.
+    enum { SIGN_CAP_LIMIT = 384 };
+    size_t cap = 3*(size_t) (b->maxEdges > 0 ? b->maxEdges : 1);
+    if (cap > SIGN_CAP_LIMIT)
+        cap = SIGN_CAP_LIMIT;
+    const size_t lds = SIGN_ROWS*cap*(sizeof(double)+sizeof(int))+SIGN_ROWS*sizeof(int);   // per-row intersection lists
     int rc = setLds(k_sign_correction<N>, lds);
     if (rc != MSDFHIP_OK)
         return rc;
-    ScopedTimer timer(stream, 1);
-    hipLaunchKernelGGL((k_sign_correction<N>), dim3((unsigned) blocks), dim3(WAVE), lds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, b->maxEdges,
+    ScopedTimer timer(stream, 2);
+    hipLaunchKernelGGL((k_sign_correction<N>), dim3((unsigned) blocks), dim3(WAVE), lds, stream, viewOf(b), dGlyphs, w, h, spansX, span, spans, (int) cap,
                        src, out, dstPacked, zero, fillRule, rasterizeOnly);
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
@@ -898,8 +906,8 @@ int msdfhip_set_kernel_timing(int enable) {
 
 int msdfhip_kernel_timing(double *avgDistance, double *avgCorrection, int *launches, int reset) {
     std::lock_guard<std::mutex> lock(gTimingMutex);
-    double sum[2] = { 0, 0 };
-    int cnt[2] = { 0, 0 };
+    double sum[3] = { 0, 0, 0 };                                 // 0 distance, 1 error correction, 2 sign correction
+    int cnt[3] = { 0, 0, 0 };
     for (size_t i = 0; i < gTimed.size(); ++i) {
         float ms = 0;
         if (hipEventSynchronize(gTimed[i].b) == hipSuccess && hipEventElapsedTime(&ms, gTimed[i].a, gTimed[i].b) == hipSuccess) {
@@ -908,7 +916,7 @@ int msdfhip_kernel_timing(double *avgDistance, double *avgCorrection, int *launc
         }
     }
     if (avgDistance) *avgDistance = cnt[0] ? sum[0]/cnt[0] : 0;
-    if (avgCorrection) *avgCorrection = cnt[1] ? sum[1]/cnt[1] : 0;
+    if (avgCorrection) *avgCorrection = cnt[1] ? (sum[1]+sum[2])/cnt[1] : cnt[2] ? sum[2]/cnt[2] : 0;   // everything after the distance kernel
     if (launches) *launches = cnt[0];
     if (reset) {
         for (size_t i = 0; i < gTimed.size(); ++i) {

@@ -493,19 +493,73 @@ k_ec_slow(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, co
 
 // ------------------------------------------------------------------------------------------- distance sign correction
 
-// distanceSignCorrection (core/rasterization.cpp:19-88) for one 8x8 tile per wavefront; src -> out (distinct buffers).
-// Phase 1 (lanes = (row, edge) tasks): intersections of every edge with the tile's 8 texel rows, appended per row in LDS
-// (order is irrelevant: the fill test is a sum). Phase 2 (lanes = texels): fill bit = fill rule of the sum of directions left of
-// the texel centre; flip the distances whose sign disagrees. Texels whose median equals the zero value exactly take the
-// reference's neighbour vote (:69-88); the two vertical neighbours' fill bits are then evaluated directly from the records.
-// src: packed [g][h][w][N] native rows. dstPacked != 0: out is packed the same way (a further pass follows), else the caller's bitmap.
-// LDS: [8][cap] doubles (x) + [8][cap] ints (direction) + 8 counters, cap = 3*maxEdges.
+// distanceSignCorrection (core/rasterization.cpp:19-88); one wavefront = `span` horizontally adjacent 8x8 tiles of one tile row (they
+// share the row lists; the host picks span so that the launch still has thousands of wavefronts); src -> out (distinct buffers).
+// Phase 1 (lanes = (row, edge) tasks): intersections of every edge with the tile row's texel rows, appended per row in LDS (order is
+// irrelevant: the fill test is a sum). Multi-channel fields also list the row above and the row below the tile row, so that the
+// neighbour vote of an ambiguous texel (:69-88) finds all four neighbours' fill bits in LDS.
+// Phase 2 (lanes = texels): fill bit = fill rule of the sum of directions left of the texel centre; flip the distances whose sign
+// disagrees; texels whose median equals the zero value exactly take the reference's neighbour vote.
+// Shapes with more than cap/3 edges (cap = list capacity per row, bounded by the host to keep the lists in LDS) run phase 1 in edge
+// chunks and accumulate the five sums of every texel chunk by chunk (slower, only for such shapes).
+// src: packed [g][h][w][N] native rows (unused when rasterizeOnly: the output is the fill bit itself, rasterization.cpp:8-16).
+// dstPacked != 0: out is packed the same way (a further pass follows), else the caller's bitmap.
+// LDS: [ROWS][cap] doubles (x) + [ROWS][cap] ints (direction) + ROWS counters, ROWS = 10.
+enum { SIGN_ROWS = TILE+2 };
+
+struct RowLists {
+    double *x;      // [SIGN_ROWS][cap]
+    int *dir;       // [SIGN_ROWS][cap]
+    int *count;     // [SIGN_ROWS]
+    int cap;
+    __device__ int sum(int row, double px) const {                       // Scanline::sumIntersections, Scanline.cpp:98-104
+        const double *rx = x+(size_t) row*cap;
+        const int *rd = dir+(size_t) row*cap;
+        const int cnt = count[row];
+        int s = 0;
+        for (int i = 0; i < cnt; ++i)
+            s += px >= rx[i] ? rd[i] : 0;
+        return s;
+    }
+};
+
+// Lists of edges [eBegin, eEnd) for list rows rowLo..rowLo+rows-1 (list row rr <-> bitmap row ty*TILE+rr-1). All lanes take part.
+__device__ inline void buildRowLists(const RowLists &L, const EdgeRec *rec, int eBegin, int eEnd, int rowLo, int rows, int ty, int height,
+                                     const Xform &t, int lane) {
+    waveSync();                                                          // earlier readers of the lists are done
+    if (lane < SIGN_ROWS)
+        L.count[lane] = 0;
+    waveSync();
+    for (int task = lane; task < rows*(eEnd-eBegin); task += WAVE) {
+        const int k = task/rows, rr = rowLo+task-k*rows;
+        const int e = eBegin+k;
+        const int ys = ty*TILE+rr-1;
+        if (ys < 0 || ys >= height)
+            continue;
+        const double y = (ys+.5)/t.sy-t.ty;                              // projection.unprojectY(y+.5), Projection.cpp:38-40
+        if (!rowMayIntersect(rec[e], y))
+            continue;
+        double x[3];
+        int dy[3];
+        const int n = scanlineIntersections(rec[e], x, dy, y);
+        if (n > 0) {
+            const int slot = atomicAdd(&L.count[rr], n);
+            for (int q = 0; q < 3; ++q)
+                if (q < n) {
+                    L.x[(size_t) rr*L.cap+slot+q] = x[q];
+                    L.dir[(size_t) rr*L.cap+slot+q] = dy[q];
+                }
+        }
+    }
+    waveSync();
+}
+
 template <int N>
-__global__ void __launch_bounds__(WAVE)
-k_sign_correction(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges,
+__global__ void __launch_bounds__(WAVE, 3)
+k_sign_correction(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int spansX, int span, int spansPerGlyph, int cap,
                   const float *src, float *out, int dstPacked, float zero, int fillRule, int rasterizeOnly) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const GlyphWork wk = decodeBlock(batch.nGlyphs, tilesPerGlyph);
+    const GlyphWork wk = decodeBlock(batch.nGlyphs, spansPerGlyph);
     if (!wk.valid)
         return;
     const int c0 = batch.glyphContourOffsets[wk.g], C = batch.glyphContourOffsets[wk.g+1]-c0;
@@ -513,99 +567,85 @@ k_sign_correction(BatchView batch, const MsdfHipGlyph *glyphs, int width, int he
     const int e0 = coff[0], nE = coff[C]-e0;
     const EdgeRec *rec = batch.recs+e0;
     const int lane = threadIdx.x;
-    const int cap = 3*(maxEdges > 0 ? maxEdges : 1);
-    double *rowX = smem;                                            // [8][cap]
-    int *rowDir = reinterpret_cast<int *>(rowX+(size_t) TILE*cap);  // [8][cap]
-    int *rowCount = rowDir+(size_t) TILE*cap;                       // [8]
+    RowLists L;
+    L.cap = cap;
+    L.x = smem;
+    L.dir = reinterpret_cast<int *>(L.x+(size_t) SIGN_ROWS*cap);
+    L.count = L.dir+(size_t) SIGN_ROWS*cap;
     const MsdfHipGlyph gd = glyphs[wk.g];
     const Xform t = loadXform(gd);
-    const int tx = wk.tile%tilesX, ty = wk.tile/tilesX;
-
-    if (lane < TILE)
-        rowCount[lane] = 0;
-    waveSync();
-    for (int task = lane; task < TILE*nE; task += WAVE) {           // phase 1
-        const int r = task&(TILE-1), e = task>>3;
-        const int ys = ty*TILE+r;
-        if (ys >= height)
-            continue;
-        const double y = (ys+.5)/t.sy-t.ty;                          // projection.unprojectY(y+.5), Projection.cpp:38-40
-        if (!rowMayIntersect(rec[e], y))
-            continue;
-        double x[3];
-        int dy[3];
-        const int n = scanlineIntersections(rec[e], x, dy, y);
-        if (n > 0) {
-            const int slot = atomicAdd(&rowCount[r], n);
-            for (int k = 0; k < 3; ++k)
-                if (k < n) {
-                    rowX[(size_t) r*cap+slot+k] = x[k];
-                    rowDir[(size_t) r*cap+slot+k] = dy[k];
-                }
-        }
-    }
-    waveSync();
+    const int tx0 = (wk.tile%spansX)*span, ty = wk.tile/spansX;          // this wavefront: tiles tx0..tx0+span-1 of tile row ty
+    const int rowLo = N == 1 ? 1 : 0, rows = N == 1 ? TILE : SIGN_ROWS;
+    const bool chunked = 3*nE > cap;                                     // wave-uniform
+    const int chunkE = chunked ? cap/3 : (nE > 0 ? nE : 1);
 
     const int lx = lane&(TILE-1), ly = lane>>3;
-    const int x = tx*TILE+lx, ys = ty*TILE+ly;                      // shape orientation (sdf.reorient, rasterization.cpp:39)
-    if (x >= width || ys >= height)
-        return;
-    const int cnt = rowCount[ly];
-    // fill bits of this texel and of its left / right neighbours (same row list)
-    const double px = (x+.5)/t.sx-t.tx, pxl = (x-.5)/t.sx-t.tx, pxr = (x+1.5)/t.sx-t.tx;   // projection.unprojectX(x+.5)
-    int sum = 0, sumL = 0, sumR = 0;
-    for (int i = 0; i < cnt; ++i) {
-        const double xi = rowX[(size_t) ly*cap+i];
-        const int d = rowDir[(size_t) ly*cap+i];
-        if (px >= xi) sum += d;
-        if (pxl >= xi) sumL += d;
-        if (pxr >= xi) sumR += d;
-    }
-    const bool fill = interpretFillRule(sum, fillRule);
+    const int ys = ty*TILE+ly;                                           // shape orientation (sdf.reorient, rasterization.cpp:39)
     const int yn = gd.flip ? height-1-ys : ys;
     const float *tile = src+(size_t) wk.g*height*width*N;
-    const float *in = tile+((size_t) yn*width+x)*N;
     const float twice = zero+zero;
-    float v[N];
-    if (rasterizeOnly) {                                            // rasterize(), rasterization.cpp:8-16 (N == 1)
-        for (int i = 0; i < N; ++i)
-            v[i] = (float) fill;
-    } else {
-        for (int i = 0; i < N; ++i)
-            v[i] = in[i];
-    }
-    if (rasterizeOnly) {
-    } else if (N == 1) {                                            // :19-33
-        if ((v[0] > zero) != fill)
-            v[0] = twice-v[0];
-    } else {                                                        // :35-88
-        const int match = signMatch(v, fill, zero);
-        bool flipRgb = match < 0;
-        if (match == 0) {                                           // ambiguous texel: neighbour vote (:69-86)
-            int vote = 0;
-            if (x > 0)
-                vote += signMatch(tile+((size_t) yn*width+x-1)*N, interpretFillRule(sumL, fillRule), zero);
-            if (x < width-1)
-                vote += signMatch(tile+((size_t) yn*width+x+1)*N, interpretFillRule(sumR, fillRule), zero);
-            if (ys > 0) {
-                const int ynb = gd.flip ? height-1-(ys-1) : ys-1;
-                vote += signMatch(tile+((size_t) ynb*width+x)*N, filledDirect(rec, nE, px, (ys-.5)/t.sy-t.ty, fillRule), zero);
+    for (int s = 0; s < span; ++s) {                                     // one 8x8 tile per step
+        if ((tx0+s)*TILE >= width)
+            break;                                                       // wave-uniform
+        const int x = (tx0+s)*TILE+lx;
+        const bool valid = x < width && ys < height;
+        const double px = (x+.5)/t.sx-t.tx;                              // projection.unprojectX(x+.5)
+        const double pxl = (x-.5)/t.sx-t.tx, pxr = (x+1.5)/t.sx-t.tx;    // the horizontal neighbours' centres
+        int sum = 0, sumL = 0, sumR = 0, sumU = 0, sumD = 0;
+        for (int k = 0; k == 0 || (chunked && k < nE); k += chunkE) {     // a single pass unless the shape is chunked
+            if (chunked || s == 0)
+                buildRowLists(L, rec, k, k+chunkE < nE ? k+chunkE : nE, rowLo, rows, ty, height, t, lane);
+            sum += L.sum(ly+1, px);
+            if (N > 1 && chunked) {
+                sumL += L.sum(ly+1, pxl), sumR += L.sum(ly+1, pxr);
+                sumU += L.sum(ly, px), sumD += L.sum(ly+2, px);
             }
-            if (ys < height-1) {
-                const int ynb = gd.flip ? height-1-(ys+1) : ys+1;
-                vote += signMatch(tile+((size_t) ynb*width+x)*N, filledDirect(rec, nE, px, (ys+1.5)/t.sy-t.ty, fillRule), zero);
-            }
-            flipRgb = vote < 0;
         }
-        if (flipRgb)
-            v[0] = twice-v[0], v[1] = twice-v[1], v[2] = twice-v[2];
-        if (N >= 4 && (v[N >= 4 ? 3 : 0] > zero) != fill)
-            v[N >= 4 ? 3 : 0] = twice-v[N >= 4 ? 3 : 0];
+        if (!valid)
+            continue;
+        const bool fill = interpretFillRule(sum, fillRule);
+        float v[N];
+        if (rasterizeOnly) {                                             // rasterize(), rasterization.cpp:8-16 (N == 1)
+            for (int i = 0; i < N; ++i)
+                v[i] = (float) fill;
+        } else {
+            const float *in = tile+((size_t) yn*width+x)*N;
+            for (int i = 0; i < N; ++i)
+                v[i] = in[i];
+            if (N == 1) {                                                // :19-33
+                if ((v[0] > zero) != fill)
+                    v[0] = twice-v[0];
+            } else {                                                     // :35-88
+                const int match = signMatch(v, fill, zero);
+                bool flipRgb = match < 0;
+                if (match == 0) {                                        // ambiguous texel: neighbour vote (:69-86)
+                    if (!chunked) {
+                        sumL = L.sum(ly+1, pxl), sumR = L.sum(ly+1, pxr);
+                        sumU = L.sum(ly, px), sumD = L.sum(ly+2, px);
+                    }
+                    int vote = 0;
+                    if (x > 0)
+                        vote += signMatch(tile+((size_t) yn*width+x-1)*N, interpretFillRule(sumL, fillRule), zero);
+                    if (x < width-1)
+                        vote += signMatch(tile+((size_t) yn*width+x+1)*N, interpretFillRule(sumR, fillRule), zero);
+                    if (ys > 0)
+                        vote += signMatch(tile+((size_t) (gd.flip ? height-1-(ys-1) : ys-1)*width+x)*N, interpretFillRule(sumU, fillRule), zero);
+                    if (ys < height-1)
+                        vote += signMatch(tile+((size_t) (gd.flip ? height-1-(ys+1) : ys+1)*width+x)*N, interpretFillRule(sumD, fillRule), zero);
+                    flipRgb = vote < 0;
+                }
+                if (flipRgb)
+                    for (int i = 0; i < (N < 3 ? N : 3); ++i)
+                        v[i] = twice-v[i];
+                if (N >= 4 && (v[N >= 4 ? 3 : 0] > zero) != fill)
+                    v[N >= 4 ? 3 : 0] = twice-v[N >= 4 ? 3 : 0];
+            }
+        }
+        float *px_ = dstPacked ? out+(((size_t) wk.g*height+yn)*width+x)*N
+                               : out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
+        for (int i = 0; i < N; ++i)
+            px_[i] = v[i];
     }
-    float *px_ = dstPacked ? out+(((size_t) wk.g*height+yn)*width+x)*N
-                           : out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
-    for (int i = 0; i < N; ++i)
-        px_[i] = v[i];
 }
 
 // ------------------------------------------------------------------------------------------------- distance queries

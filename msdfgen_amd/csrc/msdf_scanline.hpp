@@ -7,7 +7,7 @@
 // The reference sorts a row's intersections and prefix-sums their directions; filled(x) then reads the sum over all intersections
 // with x_i <= x -- an order-independent sum, evaluated here directly. The correction of a texel is a pure function of its own value
 // and fill bit, plus (only for texels whose median is EXACTLY the zero value) the match state of its four neighbours, which in turn
-// is a pure function of the ORIGINAL field -- hence one gather pass, input and output buffers distinct.
+// is a pure function of the ORIGINAL field and the neighbours' fill bits -- hence one gather pass, input and output buffers distinct.
 #pragma once
 
 #include "msdf_device.hpp"
@@ -129,22 +129,6 @@ MSDF_HD bool rowMayIntersect(const EdgeRec &e, double y) {
 
 MSDF_HD bool interpretFillRule(int intersections, int rule) {                 // Scanline.cpp:13-25: 0 nonzero, 1 odd, 2 positive, 3 negative
     return rule == 0 ? intersections != 0 : rule == 1 ? (intersections&1) != 0 : rule == 2 ? intersections > 0 : intersections < 0;
-}
-
-// Scanline::filled at (px, row y) evaluated straight from the records (no shared row list): sum of directions with x_i <= px.
-MSDF_HD bool filledDirect(const EdgeRec *rec, int nE, double px, double y, int rule) {
-    int sum = 0;
-    for (int i = 0; i < nE; ++i) {
-        if (!rowMayIntersect(rec[i], y))
-            continue;
-        double x[3];
-        int dy[3];
-        const int n = scanlineIntersections(rec[i], x, dy, y);
-        for (int k = 0; k < 3; ++k)
-            if (k < n && px >= x[k])
-                sum += dy[k];
-    }
-    return interpretFillRule(sum, rule);
 }
 
 // match value of a texel (rasterization.cpp:55-66): 0 ambiguous, -1 sign flipped, +1 sign kept.

@@ -313,7 +313,15 @@ void emu_generate(int mode, int correctionOnly, float *pixels, int w, int h, int
 }
 
 // Mirrors k_sign_correction (msdf_kernels.hpp): per 8x8 tile, phase 1 builds the per-row intersection lists from the records
-// (lanes = (row, edge) tasks, serialised here; the list order does not matter, only sums over it are taken), phase 2 is per texel.
+// (lanes = (row, edge) tasks, serialised here; the list order does not matter, only sums over it are taken) -- for multi-channel
+// fields including the row above and the row below the tile; phase 2 is per texel.
+static int scanlineSumEmu(const std::vector<double> &xs, const std::vector<int> &dirs, double px) {
+    int sum = 0;
+    for (size_t i = 0; i < xs.size(); ++i)
+        sum += px >= xs[i] ? dirs[i] : 0;
+    return sum;
+}
+
 template <int N>
 static void signCorrectionEmu(const Digest &d, int nE, const Xform &t, int w, int h, int flip, const float *src, float *pixels, int rowStride,
                               float zero, int fillRule, int rasterizeOnly = 0) {
@@ -321,12 +329,13 @@ static void signCorrectionEmu(const Digest &d, int nE, const Xform &t, int w, in
     const int tilesX = (w+7)/8, tilesY = (h+7)/8;
     for (int tile = 0; tile < tilesX*tilesY; ++tile) {
         const int tx = tile%tilesX, ty = tile/tilesX;
-        std::vector<double> rowX[8];
-        std::vector<int> rowDir[8];
-        for (int task = 0; task < 8*nE; ++task) {
-            const int r = task&7, e = task>>3;
-            const int ys = ty*8+r;
-            if (ys >= h)
+        std::vector<double> rowX[10];
+        std::vector<int> rowDir[10];
+        const int rowLo = N == 1 ? 1 : 0, rows = N == 1 ? 8 : 10;
+        for (int task = 0; task < rows*nE; ++task) {
+            const int e = task/rows, rr = rowLo+task-e*rows;
+            const int ys = ty*8+rr-1;
+            if (ys < 0 || ys >= h)
                 continue;
             const double y = (ys+.5)/t.sy-t.ty;
             if (!rowMayIntersect(rec[e], y))
@@ -335,57 +344,51 @@ static void signCorrectionEmu(const Digest &d, int nE, const Xform &t, int w, in
             int dy[3];
             const int n = scanlineIntersections(rec[e], x, dy, y);
             for (int k = 0; k < n; ++k)
-                rowX[r].push_back(x[k]), rowDir[r].push_back(dy[k]);
+                rowX[rr].push_back(x[k]), rowDir[rr].push_back(dy[k]);
         }
         for (int lane = 0; lane < 64; ++lane) {
             const int lx = lane&7, ly = lane>>3;
             const int x = tx*8+lx, ys = ty*8+ly;
             if (x >= w || ys >= h)
                 continue;
-            const int cnt = (int) rowX[ly].size();
-            const double px = (x+.5)/t.sx-t.tx, pxl = (x-.5)/t.sx-t.tx, pxr = (x+1.5)/t.sx-t.tx;
-            int sum = 0, sumL = 0, sumR = 0;
-            for (int i = 0; i < cnt; ++i) {
-                const double xi = rowX[ly][i];
-                const int dd = rowDir[ly][i];
-                if (px >= xi) sum += dd;
-                if (pxl >= xi) sumL += dd;
-                if (pxr >= xi) sumR += dd;
-            }
-            const bool fill = interpretFillRule(sum, fillRule);
+            const double px = (x+.5)/t.sx-t.tx;
+            const bool fill = interpretFillRule(scanlineSumEmu(rowX[ly+1], rowDir[ly+1], px), fillRule);
             const int yn = flip ? h-1-ys : ys;
-            const float *in = src+((size_t) yn*w+x)*N;
             const float twice = zero+zero;
             float v[4] = { 0, 0, 0, 0 };
-            for (int i = 0; i < N; ++i)
-                v[i] = rasterizeOnly ? (float) fill : in[i];
             if (rasterizeOnly) {
-            } else if (N == 1) {
-                if ((v[0] > zero) != fill)
-                    v[0] = twice-v[0];
+                v[0] = (float) fill;
             } else {
-                const int match = signMatch(v, fill, zero);
-                bool flipRgb = match < 0;
-                if (match == 0) {
-                    int vote = 0;
-                    if (x > 0)
-                        vote += signMatch(src+((size_t) yn*w+x-1)*N, interpretFillRule(sumL, fillRule), zero);
-                    if (x < w-1)
-                        vote += signMatch(src+((size_t) yn*w+x+1)*N, interpretFillRule(sumR, fillRule), zero);
-                    if (ys > 0) {
-                        const int ynb = flip ? h-1-(ys-1) : ys-1;
-                        vote += signMatch(src+((size_t) ynb*w+x)*N, filledDirect(rec, nE, px, (ys-.5)/t.sy-t.ty, fillRule), zero);
+                const float *in = src+((size_t) yn*w+x)*N;
+                for (int i = 0; i < N; ++i)
+                    v[i] = in[i];
+                if (N == 1) {
+                    if ((v[0] > zero) != fill)
+                        v[0] = twice-v[0];
+                } else {
+                    const int match = signMatch(v, fill, zero);
+                    bool flipRgb = match < 0;
+                    if (match == 0) {
+                        int vote = 0;
+                        if (x > 0)
+                            vote += signMatch(src+((size_t) yn*w+x-1)*N, interpretFillRule(scanlineSumEmu(rowX[ly+1], rowDir[ly+1], (x-.5)/t.sx-t.tx), fillRule), zero);
+                        if (x < w-1)
+                            vote += signMatch(src+((size_t) yn*w+x+1)*N, interpretFillRule(scanlineSumEmu(rowX[ly+1], rowDir[ly+1], (x+1.5)/t.sx-t.tx), fillRule), zero);
+                        if (ys > 0) {
+                            const int ynb = flip ? h-1-(ys-1) : ys-1;
+                            vote += signMatch(src+((size_t) ynb*w+x)*N, interpretFillRule(scanlineSumEmu(rowX[ly], rowDir[ly], px), fillRule), zero);
+                        }
+                        if (ys < h-1) {
+                            const int ynb = flip ? h-1-(ys+1) : ys+1;
+                            vote += signMatch(src+((size_t) ynb*w+x)*N, interpretFillRule(scanlineSumEmu(rowX[ly+2], rowDir[ly+2], px), fillRule), zero);
+                        }
+                        flipRgb = vote < 0;
                     }
-                    if (ys < h-1) {
-                        const int ynb = flip ? h-1-(ys+1) : ys+1;
-                        vote += signMatch(src+((size_t) ynb*w+x)*N, filledDirect(rec, nE, px, (ys+1.5)/t.sy-t.ty, fillRule), zero);
-                    }
-                    flipRgb = vote < 0;
+                    if (flipRgb)
+                        v[0] = twice-v[0], v[1] = twice-v[1], v[2] = twice-v[2];
+                    if (N >= 4 && (v[3] > zero) != fill)
+                        v[3] = twice-v[3];
                 }
-                if (flipRgb)
-                    v[0] = twice-v[0], v[1] = twice-v[1], v[2] = twice-v[2];
-                if (N >= 4 && (v[3] > zero) != fill)
-                    v[3] = twice-v[3];
             }
             float *o = pixels+(ptrdiff_t) rowStride*yn+(ptrdiff_t) N*x;
             for (int i = 0; i < N; ++i)

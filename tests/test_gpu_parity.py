@@ -349,6 +349,27 @@ def test_distance_sign_correction_standalone_vs_oracle(oracle, seed):
         assert (bits(got) == bits(want)).all()
 
 
+def test_distance_sign_correction_many_edges_chunked_lists(oracle):
+    """Shapes with more than 128 edges exceed the per-row list capacity kept in LDS: the kernel then walks the edges in chunks
+    (k_sign_correction). CJK-like glyphs (~100 edges, unchunked), 150-300 edge blobs, the 926-edge cubic logo on a wide bitmap."""
+    rng = np.random.default_rng(77)
+    cases = [(synth.cjk_like_shape(8300+i), 48, 48) for i in range(2)]
+    cases += [(synth.random_shape(8400+i, n_contours=18+4*i, edges_per_contour=(7, 12), kinds=(1, 2, 3)), 40+9*i, 56-7*i) for i in range(3)]
+    cases += [(synth.logo_shape(5), 136, 72)]
+    assert max(s.n_edges for s, _, _ in cases) > 900 and sum(s.n_edges > 128 for s, _, _ in cases) >= 4
+    for s, w, h in cases:
+        xf = autoframe(s.bounds(), w, h, 4)
+        for mode in (1, 3, 4):
+            field = oracle.generate(s, mode, w, h, xf, ec_mode=0)
+            if mode >= 3:
+                field[rng.integers(0, h, 12), rng.integers(0, w, 12)] = .5
+            for rule in (0, 1, 3):
+                want = oracle.sign_correction(s, field, xf, .5, rule)
+                got = M.distance_sign_correction(field.copy(), s, M.SDFTransformation.from_xf(xf), .5, rule)
+                assert (bits(got) == bits(want)).all(), "%d edges mode %d rule %d: %d texels differ" % (s.n_edges, mode, rule, int((bits(got) != bits(want)).sum()))
+        assert (M.rasterize(np.zeros((h, w, 1), np.float32), s, M.SDFTransformation.from_xf(xf), 1) == oracle.rasterize(s, w, h, xf, 1)).all()
+
+
 def test_scanline_pass_pipeline_stays_on_device(latin, oracle):
     """The reference's -scanline flow (main.cpp:1233-1298): generate with the simple combiner and no correction, sign-correct
     against the scanline fill, then msdfErrorCorrection with DO_NOT_CHECK_DISTANCE -- as one batched call, vs the oracle's

@@ -1,0 +1,96 @@
+"""Timings of the BASELINE configs that are NOT the headline bench line (bench.py owns that): each through GlyphBatch.generate on
+one MI355X, inputs/outputs resident in HBM, torch events on the launch stream.  Prints one JSON object per line.
+
+    python tools/bench_configs.py [--reps 10]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(fn, reps, warmup=2):
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b)/reps
+
+
+def kernel_ms(fn):
+    """HIP-event time of the distance kernel and of everything after it (sign pass + error correction) in one call."""
+    import ctypes as C
+    import torch
+    from msdfgen_amd import lib as L
+    lib = L.load()
+    lib.msdfhip_set_kernel_timing(1)
+    lib.msdfhip_kernel_timing(None, None, None, 1)
+    fn()
+    torch.cuda.synchronize()
+    lib.msdfhip_set_kernel_timing(0)
+    kd, kc, kn = C.c_double(), C.c_double(), C.c_int()
+    lib.msdfhip_kernel_timing(C.byref(kd), C.byref(kc), C.byref(kn), 1)
+    return [round(kd.value, 4), round(kc.value, 4)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=10)
+    args = ap.parse_args()
+    import torch  # noqa: F401
+    import msdfgen_amd as M
+    from msdfgen_amd import synth
+    from msdfgen_amd.shape import ShapeBatch, autoframe
+    from bench import load_latin, tile_batch
+    M.init(0)
+    latin, xf64 = load_latin()
+
+    def report(name, batch, mode, w, h, xfs, config=None, reps=args.reps, **kw):
+        gb = M.GlyphBatch(batch)
+        out = torch.empty((batch.n_glyphs, h, w, M.CHANNELS[mode]), dtype=torch.float32, device="cuda")
+        desc = gb.descriptors(xfs, w, h, M.CHANNELS[mode])
+
+        def step():
+            gb.digest()
+            gb.generate(mode, w, h, descriptors=desc, out=out, config=config, **kw)
+        ms = timed(step, reps)
+        km = kernel_ms(step)
+        print(json.dumps({"config": name, "glyphs": batch.n_glyphs, "edges_per_glyph": round(batch.n_edges/batch.n_glyphs, 1),
+                          "contours_per_glyph": round(batch.n_contours/batch.n_glyphs, 2), "tile": [w, h], "mode": mode,
+                          "ms_per_step": round(ms, 3), "glyphs_per_s": round(batch.n_glyphs/ms*1e3), "mtexel_per_s": round(batch.n_glyphs*w*h/ms/1e3),
+                          "kernel_ms_distance_and_post": km}), flush=True)
+        gb.close()
+
+    b, x = tile_batch(latin, xf64, 8192)
+    report("cfg2/3 headline: Basic-Latin msdf 64x64 default EC", b, 3, 64, 64, x)
+    report("cfg3: Basic-Latin mtsdf 64x64 default EC", b, 4, 64, 64, x)
+    report("Basic-Latin sdf 64x64", b, 1, 64, 64, x)
+    report("Basic-Latin psdf 64x64", b, 2, 64, 64, x)
+    report("Basic-Latin msdf 64x64, simple combiner (overlapSupport=false)", b, 3, 64, 64, x, config=M.MSDFGeneratorConfig(False))
+    report("Basic-Latin msdf 64x64, error correction disabled", b, 3, 64, 64, x, config=M.MSDFGeneratorConfig(True, M.ErrorCorrectionConfig(M.EC_DISABLED)))
+    scan = M.MSDFGeneratorConfig(False, M.ErrorCorrectionConfig(M.EC_EDGE_PRIORITY, M.DO_NOT_CHECK_DISTANCE))
+    report("scanline flow (main.cpp:1233-1298): msdf 64x64 simple combiner -> distanceSignCorrection -> EC without distance check", b, 3, 64, 64, x,
+           config=scan, scanline_pass=True)
+    base = [synth.cjk_like_shape(20000+i) for i in range(512)]
+    cj = ShapeBatch.from_shapes([base[i % 512] for i in range(8192)])
+    cx = np.stack([autoframe(s.bounds(), 48, 48, 4) for s in base])[np.arange(8192) % 512]
+    report("cfg4: 8192 CJK-like synthetic glyphs msdf 48x48 default EC", cj, 3, 48, 48, cx, reps=max(2, args.reps//3))
+    logo = synth.logo_shape(5)
+    lb = ShapeBatch.from_shapes([logo])
+    lx = np.stack([autoframe(logo.bounds(), 1024, 1024, 8)])
+    report("cfg5: %d-edge cubic logo msdf 1024x1024 default EC" % logo.n_edges, lb, 3, 1024, 1024, lx, reps=max(2, args.reps//3))
+
+
+if __name__ == "__main__":
+    main()
