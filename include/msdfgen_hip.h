@@ -144,6 +144,17 @@ int msdfhip_rasterize(float *pixels, int width, int height, int row_stride, int 
                       const int32_t *contour_offsets, int n_contours, const double *points, const uint8_t *types, const uint8_t *colors,
                       const double *xf, int fill_rule);
 
+/* Transparent micro-batching of the single-shape entry points above. Host threads that call them concurrently
+ * (msdf-atlas-gen's workers) are combined group-commit style into one device batch per set of calls with equal launch parameters
+ * (mode, size, config); a lone caller never waits. On by default (groups of up to 256 calls, 2 concurrent leaders); the
+ * environment variable MSDFHIP_MICROBATCH=0 or max_group <= 1 turns it off (every call then runs on its own stream).
+ * msdfhip_microbatch_stats: calls served / device batches run / largest group since the last reset. */
+int msdfhip_set_microbatch(int max_group, int max_leaders);
+int msdfhip_microbatch_stats(long long *calls, long long *batches, long long *largest, int reset);
+/* Where the host-pointer calls spend their wall time, summed over device batches since the last reset (milliseconds):
+ * staging the inputs, H2D + kernels + D2H + stream sync, scattering the tiles into the callers' bitmaps. */
+int msdfhip_microbatch_times(double *stage_ms, double *device_ms, double *scatter_ms, int reset);
+
 /* ShapeDistanceFinder<CC<Selector>>::oneShotDistance at n shape-space points (core/ShapeDistanceFinder.hpp:36-58; the
  * per-pixel engine under generate*).  selector = mode 1..4; out receives n*4 doubles (unused channels 0). */
 int msdfhip_shape_distance(int selector, int overlap_support, const int32_t *contour_offsets, int n_contours, const double *points,

@@ -2,7 +2,7 @@
 generateSDF / generatePSDF / generateMSDF / generateMTSDF and the MSDF error-correction pass, behind a C ABI
 (include/msdfgen_hip.h) and this thin host-side mirror of the reference's interface.  There is no CPU compute path."""
 from .shape import FlatShape, ShapeBatch, autoframe, distance_mapping  # noqa: F401
-from .lib import MsdfHipError, load, init, device_info, default_config  # noqa: F401
+from .lib import MsdfHipError, load, init, device_info, default_config, set_microbatch, microbatch_stats  # noqa: F401
 from .api import (  # noqa: F401
     Projection, Range, DistanceMapping, SDFTransformation, ErrorCorrectionConfig, GeneratorConfig, MSDFGeneratorConfig,
     generate_sdf, generate_psdf, generate_msdf, generate_mtsdf, msdf_error_correction, distance_sign_correction, rasterize, shape_distance, contour_windings, GlyphBatch,

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -219,6 +221,9 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
                        : launchDistance<SEL, false, false, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
 }
 
+// Records of the per-glyph candidate segments incl. the header (msdf_kernels.hpp, EcCandidate).
+size_t deferredRecords(int nGlyphs, size_t texelsPerGlyph) { return ecHeaderRecords(nGlyphs)+(size_t) nGlyphs*ecSegment(texelsPerGlyph); }
+
 int ensureDeferred(const MsdfHipBatch *b, size_t cap, EcCandidate **out) {
     std::lock_guard<std::mutex> lock(b->scratchMutex);
     if (b->deferredCap < cap) {
@@ -226,7 +231,7 @@ int ensureDeferred(const MsdfHipBatch *b, size_t cap, EcCandidate **out) {
             hipFree(b->dDeferred);
         b->dDeferred = NULL;
         b->deferredCap = 0;
-        HIPCHK(hipMalloc((void **) &b->dDeferred, (cap+1)*sizeof(EcCandidate)));
+        HIPCHK(hipMalloc((void **) &b->dDeferred, cap*sizeof(EcCandidate)));
         b->deferredCap = cap;
     }
     if (!b->dEcParams)
@@ -262,11 +267,12 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
         const unsigned cap = GRES ? slowGrid : 16384u;
         const unsigned slowBlocks = (unsigned) ((allTexels+WAVE-1)/WAVE < cap ? (allTexels+WAVE-1)/WAVE : cap);
         hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowBlocks), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
-                           (const EcCandidate *) NULL, 0u, 0, gres, gresStride);
+                           (const EcCandidate *) NULL, 0, gres, gresStride);
         HIPCHK(hipGetLastError());
         return MSDFHIP_OK;
     }
-    const size_t cap = allTexels/16 > 4096 ? allTexels/16 : 4096;
+    const unsigned seg = ecSegment((size_t) w*h);                // candidate records per glyph
+    const size_t cap = deferredRecords(b->nGlyphs, (size_t) w*h);
     EcCandidate *deferred = NULL;
     rc = ensureDeferred(b, cap, &deferred);
     if (rc != MSDFHIP_OK)
@@ -274,18 +280,23 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     rc = setLds(k_ec_query<N, OVERLAP, GRES>, slowLds);
     if (rc != MSDFHIP_OK)
         return rc;
-    HIPCHK(hipMemsetAsync(deferred, 0, sizeof(EcCandidate), stream));
+    HIPCHK(hipMemsetAsync(deferred, 0, ecHeaderRecords(b->nGlyphs)*sizeof(EcCandidate), stream));
     const size_t fastLds = (size_t) (b->maxEdges > 0 ? b->maxEdges : 1)*2*sizeof(int);
     rc = setLds(k_ec_fast<N>, fastLds);
     if (rc != MSDFHIP_OK)
         return rc;
+    // query work units: K wavefronts per glyph, each taking every K-th candidate of the glyph (a handful per glyph is typical)
+    unsigned K = (unsigned) ((16384+b->nGlyphs-1)/b->nGlyphs);
+    K = K < 4 ? 4 : K > seg ? seg : K;
+    const size_t units = (size_t) b->nGlyphs*K;
+    const unsigned queryBlocks = (unsigned) (GRES ? (units < queryGrid ? units : queryGrid) : (units < 0x7fffffffull ? units : 0x7fffffffull));
     hipLaunchKernelGGL(k_ec_params, dim3((b->nGlyphs+255)/256), dim3(256), 0, stream, b->dEcParams, dGlyphs, b->nGlyphs, cfg);
     hipLaunchKernelGGL((k_ec_fast<N>), dim3(blocks), dim3(WAVE), fastLds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, src, out, stencil, cfg,
-                       (const EcGlyphParams *) b->dEcParams, deferred, (unsigned) cap);
-    hipLaunchKernelGGL((k_ec_query<N, OVERLAP, GRES>), dim3(queryGrid), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
-                       (const EcCandidate *) deferred, (unsigned) cap, gres, gresStride);
+                       (const EcGlyphParams *) b->dEcParams, deferred, seg);
+    hipLaunchKernelGGL((k_ec_query<N, OVERLAP, GRES>), dim3(queryBlocks), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
+                       (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, K, gres, gresStride);
     hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowGrid), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
-                       (const EcCandidate *) deferred, (unsigned) cap, 1, gres, gresStride);
+                       (const EcCandidate *) deferred, 1, gres, gresStride);
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
 }
@@ -674,75 +685,106 @@ struct Carver {                                                  // 256-byte ali
 
 enum SingleOp { OP_GENERATE = 0, OP_ERROR_CORRECTION = 1, OP_SIGN_CORRECTION = 2, OP_RASTERIZE = 3 };   // what the single-shape call does to `pixels`
 
-static int singleShape(int mode, int channels, int op, float *pixels, int w, int h, int rowStride, int flip,
-                       const int32_t *co, int nC, const double *points, const uint8_t *types, const uint8_t *colors,
-                       const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil) {
-    if (w < 0 || h < 0 || nC < 0 || !co || !xf || (!pixels && w*h > 0))
-        return fail(MSDFHIP_ERR_INVALID, "bad arguments");
-    int rc = checkConfig(cfg);
+// One host-pointer call (generate* / msdfErrorCorrection / distanceSignCorrection / rasterize on one shape and one bitmap).
+struct ShapeCall {
+    int mode, channels, op, w, h, rowStride, flip, nC;
+    float *pixels;
+    const int32_t *co;
+    const double *points;
+    const uint8_t *types, *colors;
+    double xf[6];
+    MsdfHipConfig cfg;
+    uint8_t *stencil;
+    // micro-batcher state (guarded by gQueueMutex)
+    bool claimed, done;
+    int rc;
+    std::string error;
+    std::condition_variable cv;
+};
+
+// Calls can share one launch sequence when everything that is a launch parameter agrees.
+static bool sameLaunch(const ShapeCall &a, const ShapeCall &b) {
+    return a.mode == b.mode && a.channels == b.channels && a.op == b.op && a.w == b.w && a.h == b.h && memcmp(&a.cfg, &b.cfg, sizeof(MsdfHipConfig)) == 0;
+}
+
+static std::atomic<long long> gNsStage(0), gNsDevice(0), gNsScatter(0);
+static long long nowNs() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Runs n compatible calls as ONE device batch on the calling thread's arena: stage all inputs -> one H2D copy -> digest + kernels ->
+// one D2H copy -> scatter the tiles into the callers' bitmaps. n == 1 is the plain single-shape call.
+static int runGroup(ShapeCall *const *calls, int n) {
+    const ShapeCall &c0 = *calls[0];
+    const int mode = c0.mode, channels = c0.channels, op = c0.op, w = c0.w, h = c0.h;
+    const MsdfHipConfig *cfg = &c0.cfg;
+    int rc = ensureDevice();
     if (rc != MSDFHIP_OK)
         return rc;
-    if (w == 0 || h == 0)
-        return MSDFHIP_OK;
-    const bool correctionOnly = op == OP_ERROR_CORRECTION || op == OP_SIGN_CORRECTION;   // the bitmap is an input as well
-    if (op == OP_ERROR_CORRECTION && cfg->ec_mode == MSDFHIP_EC_DISABLED)
-        return MSDFHIP_OK;
-    rc = ensureDevice();
-    if (rc != MSDFHIP_OK)
-        return rc;
-    if (co[0] != 0)
-        return fail(MSDFHIP_ERR_INVALID, "contour_offsets must start at 0");
-    for (int c = 0; c < nC; ++c)
-        if (co[c+1] < co[c])
-            return fail(MSDFHIP_ERR_INVALID, "contour_offsets not monotonic at %d", c);
-    const int nE = co[nC];
-    for (int e = 0; e < nE; ++e)
-        if (types[e] < 1 || types[e] > 3)
-            return fail(MSDFHIP_ERR_INVALID, "edge %d has type %d (must be 1, 2 or 3)", e, (int) types[e]);
+    const bool bitmapIsInput = op == OP_ERROR_CORRECTION || op == OP_SIGN_CORRECTION;
     const bool correct = op <= OP_ERROR_CORRECTION && channels >= 3 && cfg->ec_mode != MSDFHIP_EC_DISABLED;
     const int stages = op == OP_GENERATE ? (correct ? 1 : 0)+(cfg->sign_correction ? 1 : 0) : 0;
+    bool anyStencil = false;
+    size_t sumC = 0, sumE = 0;
+    int maxC = 0, maxE = 0;
+    for (int g = 0; g < n; ++g) {
+        const ShapeCall &c = *calls[g];
+        const int nE = c.co[c.nC];
+        sumC += c.nC, sumE += nE;
+        maxC = c.nC > maxC ? c.nC : maxC, maxE = nE > maxE ? nE : maxE;
+        anyStencil = anyStencil || c.stencil != NULL;
+    }
     const size_t texels = (size_t) w*h, tileBytes = texels*channels*sizeof(float);
-    const size_t eAlloc = nE > 0 ? nE : 1, cAlloc = nC > 0 ? nC : 1;
-    const size_t candCap = texels/16 > 4096 ? texels/16 : 4096;
+    const size_t eAlloc = sumE > 0 ? sumE : 1, cAlloc = sumC > 0 ? sumC : 1;
+    const size_t candCap = deferredRecords(n, texels);
 
     // host staging layout (inputs first: one H2D copy; then the results: one D2H copy)
     Carver hc;
-    const size_t hGco = hc.take(2*sizeof(int32_t)), hCo = hc.take((nC+1)*sizeof(int32_t)), hPts = hc.take(eAlloc*8*sizeof(double));
-    const size_t hTypes = hc.take(eAlloc), hColors = hc.take(eAlloc), hGlyph = hc.take(sizeof(MsdfHipGlyph));
-    const size_t hSrc = correctionOnly ? hc.take(tileBytes) : hc.off;
+    const size_t hGco = hc.take((n+1)*sizeof(int32_t)), hCo = hc.take((sumC+1)*sizeof(int32_t)), hPts = hc.take(eAlloc*8*sizeof(double));
+    const size_t hTypes = hc.take(eAlloc), hColors = hc.take(eAlloc), hGlyph = hc.take(n*sizeof(MsdfHipGlyph));
+    const size_t hSrc = bitmapIsInput ? hc.take(n*tileBytes) : hc.off;
     const size_t inputBytes = hc.off;
-    const size_t hOut = hc.take(tileBytes), hStencil = hc.take(texels);
+    const size_t hOut = hc.take(n*tileBytes), hStencil = hc.take(n*texels);
     const size_t resultBytes = hc.off-hOut;
     // device layout: mirror of the staging area, then device-only work buffers
     Carver dc;
     dc.off = hc.off;
-    const size_t dRecs = dc.take(eAlloc*sizeof(EdgeRec)), dWind = dc.take(cAlloc), dScratch = dc.take(tileBytes*stages);
-    const size_t dCands = dc.take(correct ? (candCap+1)*sizeof(EcCandidate) : 0), dParams = dc.take(sizeof(EcGlyphParams));
+    const size_t dRecs = dc.take(eAlloc*sizeof(EdgeRec)), dWind = dc.take(cAlloc), dScratch = dc.take(n*tileBytes*stages);
+    const size_t dCands = dc.take(correct ? candCap*sizeof(EcCandidate) : 0), dParams = dc.take(n*sizeof(EcGlyphParams));
     ThreadArena &a = tlsArena;
     rc = arenaReserve(a, dc.off, hc.off);
     if (rc != MSDFHIP_OK)
         return rc;
 
-    int32_t *gco = reinterpret_cast<int32_t *>(a.pinned+hGco);
-    gco[0] = 0, gco[1] = nC;
-    memcpy(a.pinned+hCo, co, (nC+1)*sizeof(int32_t));
-    if (nE) {
-        memcpy(a.pinned+hPts, points, (size_t) nE*8*sizeof(double));
-        memcpy(a.pinned+hTypes, types, nE);
-        memcpy(a.pinned+hColors, colors, nE);
-    }
+    const long long t0 = nowNs();
+    int32_t *gco = reinterpret_cast<int32_t *>(a.pinned+hGco), *co = reinterpret_cast<int32_t *>(a.pinned+hCo);
     MsdfHipGlyph *gd = reinterpret_cast<MsdfHipGlyph *>(a.pinned+hGlyph);
-    memcpy(gd->xf, xf, sizeof(gd->xf));
-    gd->out_offset = 0;
-    gd->row_stride = w*channels;                                 // the device tile is tightly packed in memory-row order
-    gd->flip = flip ? 1 : 0;
-    if (correctionOnly)
-        for (int y = 0; y < h; ++y)
-            memcpy(a.pinned+hSrc+(size_t) y*w*channels*sizeof(float), pixels+(ptrdiff_t) rowStride*y, sizeof(float)*(size_t) w*channels);
+    size_t cAt = 0, eAt = 0;
+    co[0] = 0;
+    for (int g = 0; g < n; ++g) {
+        const ShapeCall &c = *calls[g];
+        const int nE = c.co[c.nC];
+        gco[g] = (int32_t) cAt;
+        for (int k = 1; k <= c.nC; ++k)
+            co[cAt+k] = (int32_t) (eAt+c.co[k]);
+        if (nE) {
+            memcpy(a.pinned+hPts+eAt*8*sizeof(double), c.points, (size_t) nE*8*sizeof(double));
+            memcpy(a.pinned+hTypes+eAt, c.types, nE);
+            memcpy(a.pinned+hColors+eAt, c.colors, nE);
+        }
+        cAt += c.nC, eAt += nE;
+        memcpy(gd[g].xf, c.xf, sizeof(gd[g].xf));
+        gd[g].out_offset = (int64_t) ((size_t) g*texels*channels);   // the device tiles are tightly packed in memory-row order
+        gd[g].row_stride = w*channels;
+        gd[g].flip = c.flip ? 1 : 0;
+        if (bitmapIsInput)
+            for (int y = 0; y < h; ++y)
+                memcpy(a.pinned+hSrc+((size_t) g*texels+(size_t) y*w)*channels*sizeof(float), c.pixels+(ptrdiff_t) c.rowStride*y, sizeof(float)*(size_t) w*channels);
+    }
+    gco[n] = (int32_t) cAt;
+    const long long t1 = nowNs();
     HIPCHK(hipMemcpyAsync(a.dev, a.pinned, inputBytes, hipMemcpyHostToDevice, a.stream));
 
     MsdfHipBatch b;                                              // non-owning view into the arena
-    b.nGlyphs = 1, b.nContours = nC, b.nEdges = nE, b.maxContours = nC, b.maxEdges = nE;
+    b.nGlyphs = n, b.nContours = (int) sumC, b.nEdges = (int) sumE, b.maxContours = maxC, b.maxEdges = maxE;
     b.ownsInputs = false;
     b.dGlyphContourOffsets = reinterpret_cast<int32_t *>(a.dev+hGco);
     b.dContourOffsets = reinterpret_cast<int32_t *>(a.dev+hCo);
@@ -758,7 +800,7 @@ static int singleShape(int mode, int channels, int op, float *pixels, int w, int
     b.dGres = NULL, b.gresBytes = 0;
     const MsdfHipGlyph *dGlyph = reinterpret_cast<const MsdfHipGlyph *>(a.dev+hGlyph);
     float *dOut = reinterpret_cast<float *>(a.dev+hOut);
-    uint8_t *dStencil = stencil ? reinterpret_cast<uint8_t *>(a.dev+hStencil) : NULL;
+    uint8_t *dStencil = anyStencil ? reinterpret_cast<uint8_t *>(a.dev+hStencil) : NULL;
 
     rc = digest(&b, a.stream);
     if (rc == MSDFHIP_OK) {
@@ -775,14 +817,159 @@ static int singleShape(int mode, int channels, int op, float *pixels, int w, int
         hipStreamSynchronize(a.stream);
         return rc;
     }
-    HIPCHK(hipMemcpyAsync(a.pinned+hOut, a.dev+hOut, stencil ? resultBytes : tileBytes, hipMemcpyDeviceToHost, a.stream));
+    HIPCHK(hipMemcpyAsync(a.pinned+hOut, a.dev+hOut, anyStencil ? resultBytes : n*tileBytes, hipMemcpyDeviceToHost, a.stream));
     HIPCHK(hipStreamSynchronize(a.stream));
-    const float *tile = reinterpret_cast<const float *>(a.pinned+hOut);
-    for (int y = 0; y < h; ++y)
-        memcpy(pixels+(ptrdiff_t) rowStride*y, tile+(size_t) y*w*channels, sizeof(float)*(size_t) w*channels);
-    if (stencil)
-        memcpy(stencil, a.pinned+hStencil, texels);
+    const long long t2 = nowNs();
+    for (int g = 0; g < n; ++g) {
+        const ShapeCall &c = *calls[g];
+        const float *tile = reinterpret_cast<const float *>(a.pinned+hOut)+(size_t) g*texels*channels;
+        for (int y = 0; y < h; ++y)
+            memcpy(c.pixels+(ptrdiff_t) c.rowStride*y, tile+(size_t) y*w*channels, sizeof(float)*(size_t) w*channels);
+        if (c.stencil)
+            memcpy(c.stencil, a.pinned+hStencil+(size_t) g*texels, texels);
+    }
+    gNsStage += t1-t0, gNsDevice += t2-t1, gNsScatter += nowNs()-t2;
     return MSDFHIP_OK;
+}
+
+// ---- transparent micro-batching ---------------------------------------------------------------------------
+// Callers such as msdf-atlas-gen's worker threads each call generateMSDF for one glyph at a time. A single call is bound by launch
+// and PCIe latency (~150 us), not by the GPU. Concurrent calls are therefore combined, group-commit style: a call that finds a
+// free leader slot runs at once (no waiting, no timer: a lone caller never pays for the mechanism); calls that arrive while the
+// leaders are busy queue up, and the next leader takes every queued call with the same launch parameters along as one device
+// batch. Results do not depend on the grouping (glyphs are independent).
+static std::mutex gQueueMutex;
+static std::vector<ShapeCall *> gQueue;                          // arrival order; claimed entries belong to a running leader
+static int gActiveLeaders = 0;
+static std::atomic<int> gMaxGroup(-1), gMaxLeaders(2);
+static std::atomic<long long> gStatCalls(0), gStatBatches(0), gStatLargest(0);
+static const size_t GROUP_BYTES_LIMIT = 256u<<20;                // tiles of one group (bounds the per-thread arena)
+
+static int maxGroup() {
+    int v = gMaxGroup.load();
+    if (v < 0) {
+        const char *env = getenv("MSDFHIP_MICROBATCH");          // 0 disables; N > 1 caps the group size
+        v = env ? atoi(env) : 256;
+        if (v < 1)
+            v = 1;
+        gMaxGroup.store(v);
+    }
+    return v;
+}
+
+static ShapeCall *firstUnclaimed() {
+    for (size_t i = 0; i < gQueue.size(); ++i)
+        if (!gQueue[i]->claimed)
+            return gQueue[i];
+    return NULL;
+}
+
+static int submitCall(ShapeCall &c) {
+    const int cap = maxGroup();
+    if (cap <= 1) {
+        ShapeCall *one = &c;
+        ++gStatCalls, ++gStatBatches;
+        return runGroup(&one, 1);
+    }
+    std::vector<ShapeCall *> group;
+    {
+        std::unique_lock<std::mutex> lock(gQueueMutex);
+        c.claimed = c.done = false;
+        gQueue.push_back(&c);
+        while (!c.done && !(gActiveLeaders < gMaxLeaders.load() && firstUnclaimed() == &c))
+            c.cv.wait(lock);
+        if (c.done) {
+            if (c.rc != MSDFHIP_OK)
+                tlsError = c.error;
+            return c.rc;
+        }
+        const size_t tileBytes = (size_t) c.w*c.h*c.channels*sizeof(float);
+        for (size_t i = 0; i < gQueue.size() && (int) group.size() < cap; ++i) {
+            ShapeCall *q = gQueue[i];
+            if (!q->claimed && (q == &c || (sameLaunch(*q, c) && (group.size()+1)*tileBytes <= GROUP_BYTES_LIMIT))) {
+                q->claimed = true;
+                group.push_back(q);
+            }
+        }
+        ++gActiveLeaders;
+        if (gActiveLeaders < gMaxLeaders.load())
+            if (ShapeCall *next = firstUnclaimed())
+                next->cv.notify_one();                           // a second leader may start on what is left
+    }
+    int rc = runGroup(group.data(), (int) group.size());
+    gStatCalls += (long long) group.size();
+    ++gStatBatches;
+    for (long long seen = gStatLargest.load(); (long long) group.size() > seen && !gStatLargest.compare_exchange_weak(seen, (long long) group.size()); ) { }
+    std::string error = rc != MSDFHIP_OK ? tlsError : std::string();
+    std::vector<int> rcs(group.size(), rc);
+    std::vector<std::string> errors(group.size(), error);
+    if (rc != MSDFHIP_OK && group.size() > 1)                    // attribute the failure: rerun the members one by one
+        for (size_t i = 0; i < group.size(); ++i) {
+            rcs[i] = runGroup(&group[i], 1);
+            errors[i] = rcs[i] != MSDFHIP_OK ? tlsError : std::string();
+        }
+    int mine = MSDFHIP_OK;
+    {
+        std::unique_lock<std::mutex> lock(gQueueMutex);
+        for (size_t i = 0; i < group.size(); ++i) {
+            ShapeCall *q = group[i];
+            for (size_t k = 0; k < gQueue.size(); ++k)
+                if (gQueue[k] == q) {
+                    gQueue.erase(gQueue.begin()+k);
+                    break;
+                }
+            if (q == &c) {
+                mine = rcs[i];
+                if (mine != MSDFHIP_OK)
+                    tlsError = errors[i];
+            } else {
+                q->rc = rcs[i];
+                q->error = errors[i];
+                q->done = true;
+                q->cv.notify_one();
+            }
+        }
+        --gActiveLeaders;
+        if (ShapeCall *next = firstUnclaimed())
+            next->cv.notify_one();
+    }
+    return mine;
+}
+
+static int singleShape(int mode, int channels, int op, float *pixels, int w, int h, int rowStride, int flip,
+                       const int32_t *co, int nC, const double *points, const uint8_t *types, const uint8_t *colors,
+                       const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil) {
+    if (w < 0 || h < 0 || nC < 0 || !co || !xf || (!pixels && w*h > 0))
+        return fail(MSDFHIP_ERR_INVALID, "bad arguments");
+    int rc = checkConfig(cfg);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    if (w == 0 || h == 0)
+        return MSDFHIP_OK;
+    if (op == OP_ERROR_CORRECTION && cfg->ec_mode == MSDFHIP_EC_DISABLED)
+        return MSDFHIP_OK;
+    rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    if (co[0] != 0)
+        return fail(MSDFHIP_ERR_INVALID, "contour_offsets must start at 0");
+    for (int c = 0; c < nC; ++c)
+        if (co[c+1] < co[c])
+            return fail(MSDFHIP_ERR_INVALID, "contour_offsets not monotonic at %d", c);
+    const int nE = co[nC];
+    if (nE > 0 && (!points || !types || !colors))
+        return fail(MSDFHIP_ERR_INVALID, "NULL edge arrays");
+    for (int e = 0; e < nE; ++e)
+        if (types[e] < 1 || types[e] > 3)
+            return fail(MSDFHIP_ERR_INVALID, "edge %d has type %d (must be 1, 2 or 3)", e, (int) types[e]);
+    ShapeCall c;
+    c.mode = mode, c.channels = channels, c.op = op, c.w = w, c.h = h, c.rowStride = rowStride, c.flip = flip ? 1 : 0, c.nC = nC;
+    c.pixels = pixels, c.co = co, c.points = points, c.types = types, c.colors = colors, c.stencil = stencil;
+    memcpy(c.xf, xf, sizeof(c.xf));
+    c.cfg = *cfg;
+    c.claimed = c.done = false;
+    c.rc = MSDFHIP_OK;
+    return submitCall(c);
 }
 
 int msdfhip_generate(int mode, float *pixels, int w, int h, int rowStride, int flip, const int32_t *co, int nC, const double *points,
@@ -832,6 +1019,32 @@ int msdfhip_distance_sign_correction(int channels, float *pixels, int w, int h, 
     cfg.sign_correction = 1, cfg.fill_rule = fillRule, cfg.sdf_zero_value = zero;
     const double xf6[6] = { xf[0], xf[1], xf[2], xf[3], 1., 0. };  // the distance mapping plays no role here
     return singleShape(channels, channels, OP_SIGN_CORRECTION, pixels, w, h, rowStride, flip, co, nC, points, types, colors, xf6, &cfg, NULL);
+}
+
+int msdfhip_set_microbatch(int maxGroup_, int maxLeaders) {
+    if (maxGroup_ < 0 || maxLeaders < 1)
+        return fail(MSDFHIP_ERR_INVALID, "msdfhip_set_microbatch(%d, %d)", maxGroup_, maxLeaders);
+    gMaxGroup.store(maxGroup_ < 1 ? 1 : maxGroup_);
+    gMaxLeaders.store(maxLeaders);
+    return MSDFHIP_OK;
+}
+
+int msdfhip_microbatch_stats(long long *calls, long long *batches, long long *largest, int reset) {
+    if (calls) *calls = gStatCalls.load();
+    if (batches) *batches = gStatBatches.load();
+    if (largest) *largest = gStatLargest.load();
+    if (reset)
+        gStatCalls = 0, gStatBatches = 0, gStatLargest = 0;
+    return MSDFHIP_OK;
+}
+
+int msdfhip_microbatch_times(double *stageMs, double *deviceMs, double *scatterMs, int reset) {
+    if (stageMs) *stageMs = gNsStage.load()*1e-6;
+    if (deviceMs) *deviceMs = gNsDevice.load()*1e-6;
+    if (scatterMs) *scatterMs = gNsScatter.load()*1e-6;
+    if (reset)
+        gNsStage = 0, gNsDevice = 0, gNsScatter = 0;
+    return MSDFHIP_OK;
 }
 
 int msdfhip_rasterize(float *pixels, int w, int h, int rowStride, int flip, const int32_t *co, int nC, const double *points,

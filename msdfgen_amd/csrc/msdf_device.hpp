@@ -691,18 +691,26 @@ struct EdgesCulled {                    // survivors of the per-tile cull (msdf_
     MSDF_HD int at(int k) const { return list ? MSDF_UNIFORM(list[k]) : k; }   // uniform index -> scalar loads of the record
 };
 
+// Feeds contour c's edges to the selector, in visit order (ShapeDistanceFinder.hpp:45-57). The default walks them one after the
+// other in every lane; an Edges policy may provide its own (msdf_kernels.hpp: lanes = edges for a wave-uniform query point).
+template <int SEL, class Edges>
+MSDF_HD void selAddContourSerial(Selector<SEL> &sel, const EdgeRec *rec, const Edges &edges, int c, V2 o) {
+    const int e = edges.end(c);
+    for (int k = edges.begin(c); k < e; ++k) {
+        const int i = edges.at(k);
+        if (MSDF_WAVE_ANY(selEdgeRelevant(sel, rec[i], o)))
+            selAddEdge(sel, rec[i], i, o);
+    }
+}
+template <int SEL> MSDF_HD void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, const EdgesAll &edges, int c, V2 o) { selAddContourSerial(sel, rec, edges, c, o); }
+template <int SEL> MSDF_HD void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, const EdgesCulled &edges, int c, V2 o) { selAddContourSerial(sel, rec, edges, c, o); }
+
 template <int SEL, class Edges>
 MSDF_HD void shapeDistanceSimple(const EdgeRec *rec, const Edges &edges, int C, V2 o, double *out) { // contour-combiners.cpp:34-50
     Selector<SEL> sel;
     selInit(sel);
-    for (int c = 0; c < C; ++c) {
-        const int e = edges.end(c);
-        for (int k = edges.begin(c); k < e; ++k) {
-            const int i = edges.at(k);
-            if (MSDF_WAVE_ANY(selEdgeRelevant(sel, rec[i], o)))
-                selAddEdge(sel, rec[i], i, o);
-        }
-    }
+    for (int c = 0; c < C; ++c)
+        selAddContour(sel, rec, edges, c, o);
     selDistance(sel, rec, o, out);
 }
 
@@ -722,12 +730,7 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
     for (int c = 0; c < C; ++c) {
         Selector<SEL> sel;
         selInit(sel);
-        const int e = edges.end(c);
-        for (int k = edges.begin(c); k < e; ++k) {
-            const int i = edges.at(k);
-            if (MSDF_WAVE_ANY(selEdgeRelevant(sel, rec[i], o)))
-                selAddEdge(sel, rec[i], i, o);
-        }
+        selAddContour(sel, rec, edges, c, o);
         double d[NCH];
         selDistance(sel, rec, o, d);
         for (int ch = 0; ch < NCH; ++ch)

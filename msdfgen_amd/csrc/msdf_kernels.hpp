@@ -279,8 +279,66 @@ struct PsdfQuery {                                                  // ShapeDist
     }
 };
 
-// One deferred distance check: texel (packed index), neighbour direction and interpolation parameter. cands[0] is the header
-// (texel = number of candidates pushed so far, zeroed by the host before k_ec_fast); records start at cands[1].
+// Edge policy for a WAVE-UNIFORM query point: the 64 lanes evaluate 64 edges of the contour at once, then the single-edge selector
+// states are merged across lanes in visit order. pbMerge keeps the earlier state on ties exactly like the sequential pbAddTrue
+// (strict SignedDistance <, edge-selectors.cpp:81-87, :96-106) and max/min of the perpendicular distances do not depend on the
+// order, so the merged state -- identical in every lane afterwards -- equals the sequential one bit for bit.
+struct EdgesCooperative {
+    const int32_t *coff;
+    int lane;
+    MSDF_HD int begin(int c) const { return coff[c]-coff[0]; }
+    MSDF_HD int end(int c) const { return coff[c+1]-coff[0]; }
+};
+
+__device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const EdgesCooperative &edges, int c, V2 o) {
+    const int e = edges.end(c);
+    for (int base = edges.begin(c); base < e; base += WAVE) {
+        Selector<2> mine;
+        selInit(mine);
+        const int i = base+edges.lane;
+        if (i < e)
+            selAddEdge(mine, rec[i], i, o);
+        PB &m = mine.c[0];
+        MSDF_UNROLL
+        for (int off = 1; off < WAVE; off <<= 1) {                  // lane l <- merge(l, l+off): the lower lane is the earlier edge
+            PB other;
+            other.td = __shfl_down(m.td, off), other.tdot = __shfl_down(m.tdot, off);
+            other.neg = __shfl_down(m.neg, off), other.pos = __shfl_down(m.pos, off);
+            other.param = __shfl_down(m.param, off), other.near = __shfl_down(m.near, off);
+            if (edges.lane+off < WAVE)
+                pbMerge(m, other);
+        }
+        PB all;                                                     // lane 0 holds the chunk's state: broadcast
+        all.td = __shfl(m.td, 0), all.tdot = __shfl(m.tdot, 0), all.neg = __shfl(m.neg, 0), all.pos = __shfl(m.pos, 0);
+        all.param = __shfl(m.param, 0), all.near = __shfl(m.near, 0);
+        pbMerge(sel.c[0], all);                                     // chunks in order; the running state is the earlier one
+    }
+}
+
+template <bool OVERLAP>
+struct PsdfQueryCooperative {                                       // same query, all 64 lanes working on ONE point
+    const EdgeRec *rec;
+    const int32_t *coff;
+    const int8_t *windings;
+    int C, lane;
+    double *res;
+    __device__ double operator()(V2 q) const {
+        double out[1];
+        EdgesCooperative edges;
+        edges.coff = coff, edges.lane = lane;
+        if (OVERLAP)
+            shapeDistanceOverlap<2>(rec, edges, windings, C, q, res, WAVE, out);
+        else
+            shapeDistanceSimple<2>(rec, edges, C, q, out);
+        return out[0];
+    }
+};
+
+// One deferred distance check: texel (packed index), neighbour direction and interpolation parameter.
+// The list is segmented per glyph so that the query kernel runs one glyph per wavefront (uniform edge loop, scalar record loads):
+//   header  unsigned[1+G]   [0] = overflow flag (some glyph's segment was full), [1+g] = candidates pushed for glyph g
+//   records EcCandidate[G][seg], starting ecHeaderRecords(G) records into the buffer.
+// The host zeroes the header before k_ec_fast.
 struct EcCandidate {
     unsigned texel;
     int dir;          // (dx+1) | (dy+1)<<2
@@ -288,16 +346,22 @@ struct EcCandidate {
 };
 static_assert(sizeof(EcCandidate) == 16, "EcCandidate layout");
 
+MSDF_HD size_t ecHeaderRecords(int nGlyphs) { return ((size_t) (nGlyphs+1)*sizeof(unsigned)+sizeof(EcCandidate)-1)/sizeof(EcCandidate); }
+MSDF_HD unsigned ecSegment(size_t texelsPerGlyph) { return (unsigned) (texelsPerGlyph/16 > 64 ? (texelsPerGlyph/16+63)/64*64 : 64); }
+
 struct CandidateSink {
-    EcCandidate *cands;
-    unsigned capacity, texel;
+    unsigned *header;           // [0] overflow, [1+g] counts
+    EcCandidate *segment;       // this glyph's records
+    unsigned seg, texel;
+    int g;
     __device__ void operator()(double t, int dx, int dy) {
-        const unsigned slot = atomicAdd(&cands[0].texel, 1u);
-        if (slot < capacity) {
+        const unsigned slot = atomicAdd(&header[1+g], 1u);
+        if (slot < seg) {
             EcCandidate c;
             c.texel = texel, c.dir = (dx+1)|((dy+1)<<2), c.t = t;
-            cands[1+slot] = c;
-        }
+            segment[slot] = c;
+        } else
+            header[0] = 1u;
     }
 };
 
@@ -332,7 +396,7 @@ __global__ void k_ec_params(EcGlyphParams *out, const MsdfHipGlyph *glyphs, int 
 template <int N>
 __global__ void __launch_bounds__(WAVE)
 k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph,
-          const float *src, float *out, uint8_t *stencilOut, MsdfHipConfig cfg, const EcGlyphParams *glyphParams, EcCandidate *cands, unsigned capacity) {
+          const float *src, float *out, uint8_t *stencilOut, MsdfHipConfig cfg, const EcGlyphParams *glyphParams, EcCandidate *cands, unsigned seg) {
     extern __shared__ int smemCorners[];                            // (l, b) per colour-change corner of the glyph
     const GlyphWork wk = decodeBlock(batch.nGlyphs, tilesPerGlyph);
     if (!wk.valid)
@@ -378,7 +442,9 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
     sdf.w = width, sdf.h = height, sdf.N = N, sdf.flip = gd.flip;
     const size_t texel = ((size_t) wk.g*height+yn)*width+x;
     CandidateSink sink;
-    sink.cands = cands, sink.capacity = capacity, sink.texel = (unsigned) texel;
+    sink.header = reinterpret_cast<unsigned *>(cands);
+    sink.segment = cands+ecHeaderRecords(batch.nGlyphs)+(size_t) wk.g*seg;
+    sink.seg = seg, sink.texel = (unsigned) texel, sink.g = wk.g;
     int st = ecTexelFast(sdf, p, smemCorners, nCorners, x, yn, sink);
     const float *in = sdf.native(x, yn);
     float v[N];
@@ -396,25 +462,28 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
         stencilOut[texel] = (uint8_t) st;
 }
 
-// The deferred distance checks, one lane per candidate (all lanes run exactly one PSDF query: convergent). A candidate that
-// turns out to be an artifact flags its texel: rgb := median (apply, MSDFErrorCorrection.cpp:459-479), stencil |= ERROR. Several
-// candidates of one texel write identical values.
+// The deferred distance checks: a wavefront takes candidates of ONE glyph, one candidate at a time, and its 64 lanes evaluate the
+// glyph's edges in parallel (EdgesCooperative) -- a candidate costs one round per contour instead of a serial walk over all edges.
+// Work unit = (glyph, k): the unit handles candidates k, k+K, ... of the glyph's segment. A candidate that turns out to be an artifact flags its texel: rgb := median (apply,
+// MSDFErrorCorrection.cpp:459-479), stencil |= ERROR. Several candidates of one texel write identical values.
 template <int N, bool OVERLAP, bool GRES = false>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(WAVE, 2)
 k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, const float *src, float *out, uint8_t *stencilOut,
-           MsdfHipConfig cfg, const EcCandidate *cands, unsigned capacity, double *gres, size_t gresStride) {
+           MsdfHipConfig cfg, const EcGlyphParams *glyphParams, const EcCandidate *cands, unsigned seg, unsigned K, double *gres, size_t gresStride) {
     extern __shared__ double smemLds[];                             // [maxContours][64] combiner scratch (overlap only)
     double *smem = GRES ? gres+(size_t) blockIdx.x*gresStride : smemLds;
-    const unsigned count = cands[0].texel;
-    if (count > capacity)
+    const unsigned *header = reinterpret_cast<const unsigned *>(cands);
+    if (header[0])
         return;                                                     // overflow: k_ec_slow redoes every texel
     const size_t texelsPerGlyph = (size_t) width*height;
-    for (size_t i = (size_t) blockIdx.x*WAVE+threadIdx.x; i < count; i += (size_t) gridDim.x*WAVE) {
-        const EcCandidate cand = cands[1+i];
-        const size_t texel = cand.texel;
-        const int g = (int) (texel/texelsPerGlyph);
-        const int rem = (int) (texel%texelsPerGlyph);
-        const int yn = rem/width, x = rem%width;
+    const size_t units = (size_t) batch.nGlyphs*K;
+    for (size_t unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        const int g = (int) (unit/K);
+        const unsigned k = (unsigned) (unit-(size_t) g*K);
+        const unsigned count = header[1+g];
+        if (k >= count)
+            continue;
+        const EcCandidate *segment = cands+ecHeaderRecords(batch.nGlyphs)+(size_t) g*seg;
         const int c0 = batch.glyphContourOffsets[g], C = batch.glyphContourOffsets[g+1]-c0;
         const int32_t *coff = batch.contourOffsets+c0;
         const MsdfHipGlyph gd = glyphs[g];
@@ -423,20 +492,29 @@ k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, c
         p.minDeviationRatio = cfg.min_deviation_ratio;
         p.minImproveRatio = cfg.min_improve_ratio;
         p.mode = cfg.ec_mode, p.distanceCheck = cfg.ec_distance_check, p.overlap = OVERLAP, p.stageLimit = 0;
-        ecDerive(p);
+        const EcGlyphParams gp = glyphParams[g];
+        p.hSpan = gp.hSpan, p.vSpan = gp.vSpan, p.dSpan = gp.dSpan, p.texelX = gp.texelX, p.texelY = gp.texelY;
+        p.radiusH = gp.radiusH, p.radiusV = gp.radiusV, p.radiusD = gp.radiusD;
         SdfView sdf;
         sdf.px = src+(size_t) g*texelsPerGlyph*N;
         sdf.w = width, sdf.h = height, sdf.N = N, sdf.flip = gd.flip;
-        PsdfQuery<OVERLAP> query;
-        query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.res = smem+threadIdx.x;
-        const int ys = gd.flip ? height-1-yn : yn;
-        if (ecEvaluateCandidate(sdf, p, x, ys, cand.t, (cand.dir&3)-1, ((cand.dir>>2)&3)-1, query)) {
-            const float *in = sdf.native(x, yn);
-            const float m = medianf(in[0], in[1], in[2]);
-            float *px = out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
-            px[0] = m, px[1] = m, px[2] = m;
-            if (stencilOut)
-                stencilOut[texel] |= (uint8_t) EC_ERROR;
+        PsdfQueryCooperative<OVERLAP> query;
+        query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.lane = threadIdx.x;
+        query.res = smem+threadIdx.x;
+        for (unsigned i = k; i < count; i += K) {                    // one candidate at a time, the wavefront shares its edges
+            const EcCandidate cand = segment[i];
+            const size_t texel = cand.texel;
+            const int rem = (int) (texel-(size_t) g*texelsPerGlyph);
+            const int yn = rem/width, x = rem%width;
+            const int ys = gd.flip ? height-1-yn : yn;
+            if (ecEvaluateCandidate(sdf, p, x, ys, cand.t, (cand.dir&3)-1, ((cand.dir>>2)&3)-1, query) && threadIdx.x == 0) {
+                const float *in = sdf.native(x, yn);
+                const float m = medianf(in[0], in[1], in[2]);
+                float *px = out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
+                px[0] = m, px[1] = m, px[2] = m;
+                if (stencilOut)
+                    stencilOut[texel] |= (uint8_t) EC_ERROR;
+            }
         }
     }
 }
@@ -446,13 +524,13 @@ k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, c
 template <int N, bool OVERLAP, bool GRES = false>
 __global__ void __launch_bounds__(WAVE)
 k_ec_slow(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, const float *src, float *out, uint8_t *stencilOut,
-          MsdfHipConfig cfg, const EcCandidate *cands, unsigned capacity, int overflowOnly, double *gres, size_t gresStride) {
+          MsdfHipConfig cfg, const EcCandidate *cands, int overflowOnly, double *gres, size_t gresStride) {
     extern __shared__ double smemLds[];                             // [maxContours][64] combiner scratch (overlap only)
     double *smem = GRES ? gres+(size_t) blockIdx.x*gresStride : smemLds;
     const size_t texelsPerGlyph = (size_t) width*height;
     const size_t allTexels = texelsPerGlyph*batch.nGlyphs;
-    if (overflowOnly && cands[0].texel <= capacity)
-        return;                                                     // the candidate list held everything: k_ec_query did the job
+    if (overflowOnly && reinterpret_cast<const unsigned *>(cands)[0] == 0)
+        return;                                                     // the candidate segments held everything: k_ec_query did the job
     for (size_t i = (size_t) blockIdx.x*WAVE+threadIdx.x; i < allTexels; i += (size_t) gridDim.x*WAVE) {
         const size_t texel = i;
         const int g = (int) (texel/texelsPerGlyph);

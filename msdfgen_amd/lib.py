@@ -59,6 +59,9 @@ _PROTOS = {
     "msdfhip_error_correction": (C.c_int, [C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int] + _SHAPE_ARGS + [_dp, C.POINTER(Config), _bp]),
     "msdfhip_distance_sign_correction": (C.c_int, [C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int] + _SHAPE_ARGS + [_dp, C.c_float, C.c_int]),
     "msdfhip_rasterize": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int] + _SHAPE_ARGS + [_dp, C.c_int]),
+    "msdfhip_set_microbatch": (C.c_int, [C.c_int, C.c_int]),
+    "msdfhip_microbatch_stats": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]),
+    "msdfhip_microbatch_times": (C.c_int, [_dp, _dp, _dp, C.c_int]),
     "msdfhip_shape_distance": (C.c_int, [C.c_int, C.c_int] + _SHAPE_ARGS + [C.c_int, _dp, _dp]),
     "msdfhip_batch_create": (C.c_int, [C.POINTER(_vp), C.c_int, _ip, _ip, _dp, _bp, _bp]),
     "msdfhip_batch_create_device": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -137,3 +140,16 @@ def device_info():
 
 def ptr(a, t):
     return a.ctypes.data_as(t)
+
+
+def set_microbatch(max_group=256, max_leaders=2):
+    """Micro-batching of concurrent single-shape calls (msdfgen_hip.h). max_group <= 1 disables it."""
+    check(load().msdfhip_set_microbatch(int(max_group), int(max_leaders)))
+
+
+def microbatch_stats(reset=False):
+    a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+    x, y, z = C.c_double(), C.c_double(), C.c_double()
+    check(load().msdfhip_microbatch_times(C.byref(x), C.byref(y), C.byref(z), int(reset)))
+    check(load().msdfhip_microbatch_stats(C.byref(a), C.byref(b), C.byref(c), int(reset)))
+    return {"calls": a.value, "batches": b.value, "largest": c.value, "stage_ms": round(x.value, 3), "device_ms": round(y.value, 3), "scatter_ms": round(z.value, 3)}

@@ -322,6 +322,60 @@ def test_concurrent_host_threads(latin, oracle):
     assert not errors, errors
 
 
+def test_micro_batched_concurrent_calls_mixed_parameters(latin, oracle):
+    """concurrent single-shape calls are combined into device batches per (mode, size, config). 24 host threads
+    issue different kinds of calls at once (msdf 64x64, mtsdf 40x40 Y-down with stencil, sdf 32x32, standalone sign correction,
+    one thread with an invalid shape); every result must equal the oracle's, the bad call must fail alone, and the outcome must
+    not depend on whether batching is enabled."""
+    batch, xf64, bounds = latin
+    xf40 = [autoframe(b, 40, 40, 4) for b in bounds]
+    xf32 = [autoframe(b, 32, 32, 4) for b in bounds]
+    errors, failures = [], []
+
+    def work(t):
+        try:
+            for i in range(6):
+                g = (5*t+i) % batch.n_glyphs
+                s = batch.shape(g)
+                kind = t % 4
+                if t == 23:
+                    bad = FlatShape(s.contour_offsets, s.points, s.types.copy(), s.colors)
+                    bad.types[:] = 9                                            # past the Python-side validation: the C ABI must reject it
+                    try:
+                        gen(3, bad, 64, 64, xf64[g])
+                        errors.append("invalid edge type accepted")
+                    except M.MsdfHipError as e:
+                        failures.append(e.code)
+                elif kind == 0:
+                    close(gen(3, s, 64, 64, xf64[g]), oracle.generate(s, 3, 64, 64, xf64[g]), "msdf %d" % g)
+                elif kind == 1:
+                    st, want_st = np.zeros((40, 40), np.uint8), np.zeros((40, 40), np.uint8)
+                    got = gen(4, s, 40, 40, xf40[g], cfg(buffer=st), y_down=True)
+                    close(got, oracle.generate(s, 4, 40, 40, xf40[g], y_down=True, stencil=want_st), "mtsdf %d" % g)
+                    assert (st == want_st[::-1]).all()
+                elif kind == 2:
+                    close(gen(1, s, 32, 32, xf32[g]), oracle.generate(s, 1, 32, 32, xf32[g]), "sdf %d" % g)
+                else:
+                    f = oracle.generate(s, 3, 32, 32, xf32[g], ec_mode=0)
+                    got = M.distance_sign_correction((1-f).copy(), s, M.SDFTransformation.from_xf(xf32[g]), .5, M.FILL_ODD)
+                    assert (bits(got) == bits(oracle.sign_correction(s, 1-f, xf32[g], .5, 1))).all()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    for enabled in (True, False):
+        M.set_microbatch(256 if enabled else 1, 2)
+        M.microbatch_stats(reset=True)
+        del failures[:]
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(24)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        st = M.microbatch_stats()
+        print("micro-batching %s: %s" % ("on" if enabled else "off", st))
+        assert not errors, errors[:3]
+        assert failures == [M.lib.ERR_INVALID]*6
+        assert st["calls"] == 23*6 and (enabled or st["batches"] == st["calls"])
+    M.set_microbatch(256, 2)
+
+
 # ---- SURVEY.md 8(f1): distanceSignCorrection (core/rasterization.cpp:19-92) on the device
 
 @pytest.mark.parametrize("seed", range(6))

@@ -47,6 +47,7 @@ def kernel_ms(fn):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--only", default="", help="run only the configs whose name contains this substring")
     args = ap.parse_args()
     import torch  # noqa: F401
     import msdfgen_amd as M
@@ -57,6 +58,8 @@ def main():
     latin, xf64 = load_latin()
 
     def report(name, batch, mode, w, h, xfs, config=None, reps=args.reps, **kw):
+        if args.only and args.only not in name:
+            return
         gb = M.GlyphBatch(batch)
         out = torch.empty((batch.n_glyphs, h, w, M.CHANNELS[mode]), dtype=torch.float32, device="cuda")
         desc = gb.descriptors(xfs, w, h, M.CHANNELS[mode])
@@ -86,6 +89,8 @@ def main():
     cj = ShapeBatch.from_shapes([base[i % 512] for i in range(8192)])
     cx = np.stack([autoframe(s.bounds(), 48, 48, 4) for s in base])[np.arange(8192) % 512]
     report("cfg4: 8192 CJK-like synthetic glyphs msdf 48x48 default EC", cj, 3, 48, 48, cx, reps=max(2, args.reps//3))
+    report("cfg4 shapes, simple combiner (overlapSupport=false)", cj, 3, 48, 48, cx, config=M.MSDFGeneratorConfig(False), reps=max(2, args.reps//3))
+    report("cfg4 shapes, sdf 48x48", cj, 1, 48, 48, cx, reps=max(2, args.reps//3))
     logo = synth.logo_shape(5)
     lb = ShapeBatch.from_shapes([logo])
     lx = np.stack([autoframe(logo.bounds(), 1024, 1024, 8)])
