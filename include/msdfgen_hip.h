@@ -195,6 +195,14 @@ int msdfhip_batch_generate(const MsdfHipBatch *batch, int mode, int width, int h
 int msdfhip_batch_generate_host(const MsdfHipBatch *batch, int mode, int width, int height, const MsdfHipGlyph *glyphs,
                                 float *out, size_t out_floats, uint8_t *stencil, const MsdfHipConfig *cfg);
 
+/* 8-bit atlas output: converts packed fp32 tiles [g][h][w][channels] (msdfhip_batch_generate's output with out_offset =
+ * g*h*w*channels, row_stride = w*channels) with pixelFloatToByte (core/pixel-conversion.hpp:8-10, what the reference's savers
+ * apply, core/save-bmp.cpp:174-224, ext/save-png.cpp:83-187) and stores glyph g's rectangle at
+ * d_atlas + d_glyphs[g].out_offset + d_glyphs[g].row_stride*y + channels*x, offsets and strides in BYTES (xf and flip are not read).
+ * Asynchronous on `stream`. The device-to-host copy of an 8-bit atlas is a quarter of the float tiles'. */
+int msdfhip_tiles_to_bytes(const float *d_tiles, int n_glyphs, int width, int height, int channels, const MsdfHipGlyph *d_glyphs,
+                           uint8_t *d_atlas, void *stream);
+
 /* Timing hook for bench.py: average device time in milliseconds of the dominant kernel (the distance-field kernel) and of
  * the passes after it (sign correction + error correction, per error-correction launch) over the launches recorded since the
  * last call with reset != 0, measured with hipEvents on the launching stream.

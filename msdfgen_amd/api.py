@@ -325,6 +325,23 @@ class GlyphBatch:
         d["flip"] = (self.shapes.inverse_y.astype(bool) != (y_orientation == Y_DOWNWARD)).astype(np.int32)
         return self.torch.from_numpy(d.view(np.uint8).reshape(self.n_glyphs, 64)).to(self.device)
 
+    def to_bytes(self, tiles, atlas, out_offsets, row_stride, stream=None):
+        """pixelFloatToByte (core/pixel-conversion.hpp:8-10) of packed float tiles (G, H, W, N) + blit of glyph g's rectangle into the
+        uint8 device tensor `atlas` at byte offset out_offsets[g] with `row_stride` bytes per atlas row. Returns `atlas`."""
+        torch = self.torch
+        g, h, w, n = tiles.shape
+        assert g == self.n_glyphs and tiles.dtype == torch.float32 and tiles.is_contiguous() and atlas.dtype == torch.uint8
+        d = np.zeros(g, _lib.GLYPH_DTYPE)
+        d["out_offset"] = np.asarray(out_offsets, np.int64)
+        d["row_stride"] = row_stride
+        hi = int(d["out_offset"].max())+int(row_stride)*(h-1)+w*n if g else 0
+        if g and (int(d["out_offset"].min()) < 0 or hi > atlas.numel()):
+            raise ValueError("a glyph rectangle lies outside the atlas")
+        desc = torch.from_numpy(d.view(np.uint8).reshape(g, 64)).to(self.device)
+        s = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        _lib.check(_lib.load().msdfhip_tiles_to_bytes(tiles.data_ptr(), g, w, h, n, desc.data_ptr(), atlas.data_ptr(), s))
+        return atlas
+
     def generate(self, mode, width, height, xfs=None, config=None, out=None, stencil=None, descriptors=None, stream=None, y_orientation=Y_UPWARD,
                  scanline_pass=False, fill_rule=FILL_NONZERO, sdf_zero_value=.5):
         """Renders every glyph of the batch into its tile; returns the float32 device tensor (G, height, width, N).

@@ -606,6 +606,28 @@ int msdfhip_batch_generate(const MsdfHipBatch *b, int mode, int w, int h, const 
     return runCorrection(b, channelsOf(mode), w, h, dGlyphs, ecSrc, dOut, dStencil, *cfg, stream);
 }
 
+int msdfhip_tiles_to_bytes(const float *dTiles, int nGlyphs, int w, int h, int channels, const MsdfHipGlyph *dGlyphs, uint8_t *dAtlas, void *streamPtr) {
+    if (nGlyphs < 0 || w < 0 || h < 0 || (channels != 1 && channels != 3 && channels != 4))
+        return fail(MSDFHIP_ERR_INVALID, "bad arguments to msdfhip_tiles_to_bytes");
+    const size_t total = (size_t) nGlyphs*w*h;
+    if (!total)
+        return MSDFHIP_OK;
+    if (!dTiles || !dGlyphs || !dAtlas)
+        return fail(MSDFHIP_ERR_INVALID, "NULL argument");
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    hipStream_t stream = (hipStream_t) streamPtr;
+    const unsigned blocks = (unsigned) ((total+255)/256 < 65536 ? (total+255)/256 : 65536);
+    switch (channels) {
+        case 1: hipLaunchKernelGGL(k_tiles_to_bytes<1>, dim3(blocks), dim3(256), 0, stream, dTiles, dGlyphs, nGlyphs, w, h, dAtlas); break;
+        case 3: hipLaunchKernelGGL(k_tiles_to_bytes<3>, dim3(blocks), dim3(256), 0, stream, dTiles, dGlyphs, nGlyphs, w, h, dAtlas); break;
+        default: hipLaunchKernelGGL(k_tiles_to_bytes<4>, dim3(blocks), dim3(256), 0, stream, dTiles, dGlyphs, nGlyphs, w, h, dAtlas); break;
+    }
+    HIPCHK(hipGetLastError());
+    return MSDFHIP_OK;
+}
+
 int msdfhip_batch_generate_host(const MsdfHipBatch *b, int mode, int w, int h, const MsdfHipGlyph *glyphs, float *out, size_t outFloats,
                                 uint8_t *stencil, const MsdfHipConfig *cfg) {
     if (!b || !glyphs || !out)

@@ -726,6 +726,31 @@ k_sign_correction(BatchView batch, const MsdfHipGlyph *glyphs, int width, int he
     }
 }
 
+// ------------------------------------------------------------------------------------------- 8-bit atlas output (row f2)
+
+// pixelFloatToByte (core/pixel-conversion.hpp:8-10): byte(~int(255.5f-255.f*clamp(x))), fp32 arithmetic, clamp(NaN) = 0.
+__device__ inline uint8_t pixelFloatToByte(float x) {
+    const float c = x >= 0.f && x <= 1.f ? x : (float) (x > 0.f);            // arithmetics.hpp:35-37
+    return (uint8_t) ~(int) (255.5f-255.f*c);
+}
+
+// tiles: packed fp32 [g][h][w][N] (what batch_generate writes with default descriptors); every texel is converted and stored at
+// atlas + out_offset[g] + row_stride[g]*y + N*x (bytes): conversion and atlas-rectangle blit in one pass, D2H shrinks 4x.
+template <int N>
+__global__ void k_tiles_to_bytes(const float *tiles, const MsdfHipGlyph *glyphs, int nGlyphs, int width, int height, uint8_t *atlas) {
+    const size_t texelsPerGlyph = (size_t) width*height;
+    const size_t total = texelsPerGlyph*nGlyphs;
+    for (size_t i = (size_t) blockIdx.x*blockDim.x+threadIdx.x; i < total; i += (size_t) gridDim.x*blockDim.x) {
+        const int g = (int) (i/texelsPerGlyph);
+        const int rem = (int) (i-(size_t) g*texelsPerGlyph);
+        const int y = rem/width, x = rem-y*width;
+        const float *in = tiles+i*N;
+        uint8_t *o = atlas+glyphs[g].out_offset+(ptrdiff_t) glyphs[g].row_stride*y+(ptrdiff_t) N*x;
+        for (int ch = 0; ch < N; ++ch)
+            o[ch] = pixelFloatToByte(in[ch]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------- distance queries
 
 template <int SEL, bool OVERLAP>

@@ -1547,3 +1547,12 @@ double orc_generate_batch_timed(const orc_shape *shapes, int n_glyphs, int mode,
     clock_gettime(CLOCK_MONOTONIC, &t1);
     return (double) (t1.tv_sec-t0.tv_sec)+1e-9*(double) (t1.tv_nsec-t0.tv_nsec);
 }
+
+/* pixelFloatToByte (core/pixel-conversion.hpp:8-10) over n floats; clamp(x) per core/arithmetics.hpp:35-37. */
+void orc_pixel_float_to_byte(const float *in, unsigned char *out, long n) {
+    for (long i = 0; i < n; ++i) {
+        float x = in[i];
+        float c = x >= 0.f && x <= 1.f ? x : (float) (x > 0.f);
+        out[i] = (unsigned char) ~(int) (255.5f-255.f*c);
+    }
+}

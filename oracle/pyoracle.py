@@ -75,6 +75,7 @@ def _xf(xf):
 
 
 class Oracle:
+    _PFX = "orc_"
     """The plain-C restatement."""
 
     kind = "port"
@@ -171,6 +172,15 @@ class Oracle:
         self.lib.orc_sign_correction(C.byref(s), n, _p(px, _fp), w, h, w*n, int(y_down), _p(x4, _dp), C.c_float(zero), fill_rule)
         return px
 
+    def pixel_float_to_byte(self, a):
+        """pixelFloatToByte (core/pixel-conversion.hpp:8-10), elementwise."""
+        a = _arr(a, np.float32)
+        out = np.zeros(a.shape, np.uint8)
+        fn = getattr(self.lib, self._PFX+"pixel_float_to_byte")
+        fn.argtypes = [_fp, _bp, C.c_long]
+        fn(_p(a, _fp), _p(out, _bp), a.size)
+        return out
+
     def rasterize(self, shape, w, h, xf, fill_rule=0, y_down=False):
         """rasterize (core/rasterization.h:13): (h, w, 1) coverage."""
         f = _flat(shape)
@@ -201,6 +211,7 @@ class Oracle:
 
 
 class Ref:
+    _PFX = "ref_"
     """The compiled reference (msdfgen v1.13.0 core)."""
 
     kind = "reference"
@@ -369,6 +380,15 @@ class Ref:
         if own:
             self.free(hd)
         return px
+
+    def pixel_float_to_byte(self, a):
+        """pixelFloatToByte (core/pixel-conversion.hpp:8-10), elementwise."""
+        a = _arr(a, np.float32)
+        out = np.zeros(a.shape, np.uint8)
+        fn = getattr(self.lib, self._PFX+"pixel_float_to_byte")
+        fn.argtypes = [_fp, _bp, C.c_long]
+        fn(_p(a, _fp), _p(out, _bp), a.size)
+        return out
 
     def rasterize(self, shape, w, h, xf, fill_rule=0, y_down=False):
         """rasterize (core/rasterization.h:13): (h, w, 1) coverage."""

@@ -26,6 +26,7 @@
 #include "msdfgen.h"
 #include "core/ShapeDistanceFinder.h"
 #include "core/MSDFErrorCorrection.h"
+#include "core/pixel-conversion.hpp"
 #include "core/equation-solver.h"
 
 using namespace msdfgen;
@@ -200,6 +201,11 @@ void ref_sign_correction(void *s, int channels, float *pixels, int w, int h, int
         case 3: distanceSignCorrection(BitmapSection<float, 3>(pixels, w, h, rowStride, yo), shape, proj, sdfZeroValue, (FillRule) fillRule); break;
         case 4: distanceSignCorrection(BitmapSection<float, 4>(pixels, w, h, rowStride, yo), shape, proj, sdfZeroValue, (FillRule) fillRule); break;
     }
+}
+
+void ref_pixel_float_to_byte(const float *in, unsigned char *out, long n) {
+    for (long i = 0; i < n; ++i)
+        out[i] = pixelFloatToByte(in[i]);
 }
 
 void ref_rasterize(void *s, float *pixels, int w, int h, int rowStride, int yDown, const double *xf, int fillRule) {

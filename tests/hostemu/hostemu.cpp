@@ -426,3 +426,54 @@ extern "C" void emu_rasterize(float *pixels, int w, int h, int rowStride, int fl
     std::vector<float> src((size_t) w*h);
     signCorrectionEmu<1>(d, co[nC], t, w, h, flip, src.data(), pixels, rowStride, 0.f, fillRule, 1);
 }
+
+// Host rendition of EdgesCooperative (msdf_kernels.hpp): 64 "lanes" evaluate 64 edges each into a single-edge selector, the states
+// are merged with the kernel's shuffle tree (lane l <- merge(l, l+off), off = 1, 2, ... 32), chunk results are merged in order.
+namespace msdfhip {
+struct EdgesCoopEmu {
+    const int32_t *coff;
+    int begin(int c) const { return coff[c]-coff[0]; }
+    int end(int c) const { return coff[c+1]-coff[0]; }
+};
+inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const EdgesCoopEmu &edges, int c, V2 o) {
+    const int e = edges.end(c);
+    for (int base = edges.begin(c); base < e; base += 64) {
+        PB lanes[64];
+        for (int l = 0; l < 64; ++l) {
+            Selector<2> mine;
+            selInit(mine);
+            if (base+l < e)
+                selAddEdge(mine, rec[base+l], base+l, o);
+            lanes[l] = mine.c[0];
+        }
+        for (int off = 1; off < 64; off <<= 1) {
+            PB next[64];
+            for (int l = 0; l < 64; ++l) {
+                next[l] = lanes[l];
+                if (l+off < 64)
+                    pbMerge(next[l], lanes[l+off]);
+            }
+            for (int l = 0; l < 64; ++l)
+                lanes[l] = next[l];
+        }
+        pbMerge(sel.c[0], lanes[0]);
+    }
+}
+}
+
+extern "C" void emu_psdf_cooperative(int overlap, int nC, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors,
+                                     int n, const double *pts, double *out) {
+    Digest d = digest(nC, co, points, types, colors);
+    std::vector<double> res((size_t) (nC+1)*4);
+    EdgesCoopEmu edges;
+    edges.coff = co;
+    for (int i = 0; i < n; ++i) {
+        double o[1] = { 0 };
+        const V2 q = mk(pts[2*i], pts[2*i+1]);
+        if (overlap)
+            shapeDistanceOverlap<2>(d.recs.data(), edges, d.windings.data(), nC, q, res.data(), 1, o);
+        else
+            shapeDistanceSimple<2>(d.recs.data(), edges, nC, q, o);
+        out[i] = o[0];
+    }
+}

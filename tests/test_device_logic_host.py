@@ -202,3 +202,22 @@ def test_lean_transcendentals_are_within_one_ulp(emu):
     errp = np.abs(outp.astype(np.longdouble)-refp)/np.spacing(refp.astype(np.float64))
     assert errp.max() < 1.0, errp.max()
     print("pow third max ulp error: lean %.3f" % errp.max())
+
+
+def test_cooperative_psdf_query_equals_sequential(emu, oracle, latin):
+    """k_ec_query evaluates a glyph's edges with lanes = edges and merges the single-edge selector states with a shuffle tree
+    (EdgesCooperative). The merge must reproduce the sequential visit-order result bit for bit, ties included: points ON vertices
+    and on the bisectors of corners make adjacent edges tie in |distance|."""
+    batch, xf64, bounds = latin
+    rng = np.random.default_rng(12)
+    shapes = [batch.shape(g) for g in (1, 4, 32, 38, 51, 77)]+[synth.random_shape(900+i, n_contours=3, edges_per_contour=(30, 45), kinds=(1, 2, 3)) for i in range(3)]
+    shapes.append(synth.cjk_like_shape(8200))
+    for s in shapes:
+        b = s.bounds()
+        pts = np.column_stack([rng.uniform(b[0]-.1, b[2]+.1, 300), rng.uniform(b[1]-.1, b[3]+.1, 300)])
+        verts = s.points[:, 0:2]
+        pts = np.vstack([pts, verts[:40], verts[:40]+rng.normal(0, 1e-3, (min(40, len(verts)), 2))])
+        for overlap in (True, False):
+            want = oracle.shape_distance(s, 2, overlap, pts)[:, 0]
+            got = emu.psdf_cooperative(s, overlap, pts)
+            assert_bit_equal(got, want, "cooperative PSDF, overlap=%s, %d edges" % (overlap, s.n_edges))

@@ -485,3 +485,34 @@ def test_rasterize_vs_oracle(oracle):
         for rule in range(4):
             got = M.rasterize(np.full((h, w, 1), -3, np.float32), s, M.Projection((xf[0], xf[1]), (xf[2], xf[3])), rule, M.Y_DOWNWARD if seed & 4 else M.Y_UPWARD)
             assert (got == oracle.rasterize(s, w, h, xf, rule, y_down=bool(seed & 4))).all(), (seed, rule)
+
+
+def test_tiles_to_bytes_atlas_blit(latin, oracle):
+    """pixelFloatToByte + atlas-rectangle blit on the device (msdfhip_tiles_to_bytes): generated mtsdf tiles and a
+    tile of boundary values go into a uint8 atlas with padding; untouched atlas bytes must stay untouched."""
+    import torch
+    batch, xf64, _ = latin
+    sub = batch.select(range(20, 32))
+    gb = M.GlyphBatch(sub)
+    w = h = 40
+    xfs = np.stack([autoframe(b, w, h, 4) for b in latin[2][20:32]])
+    tiles = gb.generate(4, w, h, xfs)
+    k = np.arange(0, 256, dtype=np.float64)
+    edge = np.concatenate([(k+d)/255. for d in (0, .5, -.5)]).astype(np.float32)
+    special = np.concatenate([edge, np.nextafter(edge, np.float32(2)), np.nextafter(edge, np.float32(-2)), np.array([np.nan, np.inf, -np.inf, -3, 7], np.float32)])
+    tiles[0].view(-1)[:special.size] = torch.from_numpy(special).to(tiles.device)
+    cols, pad = 4, 3
+    aw, ah = cols*(w+pad)+5, 3*(h+pad)+2
+    atlas = torch.full((ah, aw, 4), 77, dtype=torch.uint8, device="cuda")
+    offs = [(((g//cols)*(h+pad)+1)*aw+(g % cols)*(w+pad)+2)*4 for g in range(12)]
+    gb.to_bytes(tiles, atlas, offs, aw*4)
+    torch.cuda.synchronize()
+    got, src = atlas.cpu().numpy(), tiles.cpu().numpy()
+    want = np.full((ah, aw, 4), 77, np.uint8)
+    for g in range(12):
+        y0, x0 = (g//cols)*(h+pad)+1, (g % cols)*(w+pad)+2
+        want[y0:y0+h, x0:x0+w] = oracle.pixel_float_to_byte(src[g])
+    assert (got == want).all()
+    with pytest.raises(ValueError):
+        gb.to_bytes(tiles, atlas, [o+aw*ah*4 for o in offs], aw*4)
+    gb.close()

@@ -96,3 +96,14 @@ def test_rasterize_oracle_reference_and_device_host(oracle, ref, emu, seed):
         assert (oracle.rasterize(s, w, h, xf, rule, y_down=bool(seed & 4)) == a).all()
         assert (emu.rasterize(s, w, h, xf, rule, y_down=bool(seed & 4)) == a).all()
     assert 0 < ref.rasterize(s, w, h, xf, 1).mean() < 1
+
+
+def test_pixel_float_to_byte_oracle_vs_reference(oracle, ref):
+    """pixelFloatToByte (core/pixel-conversion.hpp:8-10): every rounding boundary k/255 +- a few ulps, out-of-range, inf, NaN."""
+    k = np.arange(0, 256, dtype=np.float64)
+    edges = np.concatenate([(k+d)/255. for d in (0, .5, -.5, 1/3.)]).astype(np.float32)
+    vals = np.concatenate([edges, np.nextafter(edges, np.float32(2)), np.nextafter(edges, np.float32(-2)),
+                           np.array([-1, -0., 0, 1, 1.0000001, 2, 1e30, -1e30, np.inf, -np.inf, np.nan], np.float32),
+                           np.random.default_rng(3).uniform(-.2, 1.2, 20000).astype(np.float32)])
+    a, b = ref.pixel_float_to_byte(vals), oracle.pixel_float_to_byte(vals)
+    assert (a == b).all() and a.min() == 0 and a.max() == 255
