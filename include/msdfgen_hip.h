@@ -195,6 +195,24 @@ int msdfhip_batch_generate(const MsdfHipBatch *batch, int mode, int width, int h
 int msdfhip_batch_generate_host(const MsdfHipBatch *batch, int mode, int width, int height, const MsdfHipGlyph *glyphs,
                                 float *out, size_t out_floats, uint8_t *stencil, const MsdfHipConfig *cfg);
 
+/* Shape preparation on the device: what callers run on every glyph before the generators.
+ *   normalize  Shape::normalize (core/Shape.cpp:65-92): single-edge contours split in thirds, convergent edges pushed apart
+ *   coloring   0 keep `colors`, 1 edgeColoringSimple(shape, angle_threshold, seed) (core/edge-coloring.cpp:68-142)
+ * msdfhip_batch_create_prepared uploads RAW outlines (colors may be NULL = all WHITE), prepares them on the device and returns a
+ * digested batch of the prepared shapes; seeds: one per glyph, or NULL to use cfg->seed for every glyph. The prepared shapes can be
+ * read back with msdfhip_batch_info (sizes) + msdfhip_batch_download (arrays sized from those; any pointer may be NULL). */
+typedef struct MsdfHipPrepConfig {
+    int32_t normalize;
+    int32_t coloring;
+    double angle_threshold;       /* main.cpp:32: 3.0 */
+    uint64_t seed;
+} MsdfHipPrepConfig;
+int msdfhip_batch_create_prepared(MsdfHipBatch **batch, int n_glyphs, const int32_t *glyph_contour_offsets, const int32_t *contour_offsets,
+                                  const double *points, const uint8_t *types, const uint8_t *colors, const uint64_t *seeds,
+                                  const MsdfHipPrepConfig *cfg);
+int msdfhip_batch_info(const MsdfHipBatch *batch, int *n_glyphs, int *n_contours, int *n_edges, int *max_contours, int *max_edges);
+int msdfhip_batch_download(const MsdfHipBatch *batch, int32_t *contour_offsets, double *points, uint8_t *types, uint8_t *colors);
+
 /* 8-bit atlas output: converts packed fp32 tiles [g][h][w][channels] (msdfhip_batch_generate's output with out_offset =
  * g*h*w*channels, row_stride = w*channels) with pixelFloatToByte (core/pixel-conversion.hpp:8-10, what the reference's savers
  * apply, core/save-bmp.cpp:174-224, ext/save-png.cpp:83-187) and stores glyph g's rectangle at

@@ -289,6 +289,44 @@ class GlyphBatch:
         self._scratch = None
         self._glyph_cache = {}
 
+    @classmethod
+    def from_raw(cls, raw: ShapeBatch, normalize=True, coloring=1, angle_threshold=3.0, seeds=None, seed=0, device=None):
+        """Uploads RAW outlines and prepares them on the device: Shape::normalize (core/Shape.cpp:65-92) and, with coloring=1,
+        edgeColoringSimple(shape, angle_threshold, seed) (core/edge-coloring.cpp:68-142; `seeds`: one per glyph). The prepared
+        shapes are read back once into `.shapes` (they are small); the batch is digested and ready for generate()."""
+        import torch
+        if not torch.cuda.is_available():
+            raise MsdfHipError(_lib.ERR_NO_DEVICE, "no GPU visible to torch; msdfgen_amd has no CPU path")
+        self = object.__new__(cls)
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device) if not isinstance(device, torch.device) else device
+        _lib.init(self.device.index or 0)
+        lib = _lib.load()
+        gco = np.ascontiguousarray(raw.glyph_contour_offsets, np.int32)
+        co = np.ascontiguousarray(raw.contour_offsets, np.int32)
+        pts = np.ascontiguousarray(raw.points, np.float64).reshape(-1, 8)
+        types = np.ascontiguousarray(raw.types, np.uint8)
+        colors = np.ascontiguousarray(raw.colors, np.uint8)
+        sd = None if seeds is None else np.ascontiguousarray(seeds, np.uint64)
+        cfg = _lib.PrepConfig(int(bool(normalize)), int(coloring), float(angle_threshold), int(seed))
+        self._handle = C.c_void_p()
+        _lib.check(lib.msdfhip_batch_create_prepared(C.byref(self._handle), raw.n_glyphs, _lib.ptr(gco, _lib._ip), _lib.ptr(co, _lib._ip), _lib.ptr(pts, _lib._dp),
+                                                     _lib.ptr(types, _lib._bp), _lib.ptr(colors, _lib._bp),
+                                                     sd.ctypes.data_as(C.POINTER(C.c_uint64)) if sd is not None else None, C.byref(cfg)))
+        ng, nc, ne, mc, me = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(lib.msdfhip_batch_info(self._handle, C.byref(ng), C.byref(nc), C.byref(ne), C.byref(mc), C.byref(me)))
+        co2 = np.zeros(nc.value+1, np.int32)
+        p2 = np.zeros((max(ne.value, 1), 8), np.float64)
+        t2, c2 = np.ones(max(ne.value, 1), np.uint8), np.zeros(max(ne.value, 1), np.uint8)
+        _lib.check(lib.msdfhip_batch_download(self._handle, _lib.ptr(co2, _lib._ip), _lib.ptr(p2, _lib._dp), _lib.ptr(t2, _lib._bp), _lib.ptr(c2, _lib._bp)))
+        self.shapes = ShapeBatch(gco.copy(), co2, p2[:ne.value], t2[:ne.value].astype(np.int32), c2[:ne.value].astype(np.int32), np.asarray(raw.inverse_y).copy(),
+                                 list(raw.names) if raw.names is not None else None)
+        self.n_glyphs = raw.n_glyphs
+        self.max_contours, self.max_edges = mc.value, me.value
+        self._scratch = None
+        self._glyph_cache = {}
+        return self
+
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle:
             self.torch.cuda.synchronize(self.device)

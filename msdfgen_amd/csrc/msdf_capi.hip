@@ -8,6 +8,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -516,6 +517,155 @@ int msdfhip_batch_create(MsdfHipBatch **batch, int n_glyphs, const int32_t *gco,
         return rc;
     }
     *batch = b;
+    return MSDFHIP_OK;
+}
+
+int msdfhip_batch_create_prepared(MsdfHipBatch **batch, int n_glyphs, const int32_t *gco, const int32_t *co, const double *points, const uint8_t *types,
+                                  const uint8_t *colors, const uint64_t *seeds, const MsdfHipPrepConfig *cfg) {
+    if (!batch || n_glyphs < 0 || !gco || !co || !cfg)
+        return fail(MSDFHIP_ERR_INVALID, "bad arguments to msdfhip_batch_create_prepared");
+    if (cfg->coloring < 0 || cfg->coloring > 1)
+        return fail(MSDFHIP_ERR_INVALID, "coloring %d (0 keep, 1 edgeColoringSimple)", cfg->coloring);
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    const int nC = gco[n_glyphs], nE = co[nC];
+    if (gco[0] != 0 || co[0] != 0 || nC < 0 || nE < 0)
+        return fail(MSDFHIP_ERR_INVALID, "offset arrays must start at 0");
+    for (int g = 0; g < n_glyphs; ++g)
+        if (gco[g+1] < gco[g])
+            return fail(MSDFHIP_ERR_INVALID, "glyph_contour_offsets not monotonic at %d", g);
+    for (int c = 0; c < nC; ++c)
+        if (co[c+1] < co[c])
+            return fail(MSDFHIP_ERR_INVALID, "contour_offsets not monotonic at %d", c);
+    for (int e = 0; e < nE; ++e)
+        if (types[e] < 1 || types[e] > 3)
+            return fail(MSDFHIP_ERR_INVALID, "edge %d has type %d (must be 1, 2 or 3)", e, (int) types[e]);
+
+    // offsets after normalize are a host-side prefix over the raw contour sizes; the upper bound of the coloured size as well
+    std::vector<int32_t> co1(nC+1, 0), co2(nC+1, 0);
+    size_t bound2 = 0;
+    for (int c = 0; c < nC; ++c) {
+        const int n = co[c+1]-co[c];
+        const int n1 = cfg->normalize ? normalizedCount(n) : n;
+        co1[c+1] = co1[c]+n1;
+        bound2 += n1 < 3 ? 3*n1 : n1;
+    }
+    if (bound2 > 0x7fffffffull)
+        return fail(MSDFHIP_ERR_INVALID, "too many edges");
+    const int nE1 = co1[nC];
+    struct Dev {                                                  // scoped device allocations of this call
+        std::vector<void *> ptrs;
+        ~Dev() { for (size_t i = 0; i < ptrs.size(); ++i) hipFree(ptrs[i]); }
+        hipError_t alloc(void **p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) ptrs.push_back(*p); return e; }
+        void release(void *p) { for (size_t i = 0; i < ptrs.size(); ++i) if (ptrs[i] == p) { ptrs.erase(ptrs.begin()+i); break; } }
+    } dev;
+    #define PREP_CHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(MSDFHIP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+    int32_t *dGco = NULL, *dCo = NULL, *dCo1 = NULL, *dCo2 = NULL, *dCount = NULL;
+    unsigned long long *dSeeds = NULL;
+    EdgeArrays raw = { NULL, NULL, NULL }, norm = { NULL, NULL, NULL }, fin = { NULL, NULL, NULL };
+    const size_t eRaw = nE > 0 ? nE : 1, eNorm = nE1 > 0 ? nE1 : 1, eFin = bound2 > 0 ? bound2 : 1;
+    PREP_CHK(dev.alloc((void **) &dGco, sizeof(int32_t)*(size_t) (n_glyphs+1)));
+    PREP_CHK(dev.alloc((void **) &dCo, sizeof(int32_t)*(size_t) (nC+1)));
+    PREP_CHK(dev.alloc((void **) &dCo1, sizeof(int32_t)*(size_t) (nC+1)));
+    PREP_CHK(dev.alloc((void **) &raw.points, sizeof(double)*8*eRaw));
+    PREP_CHK(dev.alloc((void **) &raw.types, eRaw));
+    PREP_CHK(dev.alloc((void **) &norm.points, sizeof(double)*8*eNorm));
+    PREP_CHK(dev.alloc((void **) &norm.types, eNorm));
+    PREP_CHK(dev.alloc((void **) &norm.colors, eNorm));
+    PREP_CHK(hipMemcpy(dGco, gco, sizeof(int32_t)*(size_t) (n_glyphs+1), hipMemcpyHostToDevice));
+    PREP_CHK(hipMemcpy(dCo, co, sizeof(int32_t)*(size_t) (nC+1), hipMemcpyHostToDevice));
+    PREP_CHK(hipMemcpy(dCo1, co1.data(), sizeof(int32_t)*(size_t) (nC+1), hipMemcpyHostToDevice));
+    if (nE) {
+        PREP_CHK(hipMemcpy(raw.points, points, sizeof(double)*8*(size_t) nE, hipMemcpyHostToDevice));
+        PREP_CHK(hipMemcpy(raw.types, types, (size_t) nE, hipMemcpyHostToDevice));
+        if (colors) {
+            PREP_CHK(dev.alloc((void **) &raw.colors, eRaw));
+            PREP_CHK(hipMemcpy(raw.colors, colors, (size_t) nE, hipMemcpyHostToDevice));
+        }
+    }
+    if (nC)
+        hipLaunchKernelGGL(k_prep_normalize, dim3((nC+127)/128), dim3(128), 0, 0, raw, (const int32_t *) dCo, (const int32_t *) dCo1, nC, cfg->normalize ? 1 : 0, norm);
+    const int32_t *finalCo = co1.data();
+    int32_t *dFinalCo = dCo1;
+    if (cfg->coloring) {
+        const double crossThreshold = sin(cfg->angle_threshold);  // edge-coloring.cpp:69, taken by the host's libm like the reference's
+        PREP_CHK(dev.alloc((void **) &dCount, sizeof(int32_t)*(size_t) (nC+1)));
+        PREP_CHK(dev.alloc((void **) &dCo2, sizeof(int32_t)*(size_t) (nC+1)));
+        PREP_CHK(dev.alloc((void **) &fin.points, sizeof(double)*8*eFin));
+        PREP_CHK(dev.alloc((void **) &fin.types, eFin));
+        PREP_CHK(dev.alloc((void **) &fin.colors, eFin));
+        if (nC)
+            hipLaunchKernelGGL(k_prep_count, dim3((nC+127)/128), dim3(128), 0, 0, norm, (const int32_t *) dCo1, nC, crossThreshold, dCount);
+        std::vector<int32_t> count(nC+1, 0);
+        PREP_CHK(hipMemcpy(count.data(), dCount, sizeof(int32_t)*(size_t) nC, hipMemcpyDeviceToHost));   // synchronizes with the kernels above
+        for (int c = 0; c < nC; ++c)
+            co2[c+1] = co2[c]+count[c];
+        PREP_CHK(hipMemcpy(dCo2, co2.data(), sizeof(int32_t)*(size_t) (nC+1), hipMemcpyHostToDevice));
+        if (seeds && n_glyphs) {
+            PREP_CHK(dev.alloc((void **) &dSeeds, sizeof(unsigned long long)*(size_t) n_glyphs));
+            PREP_CHK(hipMemcpy(dSeeds, seeds, sizeof(unsigned long long)*(size_t) n_glyphs, hipMemcpyHostToDevice));
+        }
+        if (n_glyphs)
+            hipLaunchKernelGGL(k_prep_colour, dim3((n_glyphs+63)/64), dim3(64), 0, 0, norm, (const int32_t *) dGco, (const int32_t *) dCo1, (const int32_t *) dCo2,
+                               n_glyphs, crossThreshold, (const unsigned long long *) dSeeds, (unsigned long long) cfg->seed, fin);
+        finalCo = co2.data();
+        dFinalCo = dCo2;
+    } else
+        fin = norm;
+    PREP_CHK(hipGetLastError());
+    PREP_CHK(hipDeviceSynchronize());
+    #undef PREP_CHK
+
+    int maxC = 0, maxE = 0;
+    for (int g = 0; g < n_glyphs; ++g) {
+        const int c = gco[g+1]-gco[g], e = finalCo[gco[g+1]]-finalCo[gco[g]];
+        maxC = c > maxC ? c : maxC;
+        maxE = e > maxE ? e : maxE;
+    }
+    MsdfHipBatch *b = new MsdfHipBatch();
+    b->nGlyphs = n_glyphs, b->nContours = nC, b->nEdges = finalCo[nC], b->maxContours = maxC, b->maxEdges = maxE;
+    b->ownsInputs = true;                                        // the batch takes over the final arrays
+    b->dGlyphContourOffsets = dGco, b->dContourOffsets = dFinalCo, b->dPoints = fin.points, b->dTypes = fin.types, b->dColors = fin.colors;
+    dev.release(dGco), dev.release(dFinalCo), dev.release(fin.points), dev.release(fin.types), dev.release(fin.colors);
+    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0, b->dEcParams = NULL, b->dGres = NULL, b->gresBytes = 0;
+    rc = digest(b, NULL);
+    if (rc == MSDFHIP_OK && hipStreamSynchronize(NULL) != hipSuccess)
+        rc = fail(MSDFHIP_ERR_HIP, "edge digestion failed: %s", hipGetErrorString(hipGetLastError()));
+    if (rc != MSDFHIP_OK) {
+        msdfhip_batch_destroy(b);
+        return rc;
+    }
+    *batch = b;
+    return MSDFHIP_OK;
+}
+
+int msdfhip_batch_info(const MsdfHipBatch *b, int *nGlyphs, int *nContours, int *nEdges, int *maxContours, int *maxEdges) {
+    if (!b)
+        return fail(MSDFHIP_ERR_INVALID, "NULL batch");
+    if (nGlyphs) *nGlyphs = b->nGlyphs;
+    if (nContours) *nContours = b->nContours;
+    if (nEdges) *nEdges = b->nEdges;
+    if (maxContours) *maxContours = b->maxContours;
+    if (maxEdges) *maxEdges = b->maxEdges;
+    return MSDFHIP_OK;
+}
+
+int msdfhip_batch_download(const MsdfHipBatch *b, int32_t *co, double *points, uint8_t *types, uint8_t *colors) {
+    if (!b)
+        return fail(MSDFHIP_ERR_INVALID, "NULL batch");
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    HIPCHK(hipDeviceSynchronize());
+    if (co)
+        HIPCHK(hipMemcpy(co, b->dContourOffsets, sizeof(int32_t)*(size_t) (b->nContours+1), hipMemcpyDeviceToHost));
+    if (points && b->nEdges)
+        HIPCHK(hipMemcpy(points, b->dPoints, sizeof(double)*8*(size_t) b->nEdges, hipMemcpyDeviceToHost));
+    if (types && b->nEdges)
+        HIPCHK(hipMemcpy(types, b->dTypes, (size_t) b->nEdges, hipMemcpyDeviceToHost));
+    if (colors && b->nEdges)
+        HIPCHK(hipMemcpy(colors, b->dColors, (size_t) b->nEdges, hipMemcpyDeviceToHost));
     return MSDFHIP_OK;
 }
 

@@ -22,6 +22,7 @@
 #include "msdf_ec_fast.hpp"
 #include "msdf_cull.hpp"
 #include "msdf_scanline.hpp"
+#include "msdf_shapeprep.hpp"
 #include "../../include/msdfgen_hip.h"
 
 namespace msdfhip {
@@ -724,6 +725,40 @@ k_sign_correction(BatchView batch, const MsdfHipGlyph *glyphs, int width, int he
         for (int i = 0; i < N; ++i)
             px_[i] = v[i];
     }
+}
+
+// ------------------------------------------------------------------------------------------- shape preparation (row f3)
+
+// Shape::normalize, one thread per contour (msdf_shapeprep.hpp). co: raw contour offsets, co1: offsets after normalize.
+__global__ void k_prep_normalize(EdgeArrays raw, const int32_t *co, const int32_t *co1, int nContours, int doNormalize, EdgeArrays out) {
+    const int c = blockIdx.x*blockDim.x+threadIdx.x;
+    if (c >= nContours)
+        return;
+    const int b = co[c], n = co[c+1]-b;
+    if (doNormalize)
+        normalizeContour(raw, b, n, out, co1[c]);
+    else
+        for (int i = 0; i < n; ++i)
+            storeEdge(out, co1[c]+i, loadEdge(raw, b+i));
+}
+
+// Edges per contour after edgeColoringSimple (a one-corner contour with fewer than three edges is split), one thread per contour.
+__global__ void k_prep_count(EdgeArrays norm, const int32_t *co1, int nContours, double crossThreshold, int32_t *count) {
+    const int c = blockIdx.x*blockDim.x+threadIdx.x;
+    if (c < nContours)
+        count[c] = colouredCount(norm, co1[c], co1[c+1]-co1[c], crossThreshold);
+}
+
+// edgeColoringSimple, one thread per glyph: the colour / seed state runs through the glyph's contours (edge-coloring.cpp:68-72).
+__global__ void k_prep_colour(EdgeArrays norm, const int32_t *gco, const int32_t *co1, const int32_t *co2, int nGlyphs, double crossThreshold,
+                              const unsigned long long *seeds, unsigned long long seedAll, EdgeArrays out) {
+    const int g = blockIdx.x*blockDim.x+threadIdx.x;
+    if (g >= nGlyphs)
+        return;
+    unsigned long long seed = seeds ? seeds[g] : seedAll;
+    int color = initColor(seed);
+    for (int c = gco[g]; c < gco[g+1]; ++c)
+        colourContour(norm, co1[c], co1[c+1]-co1[c], out, co2[c], crossThreshold, color, seed);
 }
 
 // ------------------------------------------------------------------------------------------- 8-bit atlas output (row f2)

@@ -35,6 +35,11 @@ class Config(C.Structure):
                 ("sign_correction", C.c_int32), ("fill_rule", C.c_int32), ("sdf_zero_value", C.c_float), ("reserved", C.c_int32)]
 
 
+class PrepConfig(C.Structure):
+    """MsdfHipPrepConfig."""
+    _fields_ = [("normalize", C.c_int32), ("coloring", C.c_int32), ("angle_threshold", C.c_double), ("seed", C.c_uint64)]
+
+
 class Glyph(C.Structure):
     """MsdfHipGlyph."""
     _fields_ = [("xf", C.c_double*6), ("out_offset", C.c_int64), ("row_stride", C.c_int32), ("flip", C.c_int32)]
@@ -65,6 +70,9 @@ _PROTOS = {
     "msdfhip_shape_distance": (C.c_int, [C.c_int, C.c_int] + _SHAPE_ARGS + [C.c_int, _dp, _dp]),
     "msdfhip_batch_create": (C.c_int, [C.POINTER(_vp), C.c_int, _ip, _ip, _dp, _bp, _bp]),
     "msdfhip_batch_create_device": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "msdfhip_batch_create_prepared": (C.c_int, [C.POINTER(_vp), C.c_int, _ip, _ip, _dp, _bp, _bp, C.POINTER(C.c_uint64), C.POINTER(PrepConfig)]),
+    "msdfhip_batch_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "msdfhip_batch_download": (C.c_int, [_vp, _ip, _dp, _bp, _bp]),
     "msdfhip_batch_digest": (C.c_int, [_vp, _vp]),
     "msdfhip_batch_destroy": (None, [_vp]),
     "msdfhip_batch_windings": (C.c_int, [_vp, _ip]),

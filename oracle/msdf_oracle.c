@@ -1556,3 +1556,292 @@ void orc_pixel_float_to_byte(const float *in, unsigned char *out, long n) {
         out[i] = (unsigned char) ~(int) (255.5f-255.f*c);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * shape preparation -- Shape::normalize (core/Shape.cpp:65-92) and edgeColoringSimple
+ * (core/edge-coloring.cpp:68-142) on the flat shape model. Output arrays must hold 3*E edges (worst case: every edge split in thirds).
+ */
+#define CORNER_DOT_EPSILON .000001                 /* core/Shape.h:12 */
+#define DECONVERGE_OVERSHOOT 1.11111111111111111   /* core/Shape.cpp:7 */
+
+static inline int veq(v2 a, v2 b) { return a.x == b.x && a.y == b.y; }                      /* Vector2.hpp:67-69 */
+static inline v2 vorthogonal(v2 a, int polarity) { return polarity ? V(-a.y, a.x) : V(a.y, -a.x); } /* Vector2.hpp:49-51 */
+
+static edge_t mk_edge(int type, int color, v2 a, v2 b, v2 c, v2 d) {
+    edge_t e;
+    e.type = type, e.color = color;
+    e.p[0] = a, e.p[1] = b, e.p[2] = c, e.p[3] = d;
+    return e;
+}
+
+static void split_in_thirds(const edge_t *e, edge_t *part) {                                 /* edge-segments.cpp:508-527 */
+    const v2 *p = e->p;
+    const v2 z = V(0, 0);
+    switch (e->type) {
+        case 1:
+            part[0] = mk_edge(1, e->color, p[0], edge_point(e, 1/3.), z, z);
+            part[1] = mk_edge(1, e->color, edge_point(e, 1/3.), edge_point(e, 2/3.), z, z);
+            part[2] = mk_edge(1, e->color, edge_point(e, 2/3.), p[1], z, z);
+            break;
+        case 2:
+            part[0] = mk_edge(2, e->color, p[0], vmix(p[0], p[1], 1/3.), edge_point(e, 1/3.), z);
+            part[1] = mk_edge(2, e->color, edge_point(e, 1/3.), vmix(vmix(p[0], p[1], 5/9.), vmix(p[1], p[2], 4/9.), .5), edge_point(e, 2/3.), z);
+            part[2] = mk_edge(2, e->color, edge_point(e, 2/3.), vmix(p[1], p[2], 2/3.), p[2], z);
+            break;
+        default:
+            part[0] = mk_edge(3, e->color, p[0], veq(p[0], p[1]) ? p[0] : vmix(p[0], p[1], 1/3.),
+                              vmix(vmix(p[0], p[1], 1/3.), vmix(p[1], p[2], 1/3.), 1/3.), edge_point(e, 1/3.));
+            part[1] = mk_edge(3, e->color, edge_point(e, 1/3.),
+                              vmix(vmix(vmix(p[0], p[1], 1/3.), vmix(p[1], p[2], 1/3.), 1/3.), vmix(vmix(p[1], p[2], 1/3.), vmix(p[2], p[3], 1/3.), 1/3.), 2/3.),
+                              vmix(vmix(vmix(p[0], p[1], 2/3.), vmix(p[1], p[2], 2/3.), 2/3.), vmix(vmix(p[1], p[2], 2/3.), vmix(p[2], p[3], 2/3.), 2/3.), 1/3.),
+                              edge_point(e, 2/3.));
+            part[2] = mk_edge(3, e->color, edge_point(e, 2/3.), vmix(vmix(p[1], p[2], 2/3.), vmix(p[2], p[3], 2/3.), 2/3.),
+                              veq(p[2], p[3]) ? p[3] : vmix(p[2], p[3], 2/3.), p[3]);
+            break;
+    }
+}
+
+static void deconverge_edge(edge_t *e, int param, v2 vector) {                               /* Shape.cpp:44-62 */
+    if (e->type == 2) {                                                                      /* convertToCubic, edge-segments.cpp:529-531 */
+        v2 a = e->p[0], b = e->p[1], c = e->p[2];
+        *e = mk_edge(3, e->color, a, vmix(a, b, 2/3.), vmix(b, c, 1/3.), c);
+    }
+    if (e->type == 3) {
+        if (param == 0)
+            e->p[1] = vadd(e->p[1], smul(vlen(vsub(e->p[1], e->p[0])), vector));
+        else
+            e->p[2] = vadd(e->p[2], smul(vlen(vsub(e->p[2], e->p[3])), vector));
+    }
+}
+
+static void simplify_degenerate_curve(v2 *cp, int *order) {                                  /* convergent-curve-ordering.cpp:34-46 */
+    if (*order == 3 && (veq(cp[1], cp[0]) || veq(cp[1], cp[3])) && (veq(cp[2], cp[0]) || veq(cp[2], cp[3]))) {
+        cp[1] = cp[3];
+        *order = 1;
+    }
+    if (*order == 2 && (veq(cp[1], cp[0]) || veq(cp[1], cp[2]))) {
+        cp[1] = cp[2];
+        *order = 1;
+    }
+    if (*order == 1 && veq(cp[0], cp[1]))
+        *order = 0;
+}
+
+static int curve_ordering_at(const v2 *corner, int before, int after) {                      /* convergent-curve-ordering.cpp:48-119 */
+    if (!(before > 0 && after > 0))
+        return 0;
+    v2 a1, a2 = V(0, 0), a3 = V(0, 0), b1, b2 = V(0, 0), b3 = V(0, 0);
+    a1 = vsub(corner[-1], corner[0]);
+    b1 = vsub(corner[1], corner[0]);
+    if (before >= 2)
+        a2 = vsub(vsub(corner[-2], corner[-1]), a1);
+    if (after >= 2)
+        b2 = vsub(vsub(corner[2], corner[1]), b1);
+    if (before >= 3) {
+        a3 = vsub(vsub(vsub(corner[-3], corner[-2]), vsub(corner[-2], corner[-1])), a2);
+        a2 = smul(3, a2);                                                                    /* Vector2 *= double: x *= v, y *= v */
+    }
+    if (after >= 3) {
+        b3 = vsub(vsub(vsub(corner[3], corner[2]), vsub(corner[2], corner[1])), b2);
+        b2 = smul(3, b2);
+    }
+    a1 = smul(before, a1);
+    b1 = smul(after, b1);
+    double d;
+    if (vnonzero(a1) && vnonzero(b1)) {
+        double as = vlen(a1), bs = vlen(b1);
+        if ((d = as*cross(a1, b2)+bs*cross(a2, b1)))
+            return isign(d);
+        if ((d = as*as*cross(a1, b3)+as*bs*cross(a2, b2)+bs*bs*cross(a3, b1)))
+            return isign(d);
+        if ((d = as*cross(a2, b3)+bs*cross(a3, b2)))
+            return isign(d);
+        return isign(cross(a3, b3));
+    }
+    int s = 1;
+    if (vnonzero(a1)) {
+        b1 = a1;
+        a1 = b2, b2 = a2, a2 = a1;
+        a1 = b3, b3 = a3, a3 = a1;
+        s = -1;
+    }
+    if (vnonzero(b1)) {
+        if ((d = cross(a3, b1)))
+            return s*isign(d);
+        if ((d = cross(a2, b2)))
+            return s*isign(d);
+        if ((d = cross(a3, b2)))
+            return s*isign(d);
+        if ((d = cross(a2, b3)))
+            return s*isign(d);
+        return s*isign(cross(a3, b3));
+    }
+    if ((d = sqrt(vlen(a2))*cross(a2, b3)+sqrt(vlen(b2))*cross(a3, b2)))
+        return isign(d);
+    return isign(cross(a3, b3));
+}
+
+static int convergent_curve_ordering(const edge_t *a, const edge_t *b) {                     /* convergent-curve-ordering.cpp:121-138 */
+    v2 cps[12];
+    for (int i = 0; i < 12; ++i)
+        cps[i] = V(0, 0);
+    v2 *corner = cps+4, *tmp = cps+8;
+    int ao = a->type, bo = b->type;
+    for (int i = 0; i <= ao; ++i)
+        tmp[i] = a->p[i];
+    for (int i = 0; i <= bo; ++i)
+        corner[i] = b->p[i];
+    if (!veq(tmp[ao], corner[0]))
+        return 0;
+    simplify_degenerate_curve(tmp, &ao);
+    simplify_degenerate_curve(corner, &bo);
+    for (int i = 0; i < ao; ++i)
+        corner[i-ao] = tmp[i];
+    return curve_ordering_at(corner, ao, bo);
+}
+
+/* Shape::normalize on one contour; edges[] has room for 3 entries at least. Returns the new edge count. */
+static int normalize_contour(edge_t *edges, int n) {
+    if (n == 1) {
+        edge_t parts[3];
+        split_in_thirds(&edges[0], parts);
+        edges[0] = parts[0], edges[1] = parts[1], edges[2] = parts[2];
+        return 3;
+    }
+    if (n > 0) {
+        int prev = n-1;
+        for (int i = 0; i < n; ++i) {
+            v2 prevDir = vnormalize(edge_direction(&edges[prev], 1), 0);
+            v2 curDir = vnormalize(edge_direction(&edges[i], 0), 0);
+            if (dot(prevDir, curDir) < CORNER_DOT_EPSILON-1) {
+                double factor = DECONVERGE_OVERSHOOT*sqrt(1-(CORNER_DOT_EPSILON-1)*(CORNER_DOT_EPSILON-1))/(CORNER_DOT_EPSILON-1);
+                v2 axis = smul(factor, vnormalize(vsub(curDir, prevDir), 0));
+                if (convergent_curve_ordering(&edges[prev], &edges[i]) < 0)
+                    axis = vneg(axis);
+                deconverge_edge(&edges[prev], 1, vorthogonal(axis, 1));
+                deconverge_edge(&edges[i], 0, vorthogonal(axis, 0));
+            }
+            prev = i;
+        }
+    }
+    return n;
+}
+
+static int seed_extract2(unsigned long long *seed) { int v = (int) (*seed)&1; *seed >>= 1; return v; }   /* edge-coloring.cpp:36-40 */
+static int seed_extract3(unsigned long long *seed) { int v = (int) (*seed%3); *seed /= 3; return v; }      /* :42-46 */
+static void switch_color(int *color, unsigned long long *seed) {                                          /* :53-56 */
+    int shifted = *color<<(1+seed_extract2(seed));
+    *color = (shifted|shifted>>3)&7;
+}
+static void switch_color_banned(int *color, unsigned long long *seed, int banned) {                       /* :58-64 */
+    int combined = *color&banned;
+    if (combined == 1 || combined == 2 || combined == 4)
+        *color = combined^7;
+    else
+        switch_color(color, seed);
+}
+static int symmetrical_trichotomy(int position, int n) { return (int) (3+2.875*position/(n-1)-1.4375+.5)-3; } /* :18-20 */
+static int is_corner(v2 aDir, v2 bDir, double crossThreshold) {                                           /* :22-24 */
+    return dot(aDir, bDir) <= 0 || fabs(cross(aDir, bDir)) > crossThreshold;
+}
+
+/* edgeColoringSimple on one contour (edge-coloring.cpp:73-141); color/seed are the shape-wide running state. edges[] has room for
+ * 6 entries at least; corners[] for n. Returns the new edge count. */
+static int color_contour_simple(edge_t *edges, int n, int *corners, double crossThreshold, int *color, unsigned long long *seed) {
+    if (n == 0)
+        return 0;
+    int nCorners = 0;
+    v2 prevDirection = edge_direction(&edges[n-1], 1);
+    for (int i = 0; i < n; ++i) {
+        if (is_corner(vnormalize(prevDirection, 0), vnormalize(edge_direction(&edges[i], 0), 0), crossThreshold))
+            corners[nCorners++] = i;
+        prevDirection = edge_direction(&edges[i], 1);
+    }
+    if (nCorners == 0) {
+        switch_color(color, seed);
+        for (int i = 0; i < n; ++i)
+            edges[i].color = *color;
+    } else if (nCorners == 1) {
+        int colors[3];
+        switch_color(color, seed);
+        colors[0] = *color;
+        colors[1] = 7;
+        switch_color(color, seed);
+        colors[2] = *color;
+        int corner = corners[0];
+        if (n >= 3) {
+            for (int i = 0; i < n; ++i)
+                edges[(corner+i)%n].color = colors[1+symmetrical_trichotomy(i, n)];
+        } else {
+            edge_t parts[6];
+            split_in_thirds(&edges[0], parts+3*corner);
+            if (n >= 2) {
+                split_in_thirds(&edges[1], parts+3-3*corner);
+                parts[0].color = parts[1].color = colors[0];
+                parts[2].color = parts[3].color = colors[1];
+                parts[4].color = parts[5].color = colors[2];
+                for (int i = 0; i < 6; ++i)
+                    edges[i] = parts[i];
+                return 6;
+            }
+            parts[0].color = colors[0];
+            parts[1].color = colors[1];
+            parts[2].color = colors[2];
+            for (int i = 0; i < 3; ++i)
+                edges[i] = parts[i];
+            return 3;
+        }
+    } else {
+        int spline = 0, start = corners[0];
+        switch_color(color, seed);
+        int initialColor = *color;
+        for (int i = 0; i < n; ++i) {
+            int index = (start+i)%n;
+            if (spline+1 < nCorners && corners[spline+1] == index) {
+                ++spline;
+                switch_color_banned(color, seed, (spline == nCorners-1)*initialColor);
+            }
+            edges[index].color = *color;
+        }
+    }
+    return n;
+}
+
+/* normalize (if do_normalize) then edgeColoringSimple (if coloring == 1) of one shape. Output arrays: out_offsets[C+1], out_points[3E*8],
+ * out_types[3E], out_colors[3E]. Returns the number of output edges. */
+int orc_shape_prepare(const orc_shape *in, int do_normalize, int coloring, double angle_threshold, unsigned long long seed,
+                      int32_t *out_offsets, double *out_points, int32_t *out_types, int32_t *out_colors) {
+    const int C = in->n_contours;
+    double crossThreshold = sin(angle_threshold);
+    int color = 0;
+    if (coloring == 1) {                                                                     /* initColor, edge-coloring.cpp:48-51 */
+        static const int colors[3] = { 6, 5, 3 };
+        color = colors[seed_extract3(&seed)];
+    }
+    int at = 0;
+    out_offsets[0] = 0;
+    for (int c = 0; c < C; ++c) {
+        const int b = in->contour_offsets[c], n0 = in->contour_offsets[c+1]-b;
+        edge_t *edges = (edge_t *) malloc(sizeof(edge_t)*(size_t) (n0 > 2 ? n0 : 6));
+        int *corners = (int *) malloc(sizeof(int)*(size_t) (n0 > 2 ? n0 : 6));
+        for (int i = 0; i < n0; ++i)
+            edges[i] = load_edge(in, b+i);
+        int n = n0;
+        if (do_normalize)
+            n = normalize_contour(edges, n);
+        if (coloring == 1)
+            n = color_contour_simple(edges, n, corners, crossThreshold, &color, &seed);
+        for (int i = 0; i < n; ++i, ++at) {
+            for (int k = 0; k < 4; ++k) {
+                out_points[8*(size_t) at+2*k] = k <= edges[i].type ? edges[i].p[k].x : 0;
+                out_points[8*(size_t) at+2*k+1] = k <= edges[i].type ? edges[i].p[k].y : 0;
+            }
+            out_types[at] = edges[i].type;
+            out_colors[at] = edges[i].color;
+        }
+        out_offsets[c+1] = at;
+        free(edges);
+        free(corners);
+    }
+    return at;
+}

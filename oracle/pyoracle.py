@@ -172,6 +172,19 @@ class Oracle:
         self.lib.orc_sign_correction(C.byref(s), n, _p(px, _fp), w, h, w*n, int(y_down), _p(x4, _dp), C.c_float(zero), fill_rule)
         return px
 
+    def shape_prepare(self, shape, normalize=True, coloring=1, angle=3.0, seed=0):
+        """Shape::normalize + edgeColoringSimple (core/Shape.cpp:65-92, core/edge-coloring.cpp:68-142) -> FlatArrays."""
+        f = _flat(shape)
+        s = f.orc()
+        ne = int(f.contour_offsets[-1])
+        offs = np.zeros(f.n_contours+1, np.int32)
+        pts = np.zeros((max(3*ne, 1), 8))
+        types = np.zeros(max(3*ne, 1), np.int32)
+        colors = np.zeros(max(3*ne, 1), np.int32)
+        self.lib.orc_shape_prepare.argtypes = [C.POINTER(_OrcShape), C.c_int, C.c_int, C.c_double, C.c_ulonglong, _ip, _dp, _ip, _ip]
+        n = self.lib.orc_shape_prepare(C.byref(s), int(normalize), int(coloring), float(angle), int(seed), _p(offs, _ip), _p(pts, _dp), _p(types, _ip), _p(colors, _ip))
+        return FlatArrays(offs, pts[:n], types[:n], colors[:n], bool(f.inverse_y))
+
     def pixel_float_to_byte(self, a):
         """pixelFloatToByte (core/pixel-conversion.hpp:8-10), elementwise."""
         a = _arr(a, np.float32)
@@ -380,6 +393,14 @@ class Ref:
         if own:
             self.free(hd)
         return px
+
+    def shape_prepare(self, shape, normalize=True, coloring=1, angle=3.0, seed=0):
+        """The reference's own Shape::normalize + edgeColoringSimple on a copy of `shape` -> FlatArrays."""
+        h = self.shape_from_flat(shape)
+        self.prepare(h, angle, seed, normalize=normalize, color=bool(coloring))
+        fa = self.flatten(h)
+        self.free(h)
+        return fa
 
     def pixel_float_to_byte(self, a):
         """pixelFloatToByte (core/pixel-conversion.hpp:8-10), elementwise."""

@@ -13,7 +13,7 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 
 
 def build():
-    srcs = [os.path.join(HERE, "hostemu.cpp")]+[os.path.join(CSRC, f) for f in ("msdf_device.hpp", "msdf_prep.hpp", "msdf_ec.hpp", "msdf_ec_fast.hpp", "msdf_cull.hpp", "msdf_scanline.hpp")]
+    srcs = [os.path.join(HERE, "hostemu.cpp")]+[os.path.join(CSRC, f) for f in ("msdf_device.hpp", "msdf_prep.hpp", "msdf_ec.hpp", "msdf_ec_fast.hpp", "msdf_cull.hpp", "msdf_scanline.hpp", "msdf_shapeprep.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
         subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", SO, srcs[0]], check=True)
     return SO
@@ -93,3 +93,16 @@ class Emu:
         out = np.zeros(len(pts))
         self.lib.emu_psdf_cooperative(int(overlap), *args, len(pts), _p(pts, C.c_double), _p(out, C.c_double))
         return out
+
+    def shape_prepare(self, s, normalize=True, coloring=1, angle=3.0, seed=0):
+        from msdfgen_amd.shape import FlatShape
+        keep, args = self._shape(s)
+        ne = int(np.asarray(s.contour_offsets)[-1])
+        offs = np.zeros(s.n_contours+1, np.int32)
+        pts = np.zeros((max(3*ne, 1), 8))
+        types = np.zeros(max(3*ne, 1), np.uint8)
+        colors = np.zeros(max(3*ne, 1), np.uint8)
+        self.lib.emu_shape_prepare.restype = C.c_int
+        n = self.lib.emu_shape_prepare(*args, int(normalize), int(coloring), C.c_double(angle), C.c_ulonglong(int(seed)), _p(offs, C.c_int32), _p(pts, C.c_double),
+                                       _p(types, C.c_uint8), _p(colors, C.c_uint8))
+        return FlatShape(offs, pts[:n], types[:n].astype(np.int32), colors[:n].astype(np.int32))

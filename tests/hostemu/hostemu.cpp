@@ -15,6 +15,7 @@
 #include "../../msdfgen_amd/csrc/msdf_ec_fast.hpp"
 #include "../../msdfgen_amd/csrc/msdf_cull.hpp"
 #include "../../msdfgen_amd/csrc/msdf_scanline.hpp"
+#include "../../msdfgen_amd/csrc/msdf_shapeprep.hpp"
 
 using namespace msdfhip;
 
@@ -476,4 +477,45 @@ extern "C" void emu_psdf_cooperative(int overlap, int nC, const int32_t *co, con
             shapeDistanceSimple<2>(d.recs.data(), edges, nC, q, o);
         out[i] = o[0];
     }
+}
+
+// Mirrors the preparation passes of msdfhip_batch_create_prepared for ONE shape (msdf_shapeprep.hpp): normalizedCount ->
+// normalizeContour (a "thread" per contour) -> colouredCount -> prefix -> colourContour along the shape (a "thread" per glyph).
+// Output arrays sized for 3*E edges; returns the number of output edges.
+#include <cmath>
+extern "C" int emu_shape_prepare(int nC, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors, int doNormalize,
+                                 int coloring, double angleThreshold, unsigned long long seed, int32_t *outCo, double *outPoints,
+                                 uint8_t *outTypes, uint8_t *outColors) {
+    const int nE = co[nC];
+    EdgeArrays raw = { const_cast<double *>(points), const_cast<uint8_t *>(types), const_cast<uint8_t *>(colors) };
+    std::vector<int32_t> co1(nC+1, 0);
+    for (int c = 0; c < nC; ++c)
+        co1[c+1] = co1[c]+(doNormalize ? normalizedCount(co[c+1]-co[c]) : co[c+1]-co[c]);
+    std::vector<double> p1((size_t) 8*(co1[nC]+1));
+    std::vector<uint8_t> t1(co1[nC]+1), c1(co1[nC]+1);
+    EdgeArrays norm = { p1.data(), t1.data(), c1.data() };
+    for (int c = 0; c < nC; ++c) {
+        if (doNormalize)
+            normalizeContour(raw, co[c], co[c+1]-co[c], norm, co1[c]);
+        else
+            for (int i = 0; i < co[c+1]-co[c]; ++i)
+                storeEdge(norm, co1[c]+i, loadEdge(raw, co[c]+i));
+    }
+    (void) nE;
+    EdgeArrays out = { outPoints, outTypes, outColors };
+    if (!coloring) {
+        for (int c = 0; c <= nC; ++c)
+            outCo[c] = co1[c];
+        for (int e = 0; e < co1[nC]; ++e)
+            storeEdge(out, e, loadEdge(norm, e));
+        return co1[nC];
+    }
+    const double crossThreshold = sin(angleThreshold);
+    outCo[0] = 0;
+    for (int c = 0; c < nC; ++c)
+        outCo[c+1] = outCo[c]+colouredCount(norm, co1[c], co1[c+1]-co1[c], crossThreshold);
+    int color = initColor(seed);
+    for (int c = 0; c < nC; ++c)
+        colourContour(norm, co1[c], co1[c+1]-co1[c], out, outCo[c], crossThreshold, color, seed);
+    return outCo[nC];
 }

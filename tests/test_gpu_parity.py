@@ -516,3 +516,66 @@ def test_tiles_to_bytes_atlas_blit(latin, oracle):
     with pytest.raises(ValueError):
         gb.to_bytes(tiles, atlas, [o+aw*ah*4 for o in offs], aw*4)
     gb.close()
+
+
+# ---- shape preparation on the device (Shape::normalize + edgeColoringSimple)
+
+def _prep_fixture():
+    z = load_npz("prep.npz")
+    mk = lambda t: ShapeBatch(z[t+"_gco"].astype(np.int32), z[t+"_co"].astype(np.int32), z[t+"_points"], z[t+"_types"].astype(np.int32),  # noqa: E731
+                              z[t+"_colors"].astype(np.int32), np.zeros(len(z["names"]), bool), [str(n) for n in z["names"]])
+    return mk("raw"), mk("prep"), mk("norm"), z["seeds"]
+
+
+def _same_batch(a, b, what):
+    assert (a.glyph_contour_offsets == b.glyph_contour_offsets).all() and (a.contour_offsets == b.contour_offsets).all(), what+": offsets"
+    assert (a.types == b.types).all(), what+": types"
+    assert (a.colors == b.colors).all(), what+": colours"
+    pa, pb = np.ascontiguousarray(a.points, np.float64), np.ascontiguousarray(b.points, np.float64)
+    assert (pa.view(np.uint64) == pb.view(np.uint64)).all(), what+": %d control-point values differ bitwise" % int((pa.view(np.uint64) != pb.view(np.uint64)).sum())
+
+
+def test_shape_preparation_on_device_matches_reference_fixture(oracle):
+    """Raw outlines (306 font glyphs + hand-built rare cases: single-edge contours, two-edge teardrops, cusps that deconverge into
+    cubics) prepared by msdfhip_batch_create_prepared: bit-identical to the compiled reference's normalize + edgeColoringSimple
+    (tests/golden/prep.npz); the prepared batch then renders exactly what the oracle renders from the reference-prepared shapes."""
+    raw, prep, norm, seeds = _prep_fixture()
+    gb = M.GlyphBatch.from_raw(raw, True, 1, 3.0, seeds=seeds)
+    _same_batch(gb.shapes, prep, "normalize + edgeColoringSimple")
+    pick = list(range(0, raw.n_glyphs, 13))+list(range(raw.n_glyphs-23, raw.n_glyphs))
+    extent = [gb.shapes.shape(g).bounds() for g in range(raw.n_glyphs)]
+    pick = [g for g in pick if extent[g][2]-extent[g][0] > 1e-3 and extent[g][3]-extent[g][1] > 1e-3]   # a flat outline has no frame
+    # synthetic-2 / -10 contain a quadratic that runs out and straight back over itself (p0 == p2, collinear control points): the sign of
+    # its distance is nonZeroSign(cross) of two PARALLEL vectors, i.e. rounding noise of the cubic root -- the reference's own result
+    # there changes with the last ulp of acos/cos (DESIGN.md 4). Their preparation is compared above; their rendering is not.
+    pick = [g for g in pick if raw.names[g] not in ("synthetic-2", "synthetic-10")]
+    xfs = np.stack([autoframe(b if b[2]-b[0] > 1e-3 and b[3]-b[1] > 1e-3 else (0, 0, 1, 1), 32, 32, 4) for b in extent])
+    tiles = gb.generate(3, 32, 32, xfs).cpu().numpy()
+    for g in pick:
+        close(tiles[g], oracle.generate(prep.shape(g), 3, 32, 32, xfs[g]), "prepared glyph %s" % raw.names[g])
+    gb.close()
+    gb = M.GlyphBatch.from_raw(raw, True, 0)
+    _same_batch(gb.shapes, norm, "normalize only")
+    gb.close()
+    gb = M.GlyphBatch.from_raw(prep, False, 0)                          # nothing to do: a plain upload
+    _same_batch(gb.shapes, prep, "identity")
+    gb.close()
+
+
+def test_shape_preparation_random_vs_oracle(oracle):
+    rng = np.random.default_rng(8)
+    shapes, want, seeds = [], [], []
+    for i in range(200):
+        s = synth.random_shape(9500+i, n_contours=int(rng.integers(1, 6)), edges_per_contour=(1, 8), kinds=(1, 2, 3), holes=bool(i & 1))
+        s.colors[:] = 7
+        sd = int(rng.integers(0, 2**50))
+        shapes.append(s), seeds.append(sd)
+        fa = oracle.shape_prepare(s, True, 1, 2.5, sd)
+        want.append(FlatShape(fa.contour_offsets, fa.points, fa.types, fa.colors))
+    gb = M.GlyphBatch.from_raw(ShapeBatch.from_shapes(shapes), True, 1, 2.5, seeds=np.array(seeds, np.uint64))
+    _same_batch(gb.shapes, ShapeBatch.from_shapes(want), "random shapes, angle 2.5")
+    gb.close()
+    gb = M.GlyphBatch.from_raw(ShapeBatch.from_shapes(shapes[:50]), False, 1, 3.0, seed=77)    # one seed for all, colouring only
+    want = [oracle.shape_prepare(s, False, 1, 3.0, 77) for s in shapes[:50]]
+    _same_batch(gb.shapes, ShapeBatch.from_shapes([FlatShape(f.contour_offsets, f.points, f.types, f.colors) for f in want]), "colouring only")
+    gb.close()

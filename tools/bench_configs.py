@@ -91,6 +91,19 @@ def main():
     report("cfg4: 8192 CJK-like synthetic glyphs msdf 48x48 default EC", cj, 3, 48, 48, cx, reps=max(2, args.reps//3))
     report("cfg4 shapes, simple combiner (overlapSupport=false)", cj, 3, 48, 48, cx, config=M.MSDFGeneratorConfig(False), reps=max(2, args.reps//3))
     report("cfg4 shapes, sdf 48x48", cj, 1, 48, 48, cx, reps=max(2, args.reps//3))
+    if not args.only or "prep" in args.only:                          # row f3: raw outlines -> prepared, digested batch (host call, incl. copies)
+        import time
+        z = np.load(os.path.join(ROOT, "tests", "golden", "prep.npz"))
+        raw = ShapeBatch(z["raw_gco"].astype(np.int32), z["raw_co"].astype(np.int32), z["raw_points"], z["raw_types"].astype(np.int32),
+                         z["raw_colors"].astype(np.int32), np.zeros(len(z["names"]), bool), [str(n) for n in z["names"]])
+        big = raw.select([i % 283 for i in range(8192)])              # the font glyphs of the fixture, tiled
+        M.GlyphBatch.from_raw(big).close()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            M.GlyphBatch.from_raw(big, True, 1, 3.0, seed=0).close()
+        dt = (time.perf_counter()-t0)/5
+        print(json.dumps({"config": "prep: Shape::normalize + edgeColoringSimple + digest of 8192 raw glyphs (%d edges) via msdfhip_batch_create_prepared, host arrays in, "
+                                    "prepared shapes read back" % big.n_edges, "ms_per_call": round(1e3*dt, 3), "glyphs_per_s": round(8192/dt)}), flush=True)
     logo = synth.logo_shape(5)
     lb = ShapeBatch.from_shapes([logo])
     lx = np.stack([autoframe(logo.bounds(), 1024, 1024, 8)])
