@@ -221,6 +221,15 @@ int msdfhip_batch_download(const MsdfHipBatch *batch, int32_t *contour_offsets, 
 int msdfhip_tiles_to_bytes(const float *d_tiles, int n_glyphs, int width, int height, int channels, const MsdfHipGlyph *d_glyphs,
                            uint8_t *d_atlas, void *stream);
 
+/* renderSDF(output, sdf, sdfPxRange, sdThreshold) for n_glyphs packed tiles: d_out[g][oh][ow][out_channels] from
+ * d_sdf[g][sh][sw][sdf_channels], memory rows as they are.
+ *   replaces core/render-sdf.cpp:14-170 (declared core/render-sdf.h:12-17); channel pairs as the reference's overloads:
+ *   1<-1, 3<-1, 1<-3, 3<-3, 1<-4, 4<-4. range_lower == range_upper selects the thresholded rendering (core/render-sdf.cpp:16-23).
+ * msdfhip_simulate_8bit: simulate8bit (core/render-sdf.cpp:172-188) on n floats in place. Both asynchronous on `stream`. */
+int msdfhip_render_sdf(const float *d_sdf, int n_glyphs, int sdf_width, int sdf_height, int sdf_channels, float *d_out, int out_width, int out_height,
+                       int out_channels, double range_lower, double range_upper, float sd_threshold, void *stream);
+int msdfhip_simulate_8bit(float *d_pixels, size_t n, void *stream);
+
 /* Timing hook for bench.py: average device time in milliseconds of the dominant kernel (the distance-field kernel) and of
  * the passes after it (sign correction + error correction, per error-correction launch) over the launches recorded since the
  * last call with reset != 0, measured with hipEvents on the launching stream.

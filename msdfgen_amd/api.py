@@ -6,6 +6,7 @@ on top of the C ABI.  Same names, argument meaning and defaults as the reference
     msdf_error_correction(sdf, shape, transformation, config)
     distance_sign_correction(sdf, shape, projection, sdf_zero_value, fill_rule)
     rasterize(output, shape, projection, fill_rule)
+    render_sdf(sdf_tiles, out_width, out_height, out_channels, sdf_px_range, sd_threshold) / simulate_8bit(tiles)   -- device tensors
     shape_distance(shape, selector, overlap_support, points)      -- ShapeDistanceFinder::oneShotDistance
 
 `GlyphBatch` is the batched, device-resident front door (one launch for thousands of glyph tiles); it uses torch only to own
@@ -221,6 +222,30 @@ def rasterize(output, shape, projection, fill_rule=FILL_NONZERO, y_orientation=Y
     _lib.check(lib.msdfhip_rasterize(px, w, h, stride, flip, *sargs, _lib.ptr(xf, _lib._dp), int(fill_rule)))
     del keep
     return output
+
+
+def render_sdf(sdf_tiles, out_width, out_height, out_channels, sdf_px_range=(0., 0.), sd_threshold=.5, out=None, stream=None):
+    """renderSDF (core/render-sdf.h:12-17) of a device tensor of tiles (G, H, W, N) -> (G, out_height, out_width, out_channels).
+    sdf_px_range: Range as (lower, upper), or a width w meaning (-w/2, +w/2); (0, 0) = thresholded rendering."""
+    import torch
+    lo, hi = (-.5*sdf_px_range, .5*sdf_px_range) if np.isscalar(sdf_px_range) else sdf_px_range
+    g, h, w, n = sdf_tiles.shape
+    assert sdf_tiles.dtype == torch.float32 and sdf_tiles.is_contiguous()
+    if out is None:
+        out = torch.empty((g, out_height, out_width, out_channels), dtype=torch.float32, device=sdf_tiles.device)
+    s = (stream or torch.cuda.current_stream(sdf_tiles.device)).cuda_stream
+    _lib.check(_lib.load().msdfhip_render_sdf(sdf_tiles.data_ptr(), g, w, h, n, out.data_ptr(), out_width, out_height, out_channels, float(lo), float(hi),
+                                              float(sd_threshold), s))
+    return out
+
+
+def simulate_8bit(tiles, stream=None):
+    """simulate8bit (core/render-sdf.h:20-22), in place on a contiguous float32 device tensor."""
+    import torch
+    assert tiles.dtype == torch.float32 and tiles.is_contiguous()
+    s = (stream or torch.cuda.current_stream(tiles.device)).cuda_stream
+    _lib.check(_lib.load().msdfhip_simulate_8bit(tiles.data_ptr(), tiles.numel(), s))
+    return tiles
 
 
 def shape_distance(shape, selector, overlap_support, points):

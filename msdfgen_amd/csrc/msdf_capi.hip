@@ -778,6 +778,60 @@ int msdfhip_tiles_to_bytes(const float *dTiles, int nGlyphs, int w, int h, int c
     return MSDFHIP_OK;
 }
 
+int msdfhip_render_sdf(const float *dSdf, int nGlyphs, int sw, int sh, int ns, float *dOut, int ow, int oh, int no, double rangeLower, double rangeUpper,
+                       float sdThreshold, void *streamPtr) {
+    if (nGlyphs < 0 || sw < 0 || sh < 0 || ow < 0 || oh < 0)
+        return fail(MSDFHIP_ERR_INVALID, "bad arguments to msdfhip_render_sdf");
+    if (!((no == 1 && (ns == 1 || ns == 3 || ns == 4)) || (no == 3 && (ns == 1 || ns == 3)) || (no == 4 && ns == 4)))
+        return fail(MSDFHIP_ERR_INVALID, "renderSDF has no overload for %d <- %d channels (core/render-sdf.h:12-17)", no, ns);
+    const size_t total = (size_t) nGlyphs*ow*oh;
+    if (!total)
+        return MSDFHIP_OK;
+    if (!dSdf || !dOut || sw == 0 || sh == 0)
+        return fail(MSDFHIP_ERR_INVALID, "NULL or empty distance field");
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    const double scaleX = (double) sw/ow, scaleY = (double) sh/oh;       // render-sdf.cpp:15
+    const int threshold = rangeLower == rangeUpper;
+    double mapScale = 1, mapTranslate = 0;
+    float sdBias = 0;
+    if (!threshold) {
+        const double f = (double) (ow+oh)/(sw+sh);                       // render-sdf.cpp:24: sdfPxRange *= ...
+        rangeLower *= f, rangeUpper *= f;
+        const double rangeWidth = rangeUpper-rangeLower;                 // DistanceMapping::inverse(Range), DistanceMapping.cpp:6-9
+        mapScale = rangeWidth, mapTranslate = rangeLower/(rangeWidth ? rangeWidth : 1);
+        sdBias = .5f-sdThreshold;
+    }
+    hipStream_t stream = (hipStream_t) streamPtr;
+    const unsigned blocks = (unsigned) ((total+255)/256 < 65536 ? (total+255)/256 : 65536);
+    #define RENDER(NO, NS) hipLaunchKernelGGL((k_render_sdf<NO, NS>), dim3(blocks), dim3(256), 0, stream, dSdf, nGlyphs, sw, sh, dOut, ow, oh, scaleX, scaleY, \
+                                              threshold, mapScale, mapTranslate, sdThreshold, sdBias)
+    if (no == 1 && ns == 1) RENDER(1, 1);
+    else if (no == 3 && ns == 1) RENDER(3, 1);
+    else if (no == 1 && ns == 3) RENDER(1, 3);
+    else if (no == 3 && ns == 3) RENDER(3, 3);
+    else if (no == 1 && ns == 4) RENDER(1, 4);
+    else RENDER(4, 4);
+    #undef RENDER
+    HIPCHK(hipGetLastError());
+    return MSDFHIP_OK;
+}
+
+int msdfhip_simulate_8bit(float *dPixels, size_t n, void *streamPtr) {
+    if (!n)
+        return MSDFHIP_OK;
+    if (!dPixels)
+        return fail(MSDFHIP_ERR_INVALID, "NULL argument");
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    const unsigned blocks = (unsigned) ((n+255)/256 < 65536 ? (n+255)/256 : 65536);
+    hipLaunchKernelGGL(k_simulate_8bit, dim3(blocks), dim3(256), 0, (hipStream_t) streamPtr, dPixels, n);
+    HIPCHK(hipGetLastError());
+    return MSDFHIP_OK;
+}
+
 int msdfhip_batch_generate_host(const MsdfHipBatch *b, int mode, int w, int h, const MsdfHipGlyph *glyphs, float *out, size_t outFloats,
                                 uint8_t *stencil, const MsdfHipConfig *cfg) {
     if (!b || !glyphs || !out)

@@ -786,6 +786,56 @@ __global__ void k_tiles_to_bytes(const float *tiles, const MsdfHipGlyph *glyphs,
     }
 }
 
+// ------------------------------------------------------------------------------------------- renderSDF / simulate8bit (row f4)
+
+// renderSDF (core/render-sdf.cpp:14-170) of G tiles: out[g][oh][ow][NO] from sdf[g][sh][sw][NS]; one thread per output texel.
+// threshold != 0: sdfPxRange.lower == upper (binary output); else mapScale/mapTranslate = DistanceMapping::inverse(range scaled to
+// the output size), computed by the host in fp64 exactly as render-sdf.cpp:24-25. Rows are memory rows (the reference does not reorient).
+template <int NO, int NS>
+__global__ void k_render_sdf(const float *sdf, int nGlyphs, int sw, int sh, float *out, int ow, int oh, double scaleX, double scaleY, int threshold,
+                             double mapScale, double mapTranslate, float sdThreshold, float sdBias) {
+    const size_t perGlyph = (size_t) ow*oh, total = perGlyph*nGlyphs;
+    for (size_t i = (size_t) blockIdx.x*blockDim.x+threadIdx.x; i < total; i += (size_t) gridDim.x*blockDim.x) {
+        const int g = (int) (i/perGlyph);
+        const int rem = (int) (i-(size_t) g*perGlyph);
+        const int y = rem/ow, x = rem-y*ow;
+        const float *px = sdf+(size_t) g*sw*sh*NS;
+        V2 pos = mk(scaleX*(x+.5), scaleY*(y+.5));                  // scale*Point2(x+.5, y+.5)
+        pos.x = clampd(pos.x, (double) sw);                         // interpolate, bitmap-interpolation.hpp:10-25
+        pos.y = clampd(pos.y, (double) sh);
+        pos.x -= .5, pos.y -= .5;
+        int l = (int) floor(pos.x), b = (int) floor(pos.y);
+        int r = l+1, t = b+1;
+        const double lr = pos.x-l, bt = pos.y-b;
+        l = clampi(l, sw-1), r = clampi(r, sw-1);
+        b = clampi(b, sh-1), t = clampi(t, sh-1);
+        float sd[NS];
+        for (int c = 0; c < NS; ++c)
+            sd[c] = mixf(mixf(px[((size_t) b*sw+l)*NS+c], px[((size_t) b*sw+r)*NS+c], lr), mixf(px[((size_t) t*sw+l)*NS+c], px[((size_t) t*sw+r)*NS+c], lr), bt);
+        float in[NO];
+        if (NO == 1 && NS >= 3)
+            in[0] = medianf(sd[0], sd[NS >= 3 ? 1 : 0], sd[NS >= 3 ? 2 : 0]);
+        else
+            for (int c = 0; c < NO; ++c)
+                in[c] = sd[c < NS ? c : 0];
+        float *o = out+i*NO;
+        for (int c = 0; c < NO; ++c) {
+            if (threshold)
+                o[c] = (float) (in[c] >= sdThreshold);
+            else {                                                  // distVal, render-sdf.cpp:10-12
+                const double v = mapScale*((double) (in[c]+sdBias)+mapTranslate)+.5;
+                o[c] = (float) (v >= 0 && v <= 1 ? v : (double) (v > 0));
+            }
+        }
+    }
+}
+
+// simulate8bit (core/render-sdf.cpp:172-188): p = pixelByteToFloat(pixelFloatToByte(p)).
+__global__ void k_simulate_8bit(float *px, size_t n) {
+    for (size_t i = (size_t) blockIdx.x*blockDim.x+threadIdx.x; i < n; i += (size_t) gridDim.x*blockDim.x)
+        px[i] = 1.f/255.f*(float) pixelFloatToByte(px[i]);
+}
+
 // ------------------------------------------------------------------------------------------------- distance queries
 
 template <int SEL, bool OVERLAP>

@@ -1845,3 +1845,67 @@ int orc_shape_prepare(const orc_shape *in, int do_normalize, int coloring, doubl
     }
     return at;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * renderSDF (core/render-sdf.cpp:10-170) and simulate8bit (:172-188). Bitmaps are plain row-major here
+ * (the reference's renderSDF does not reorient). Channel pairs as the reference's overloads: out 1 <- sdf 1|3|4 (median of rgb),
+ * out 3 <- sdf 1 (replicated) | 3, out 4 <- sdf 4.
+ */
+static void interpolate_n(float *output, const float *px, int w, int h, int N, v2 pos) {     /* bitmap-interpolation.hpp:10-25 */
+    pos.x = dclamp(pos.x, (double) w);
+    pos.y = dclamp(pos.y, (double) h);
+    pos.x -= .5, pos.y -= .5;
+    int l = (int) floor(pos.x), b = (int) floor(pos.y);
+    int r = l+1, t = b+1;
+    double lr = pos.x-l, bt = pos.y-b;
+    l = iclamp(l, w-1), r = iclamp(r, w-1);
+    b = iclamp(b, h-1), t = iclamp(t, h-1);
+    for (int i = 0; i < N; ++i)
+        output[i] = fmix(fmix(px[((size_t) b*w+l)*N+i], px[((size_t) b*w+r)*N+i], lr), fmix(px[((size_t) t*w+l)*N+i], px[((size_t) t*w+r)*N+i], lr), bt);
+}
+
+static float dist_val(float dist, double mapScale, double mapTranslate) {                    /* render-sdf.cpp:10-12 */
+    double v = mapScale*((double) dist+mapTranslate)+.5;
+    return (float) (v >= 0 && v <= 1 ? v : (double) (v > 0));
+}
+
+int orc_render_sdf(float *out, int ow, int oh, int No, const float *sdf, int sw, int sh, int Ns, double rangeLower, double rangeUpper, float sdThreshold) {
+    if (!((No == 1 && (Ns == 1 || Ns == 3 || Ns == 4)) || (No == 3 && (Ns == 1 || Ns == 3)) || (No == 4 && Ns == 4)))
+        return -1;
+    v2 scale = V((double) sw/ow, (double) sh/oh);
+    const int threshold = rangeLower == rangeUpper;
+    double mapScale = 1, mapTranslate = 0;
+    float sdBias = 0;
+    if (!threshold) {
+        double f = (double) (ow+oh)/(sw+sh);                                                 /* Range *= (Range.hpp:20-24) */
+        rangeLower *= f, rangeUpper *= f;
+        double rangeWidth = rangeUpper-rangeLower;                                           /* DistanceMapping::inverse(Range), DistanceMapping.cpp:6-9 */
+        mapScale = rangeWidth, mapTranslate = rangeLower/(rangeWidth ? rangeWidth : 1);
+        sdBias = .5f-sdThreshold;
+    }
+    for (int y = 0; y < oh; ++y)
+        for (int x = 0; x < ow; ++x) {
+            float sd[4] = { 0, 0, 0, 0 }, v[4];
+            interpolate_n(sd, sdf, sw, sh, Ns, vmulv(scale, V(x+.5, y+.5)));
+            int n = No;
+            if (No == 1 && Ns >= 3)
+                sd[0] = fmedian(sd[0], sd[1], sd[2]);
+            if (No == 3 && Ns == 1)
+                sd[1] = sd[2] = sd[0];
+            for (int i = 0; i < n; ++i)
+                v[i] = threshold ? (float) (sd[i] >= sdThreshold) : dist_val(sd[i]+sdBias, mapScale, mapTranslate);
+            if (No == 3 && Ns == 1)
+                v[1] = v[2] = v[0];
+            for (int i = 0; i < n; ++i)
+                out[((size_t) y*ow+x)*No+i] = v[i];
+        }
+    return 0;
+}
+
+void orc_simulate_8bit(float *px, long n) {                                                  /* render-sdf.cpp:172-188, pixel-conversion.hpp */
+    for (long i = 0; i < n; ++i) {
+        unsigned char b;
+        orc_pixel_float_to_byte(px+i, &b, 1);
+        px[i] = 1.f/255.f*(float) b;
+    }
+}

@@ -185,6 +185,28 @@ class Oracle:
         n = self.lib.orc_shape_prepare(C.byref(s), int(normalize), int(coloring), float(angle), int(seed), _p(offs, _ip), _p(pts, _dp), _p(types, _ip), _p(colors, _ip))
         return FlatArrays(offs, pts[:n], types[:n], colors[:n], bool(f.inverse_y))
 
+    def render_sdf(self, sdf, ow, oh, n_out, range_lower=0., range_upper=0., threshold=.5):
+        """renderSDF (core/render-sdf.h:12-17): (oh, ow, n_out) float32 from sdf (sh, sw, Ns)."""
+        sdf = _arr(sdf, np.float32)
+        sh, sw, ns = sdf.shape
+        out = np.zeros((oh, ow, n_out), np.float32)
+        fn = getattr(self.lib, self._PFX+"render_sdf")
+        fn.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_float]
+        if fn(_p(out, _fp), ow, oh, n_out, _p(sdf, _fp), sw, sh, ns, float(range_lower), float(range_upper), C.c_float(threshold)) != 0:
+            raise ValueError("renderSDF has no overload for %d <- %d channels" % (n_out, ns))
+        return out
+
+    def simulate_8bit(self, a):
+        a = np.array(a, np.float32, order="C")
+        if self._PFX == "orc_":
+            self.lib.orc_simulate_8bit.argtypes = [_fp, C.c_long]
+            self.lib.orc_simulate_8bit(_p(a, _fp), a.size)
+        else:
+            h, w, n = a.shape
+            self.lib.ref_simulate_8bit.argtypes = [_fp, C.c_int, C.c_int, C.c_int]
+            self.lib.ref_simulate_8bit(_p(a, _fp), w, h, n)
+        return a
+
     def pixel_float_to_byte(self, a):
         """pixelFloatToByte (core/pixel-conversion.hpp:8-10), elementwise."""
         a = _arr(a, np.float32)
@@ -401,6 +423,28 @@ class Ref:
         fa = self.flatten(h)
         self.free(h)
         return fa
+
+    def render_sdf(self, sdf, ow, oh, n_out, range_lower=0., range_upper=0., threshold=.5):
+        """renderSDF (core/render-sdf.h:12-17): (oh, ow, n_out) float32 from sdf (sh, sw, Ns)."""
+        sdf = _arr(sdf, np.float32)
+        sh, sw, ns = sdf.shape
+        out = np.zeros((oh, ow, n_out), np.float32)
+        fn = getattr(self.lib, self._PFX+"render_sdf")
+        fn.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_float]
+        if fn(_p(out, _fp), ow, oh, n_out, _p(sdf, _fp), sw, sh, ns, float(range_lower), float(range_upper), C.c_float(threshold)) != 0:
+            raise ValueError("renderSDF has no overload for %d <- %d channels" % (n_out, ns))
+        return out
+
+    def simulate_8bit(self, a):
+        a = np.array(a, np.float32, order="C")
+        if self._PFX == "orc_":
+            self.lib.orc_simulate_8bit.argtypes = [_fp, C.c_long]
+            self.lib.orc_simulate_8bit(_p(a, _fp), a.size)
+        else:
+            h, w, n = a.shape
+            self.lib.ref_simulate_8bit.argtypes = [_fp, C.c_int, C.c_int, C.c_int]
+            self.lib.ref_simulate_8bit(_p(a, _fp), w, h, n)
+        return a
 
     def pixel_float_to_byte(self, a):
         """pixelFloatToByte (core/pixel-conversion.hpp:8-10), elementwise."""

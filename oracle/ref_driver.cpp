@@ -27,6 +27,7 @@
 #include "core/ShapeDistanceFinder.h"
 #include "core/MSDFErrorCorrection.h"
 #include "core/pixel-conversion.hpp"
+#include "core/render-sdf.h"
 #include "core/equation-solver.h"
 
 using namespace msdfgen;
@@ -206,6 +207,26 @@ void ref_sign_correction(void *s, int channels, float *pixels, int w, int h, int
 void ref_pixel_float_to_byte(const float *in, unsigned char *out, long n) {
     for (long i = 0; i < n; ++i)
         out[i] = pixelFloatToByte(in[i]);
+}
+
+int ref_render_sdf(float *out, int ow, int oh, int No, const float *sdf, int sw, int sh, int Ns, double rangeLower, double rangeUpper, float sdThreshold) {
+    Range range(rangeLower, rangeUpper);
+    #define RENDER(NO, NS) renderSDF(BitmapSection<float, NO>(out, ow, oh), BitmapConstSection<float, NS>(sdf, sw, sh), range, sdThreshold)
+    if (No == 1 && Ns == 1) RENDER(1, 1);
+    else if (No == 3 && Ns == 1) RENDER(3, 1);
+    else if (No == 1 && Ns == 3) RENDER(1, 3);
+    else if (No == 3 && Ns == 3) RENDER(3, 3);
+    else if (No == 1 && Ns == 4) RENDER(1, 4);
+    else if (No == 4 && Ns == 4) RENDER(4, 4);
+    else return -1;
+    #undef RENDER
+    return 0;
+}
+
+void ref_simulate_8bit(float *px, int w, int h, int N) {
+    if (N == 1) simulate8bit(BitmapSection<float, 1>(px, w, h));
+    else if (N == 3) simulate8bit(BitmapSection<float, 3>(px, w, h));
+    else simulate8bit(BitmapSection<float, 4>(px, w, h));
 }
 
 void ref_rasterize(void *s, float *pixels, int w, int h, int rowStride, int yDown, const double *xf, int fillRule) {

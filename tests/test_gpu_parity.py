@@ -579,3 +579,28 @@ def test_shape_preparation_random_vs_oracle(oracle):
     want = [oracle.shape_prepare(s, False, 1, 3.0, 77) for s in shapes[:50]]
     _same_batch(gb.shapes, ShapeBatch.from_shapes([FlatShape(f.contour_offsets, f.points, f.types, f.colors) for f in want]), "colouring only")
     gb.close()
+
+
+# ---- renderSDF / simulate8bit on the device
+
+@pytest.mark.parametrize("n_out,mode", [(1, 1), (3, 1), (1, 3), (3, 3), (1, 4), (4, 4)])
+def test_render_sdf_and_simulate_8bit(latin, oracle, n_out, mode):
+    import torch
+    batch, xf64, _ = latin
+    sub = batch.select(range(40, 52))
+    gb = M.GlyphBatch(sub)
+    xfs = np.stack([autoframe(b, 40, 32, 4) for b in latin[2][40:52]])
+    tiles = gb.generate(mode, 40, 32, xfs)
+    src = tiles.cpu().numpy()
+    for ow, oh in ((40, 32), (97, 64), (17, 23)):
+        for lo, hi, thr in ((0, 0, .5), (-2, 2, .5), (-1, 3, .4)):
+            got = M.render_sdf(tiles, ow, oh, n_out, (lo, hi), thr).cpu().numpy()
+            for g in range(12):
+                want = oracle.render_sdf(src[g], ow, oh, n_out, lo, hi, thr)
+                assert (bits(got[g]) == bits(want)).all(), "renderSDF %d<-%d %dx%d glyph %d" % (n_out, src.shape[3], ow, oh, g)
+    noisy = tiles+torch.randn_like(tiles)*.3
+    want = oracle.simulate_8bit(noisy.cpu().numpy().reshape(-1, 40, noisy.shape[3]))
+    assert (bits(M.simulate_8bit(noisy).cpu().numpy().reshape(want.shape)) == bits(want)).all()
+    with pytest.raises(M.MsdfHipError):
+        M.render_sdf(tiles, 8, 8, 2)
+    gb.close()

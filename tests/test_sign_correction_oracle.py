@@ -107,3 +107,20 @@ def test_pixel_float_to_byte_oracle_vs_reference(oracle, ref):
                            np.random.default_rng(3).uniform(-.2, 1.2, 20000).astype(np.float32)])
     a, b = ref.pixel_float_to_byte(vals), oracle.pixel_float_to_byte(vals)
     assert (a == b).all() and a.min() == 0 and a.max() == 255
+
+
+@pytest.mark.parametrize("n_out,n_sdf", [(1, 1), (3, 1), (1, 3), (3, 3), (1, 4), (4, 4)])
+def test_render_sdf_oracle_vs_reference(oracle, ref, latin, n_out, n_sdf):
+    """renderSDF (core/render-sdf.cpp): every overload, up- and down-scaling, thresholded (range 0) and ranged, plus simulate8bit."""
+    batch, xf64, _ = latin
+    rng = np.random.default_rng(n_out*10+n_sdf)
+    mode = {1: 1, 3: 3, 4: 4}[n_sdf]
+    for g in (3, 33, 51):
+        sdf = ref.generate(batch.shape(g), mode, 40, 32, autoframe(latin[2][g], 40, 32, 4))
+        for ow, oh in ((40, 32), (97, 64), (17, 23)):
+            for lo, hi, thr in ((0, 0, .5), (-2, 2, .5), (-1, 3, .4), (0, 0, .6)):
+                a = ref.render_sdf(sdf, ow, oh, n_out, lo, hi, thr)
+                b = oracle.render_sdf(sdf, ow, oh, n_out, lo, hi, thr)
+                assert_bit_equal(b, a, "renderSDF %d<-%d %dx%d range (%g,%g)" % (n_out, n_sdf, ow, oh, lo, hi))
+        noisy = sdf+rng.normal(0, .3, sdf.shape).astype(np.float32)
+        assert_bit_equal(oracle.simulate_8bit(noisy), ref.simulate_8bit(noisy), "simulate8bit")
