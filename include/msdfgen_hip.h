@@ -221,6 +221,14 @@ int msdfhip_batch_download(const MsdfHipBatch *batch, int32_t *contour_offsets, 
 int msdfhip_tiles_to_bytes(const float *d_tiles, int n_glyphs, int width, int height, int channels, const MsdfHipGlyph *d_glyphs,
                            uint8_t *d_atlas, void *stream);
 
+/* estimateSDFError(sdf, shape, projection, scanlinesPerRow, fillRule) for every glyph of a batch: d_errors[g] from the
+ * packed tiles d_tiles[g][h][w][channels] (memory rows; what msdfhip_batch_generate wrote), without leaving the device.
+ *   replaces core/sdf-error-estimation.cpp:134-164 (declared core/sdf-error-estimation.h:18-20).
+ * d_glyphs[g].xf[0..3] = the Projection; d_glyphs[g].flip is read as "shape.getYAxisOrientation() == Y_DOWNWARD"
+ * (sdf-error-estimation.cpp:146; for Y-upward bitmaps that is the flip flag the tiles were generated with). Asynchronous on `stream`. */
+int msdfhip_batch_estimate_sdf_error(const MsdfHipBatch *batch, int channels, int width, int height, const MsdfHipGlyph *d_glyphs, const float *d_tiles,
+                                     int scanlines_per_row, int fill_rule, double *d_errors, void *stream);
+
 /* renderSDF(output, sdf, sdfPxRange, sdThreshold) for n_glyphs packed tiles: d_out[g][oh][ow][out_channels] from
  * d_sdf[g][sh][sw][sdf_channels], memory rows as they are.
  *   replaces core/render-sdf.cpp:14-170 (declared core/render-sdf.h:12-17); channel pairs as the reference's overloads:

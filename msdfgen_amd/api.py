@@ -388,6 +388,22 @@ class GlyphBatch:
         d["flip"] = (self.shapes.inverse_y.astype(bool) != (y_orientation == Y_DOWNWARD)).astype(np.int32)
         return self.torch.from_numpy(d.view(np.uint8).reshape(self.n_glyphs, 64)).to(self.device)
 
+    def estimate_sdf_error(self, tiles, xfs, scanlines_per_row=1, fill_rule=FILL_NONZERO, stream=None):
+        """estimateSDFError (core/sdf-error-estimation.h:18-20) of every tile (G, H, W, N) of this batch's shapes; returns a float64
+        device tensor (G,). xfs: the (G, 6) rows the tiles were generated with (only the projection part is read)."""
+        torch = self.torch
+        g, h, w, n = tiles.shape
+        assert g == self.n_glyphs and tiles.dtype == torch.float32 and tiles.is_contiguous()
+        d = np.zeros(g, _lib.GLYPH_DTYPE)
+        d["xf"][:, :4] = np.ascontiguousarray(xfs, np.float64).reshape(g, 6)[:, :4]
+        d["flip"] = self.shapes.inverse_y.astype(bool).astype(np.int32)      # shape.getYAxisOrientation() == Y_DOWNWARD
+        desc = torch.from_numpy(d.view(np.uint8).reshape(g, 64)).to(self.device)
+        out = torch.empty(g, dtype=torch.float64, device=self.device)
+        s = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        _lib.check(_lib.load().msdfhip_batch_estimate_sdf_error(self._handle, n, w, h, desc.data_ptr(), tiles.data_ptr(), int(scanlines_per_row), int(fill_rule),
+                                                                out.data_ptr(), s))
+        return out
+
     def to_bytes(self, tiles, atlas, out_offsets, row_stride, stream=None):
         """pixelFloatToByte (core/pixel-conversion.hpp:8-10) of packed float tiles (G, H, W, N) + blit of glyph g's rectangle into the
         uint8 device tensor `atlas` at byte offset out_offsets[g] with `row_stride` bytes per atlas row. Returns `atlas`."""

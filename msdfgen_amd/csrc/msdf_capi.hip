@@ -778,6 +778,50 @@ int msdfhip_tiles_to_bytes(const float *dTiles, int nGlyphs, int w, int h, int c
     return MSDFHIP_OK;
 }
 
+int msdfhip_batch_estimate_sdf_error(const MsdfHipBatch *b, int channels, int w, int h, const MsdfHipGlyph *dGlyphs, const float *dTiles,
+                                     int scanlinesPerRow, int fillRule, double *dErrors, void *streamPtr) {
+    if (!b || !dGlyphs || !dTiles || !dErrors || w < 0 || h < 0 || (channels != 1 && channels != 3 && channels != 4))
+        return fail(MSDFHIP_ERR_INVALID, "bad arguments to msdfhip_batch_estimate_sdf_error");
+    if (fillRule < 0 || fillRule > 3)
+        return fail(MSDFHIP_ERR_INVALID, "fill rule %d (must be 0..3)", fillRule);
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    hipStream_t stream = (hipStream_t) streamPtr;
+    if (b->nGlyphs == 0)
+        return MSDFHIP_OK;
+    if (w <= 1 || h <= 1 || scanlinesPerRow < 1) {                   // sdf-error-estimation.cpp:136-137: the estimate is 0
+        HIPCHK(hipMemsetAsync(dErrors, 0, sizeof(double)*(size_t) b->nGlyphs, stream));
+        return MSDFHIP_OK;
+    }
+    const size_t perGlyph = (size_t) (h-1)*scanlinesPerRow, items = perGlyph*b->nGlyphs;
+    const int refCap = 3*(b->maxEdges > 0 ? b->maxEdges : 1), sdfCap = 3*w+2;
+    const size_t perLane = (size_t) (refCap+sdfCap)*(sizeof(double)+sizeof(int));
+    size_t chunk = (512u<<20)/perLane;                               // lanes per launch: at most 512 MB of list workspace
+    chunk = chunk < 64 ? 64 : chunk/64*64;
+    if (chunk > items)
+        chunk = (items+63)/64*64;
+    double *work = NULL;
+    rc = ensureGres(b, chunk*perLane+items*sizeof(double), &work);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    double *lines = work;                                            // [items]
+    double *listX = work+items;                                      // [refCap+sdfCap][chunk]
+    int *listDir = reinterpret_cast<int *>(listX+(size_t) (refCap+sdfCap)*chunk);
+    for (size_t base = 0; base < items; base += chunk) {
+        const size_t n = items-base < chunk ? items-base : chunk;
+        const dim3 grid((unsigned) ((n+63)/64)), block(64);
+        switch (channels) {
+            case 1: hipLaunchKernelGGL(k_sdf_error_lines<1>, grid, block, 0, stream, viewOf(b), dGlyphs, dTiles, w, h, scanlinesPerRow, fillRule, base, n, listX, listDir, refCap, lines); break;
+            case 3: hipLaunchKernelGGL(k_sdf_error_lines<3>, grid, block, 0, stream, viewOf(b), dGlyphs, dTiles, w, h, scanlinesPerRow, fillRule, base, n, listX, listDir, refCap, lines); break;
+            default: hipLaunchKernelGGL(k_sdf_error_lines<4>, grid, block, 0, stream, viewOf(b), dGlyphs, dTiles, w, h, scanlinesPerRow, fillRule, base, n, listX, listDir, refCap, lines); break;
+        }
+    }
+    hipLaunchKernelGGL(k_sdf_error_sum, dim3((b->nGlyphs+63)/64), dim3(64), 0, stream, (const double *) lines, b->nGlyphs, h, scanlinesPerRow, dErrors);
+    HIPCHK(hipGetLastError());
+    return MSDFHIP_OK;
+}
+
 int msdfhip_render_sdf(const float *dSdf, int nGlyphs, int sw, int sh, int ns, float *dOut, int ow, int oh, int no, double rangeLower, double rangeUpper,
                        float sdThreshold, void *streamPtr) {
     if (nGlyphs < 0 || sw < 0 || sh < 0 || ow < 0 || oh < 0)

@@ -836,6 +836,43 @@ __global__ void k_simulate_8bit(float *px, size_t n) {
         px[i] = 1.f/255.f*(float) pixelFloatToByte(px[i]);
 }
 
+// estimateSDFError (core/sdf-error-estimation.cpp:134-154), one lane per scanline (glyph, row, subRow). items: scanlines of this
+// launch chunk [itemBase, itemBase+nItems) in (glyph, row, subRow) order; lists: workspace, lane-strided (msdf_scanline.hpp).
+// lines[item] = 1 - overlapFactor*overlap. glyphs[g].flip is read as "the shape's Y axis points down" (shape.getYAxisOrientation()).
+template <int N>
+__global__ void k_sdf_error_lines(BatchView batch, const MsdfHipGlyph *glyphs, const float *tiles, int width, int height, int scanlinesPerRow, int fillRule,
+                                  size_t itemBase, size_t nItems, double *listX, int *listDir, int refCap, double *lines) {
+    const size_t local = (size_t) blockIdx.x*blockDim.x+threadIdx.x;
+    if (local >= nItems)
+        return;
+    const size_t item = itemBase+local;
+    const size_t perGlyph = (size_t) (height-1)*scanlinesPerRow;
+    const int g = (int) (item/perGlyph);
+    const int rem = (int) (item-(size_t) g*perGlyph);
+    const int row = rem/scanlinesPerRow, subRow = rem-row*scanlinesPerRow;
+    const int c0 = batch.glyphContourOffsets[g], C = batch.glyphContourOffsets[g+1]-c0;
+    const int32_t *coff = batch.contourOffsets+c0;
+    const int e0 = coff[0], nE = coff[C]-e0;
+    const MsdfHipGlyph gd = glyphs[g];
+    StridedList refList, sdfList;
+    refList.x = listX+local, refList.dir = listDir+local, refList.stride = nItems, refList.n = 0;
+    sdfList.x = listX+(size_t) refCap*nItems+local, sdfList.dir = listDir+(size_t) refCap*nItems+local, sdfList.stride = nItems, sdfList.n = 0;
+    lines[item] = sdfErrorOfLine<N>(batch.recs+e0, nE, tiles+(size_t) g*width*height*N, width, height, gd.xf[0], gd.xf[1], gd.xf[2], gd.xf[3], gd.flip != 0,
+                                    row, subRow, scanlinesPerRow, fillRule, refList, sdfList);
+}
+
+// The reference sums the scanlines of a glyph in (row, subRow) order and divides (:141-153): one thread per glyph, same order.
+__global__ void k_sdf_error_sum(const double *lines, int nGlyphs, int height, int scanlinesPerRow, double *errors) {
+    const int g = blockIdx.x*blockDim.x+threadIdx.x;
+    if (g >= nGlyphs)
+        return;
+    const size_t perGlyph = (size_t) (height-1)*scanlinesPerRow;
+    double error = 0;
+    for (size_t i = 0; i < perGlyph; ++i)
+        error += lines[(size_t) g*perGlyph+i];
+    errors[g] = error/((height-1)*scanlinesPerRow);
+}
+
 // ------------------------------------------------------------------------------------------------- distance queries
 
 template <int SEL, bool OVERLAP>

@@ -79,6 +79,7 @@ _PROTOS = {
     "msdfhip_batch_generate": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(Config), _vp]),
     "msdfhip_batch_generate_host": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(Glyph), _fp, C.c_size_t, _bp, C.POINTER(Config)]),
     "msdfhip_tiles_to_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "msdfhip_batch_estimate_sdf_error": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "msdfhip_render_sdf": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_float, _vp]),
     "msdfhip_simulate_8bit": (C.c_int, [_vp, C.c_size_t, _vp]),
     "msdfhip_set_kernel_timing": (C.c_int, [C.c_int]),

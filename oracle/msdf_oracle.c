@@ -1909,3 +1909,183 @@ void orc_simulate_8bit(float *px, long n) {                                     
         px[i] = 1.f/255.f*(float) b;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * estimateSDFError (core/sdf-error-estimation.cpp:134-154) = mean over sub-rows of 1 - overlap(shape scanline, scanline
+ * reconstructed from the distance field)/width.
+ */
+static void scanline_preprocess(scanline_t *line) {                                          /* Scanline.cpp:66-77: sort by x, prefix-sum directions */
+    for (int i = 1; i < line->n; ++i) {                                                      /* (ties in x: zero-length spans, order irrelevant to overlap) */
+        double x = line->x[i];
+        int d = line->dir[i], j = i-1;
+        while (j >= 0 && line->x[j] > x) {
+            line->x[j+1] = line->x[j], line->dir[j+1] = line->dir[j];
+            --j;
+        }
+        line->x[j+1] = x, line->dir[j+1] = d;
+    }
+    int total = 0;
+    for (int i = 0; i < line->n; ++i) {
+        total += line->dir[i];
+        line->dir[i] = total;
+    }
+}
+
+static double scanline_overlap(const scanline_t *a, const scanline_t *b, double xFrom, double xTo, int fillRule) {   /* Scanline.cpp:27-62 */
+    double total = 0;
+    int aInside = 0, bInside = 0;
+    int ai = 0, bi = 0;
+    double ax = a->n ? a->x[ai] : xTo;
+    double bx = b->n ? b->x[bi] : xTo;
+    while (ax < xFrom || bx < xFrom) {
+        double xNext = dmin(ax, bx);
+        if (ax == xNext && ai < a->n) {
+            aInside = interpret_fill_rule(a->dir[ai], fillRule);
+            ax = ++ai < a->n ? a->x[ai] : xTo;
+        }
+        if (bx == xNext && bi < b->n) {
+            bInside = interpret_fill_rule(b->dir[bi], fillRule);
+            bx = ++bi < b->n ? b->x[bi] : xTo;
+        }
+    }
+    double x = xFrom;
+    while (ax < xTo || bx < xTo) {
+        double xNext = dmin(ax, bx);
+        if (aInside == bInside)
+            total += xNext-x;
+        if (ax == xNext && ai < a->n) {
+            aInside = interpret_fill_rule(a->dir[ai], fillRule);
+            ax = ++ai < a->n ? a->x[ai] : xTo;
+        }
+        if (bx == xNext && bi < b->n) {
+            bInside = interpret_fill_rule(b->dir[bi], fillRule);
+            bx = ++bi < b->n ? b->x[bi] : xTo;
+        }
+        x = xNext;
+    }
+    if (aInside == bInside)
+        total += xTo-x;
+    return total;
+}
+
+/* scanlineSDF (N == 1, sdf-error-estimation.cpp:9-48) and scanlineMSDF (N >= 3, :50-125). px: row-major [h][w][N] memory rows;
+ * yDownBitmap: the shape's Y axis points down (the reference passes shape.getYAxisOrientation(), :146). */
+static void scanline_from_sdf(scanline_t *line, const float *px, int w, int h, int N, double sy, double ty, double sx, double tx, double y, int yDown) {
+    line->n = 0;
+    if (!(w > 0 && h > 0))
+        return;
+    double pixelY = dclamp(sy*(y+ty)-.5, (double) (h-1));                                    /* projection.projectY(y), Projection.cpp:30-32 */
+    if (yDown)
+        pixelY = h-1-pixelY;
+    int b = (int) floor(pixelY);
+    int t = b+1;
+    double bt = pixelY-b;
+    if (t >= h) {
+        b = h-1;
+        t = h-1;
+        bt = 1;
+    }
+    int inside = 0;
+    #define SDF_AT(X, Y, C) px[((size_t) (Y)*w+(X))*N+(C)]
+    if (N == 1) {
+        float lv, rv = fmix(SDF_AT(0, b, 0), SDF_AT(0, t, 0), bt);
+        if ((inside = rv > .5f)) {
+            line->x[line->n] = -1e240, line->dir[line->n++] = 1;
+        }
+        for (int l = 0, r = 1; r < w; ++l, ++r) {
+            lv = rv;
+            rv = fmix(SDF_AT(r, b, 0), SDF_AT(r, t, 0), bt);
+            if (lv != rv) {
+                double lr = (double) (.5f-lv)/(double) (rv-lv);
+                if (lr >= 0 && lr <= 1) {
+                    line->x[line->n] = (l+lr+.5)/sx-tx;                                      /* projection.unprojectX, Projection.cpp:34-36 */
+                    line->dir[line->n++] = isign(rv-lv);
+                }
+            }
+        }
+    } else {
+        float lv[3], rv[3];
+        for (int i = 0; i < 3; ++i)
+            rv[i] = fmix(SDF_AT(0, b, i), SDF_AT(0, t, i), bt);
+        if ((inside = fmedian(rv[0], rv[1], rv[2]) > .5f)) {
+            line->x[line->n] = -1e240, line->dir[line->n++] = 1;
+        }
+        for (int l = 0, r = 1; r < w; ++l, ++r) {
+            for (int i = 0; i < 3; ++i) {
+                lv[i] = rv[i];
+                rv[i] = fmix(SDF_AT(r, b, i), SDF_AT(r, t, i), bt);
+            }
+            double nx[4];
+            int nd[4], count = 0;
+            for (int i = 0; i < 3; ++i) {
+                if (lv[i] != rv[i]) {
+                    double lr = (double) (.5f-lv[i])/(double) (rv[i]-lv[i]);
+                    if (lr >= 0 && lr <= 1) {
+                        float v[3] = { fmix(lv[0], rv[0], lr), fmix(lv[1], rv[1], lr), fmix(lv[2], rv[2], lr) };
+                        if (fmedian(v[0], v[1], v[2]) == v[i]) {
+                            nx[count] = (l+lr+.5)/sx-tx;
+                            nd[count] = isign(rv[i]-lv[i]);
+                            ++count;
+                        }
+                    }
+                }
+            }
+            #define SWAP_NI(A, B) { nx[3] = nx[A], nd[3] = nd[A]; nx[A] = nx[B], nd[A] = nd[B]; nx[B] = nx[3], nd[B] = nd[3]; }
+            if (count >= 2) {
+                if (nx[0] > nx[1])
+                    SWAP_NI(0, 1)
+                if (count >= 3 && nx[1] > nx[2]) {
+                    SWAP_NI(1, 2)
+                    if (nx[0] > nx[1])
+                        SWAP_NI(0, 1)
+                }
+            }
+            #undef SWAP_NI
+            for (int i = 0; i < count; ++i) {
+                if ((nd[i] > 0) == !inside) {
+                    line->x[line->n] = nx[i], line->dir[line->n++] = nd[i];
+                    inside = !inside;
+                }
+            }
+            float rvScalar = fmedian(rv[0], rv[1], rv[2]);
+            if ((rvScalar > .5f) != inside && rvScalar != .5f && line->n > 0) {
+                --line->n;
+                inside = !inside;
+            }
+        }
+    }
+    #undef SDF_AT
+    scanline_preprocess(line);
+}
+
+/* per_line (optional): (h-1)*scanlinesPerRow values 1 - overlapFactor*overlap in the order they are summed. */
+double orc_estimate_sdf_error(const orc_shape *shape, const float *px, int w, int h, int N, const double *xf4, int scanlinesPerRow, int fillRule,
+                              double *per_line) {
+    if (w <= 1 || h <= 1 || scanlinesPerRow < 1)
+        return 0;
+    const double sx = xf4[0], sy = xf4[1], tx = xf4[2], ty = xf4[3];
+    double subRowSize = 1./scanlinesPerRow;
+    double xFrom = .5/sx-tx;
+    double xTo = (w-.5)/sx-tx;
+    double overlapFactor = 1/(xTo-xFrom);
+    double error = 0;
+    int nE = shape->contour_offsets[shape->n_contours];
+    scanline_t ref, sdf;
+    ref.cap = 3*nE+1, sdf.cap = 3*w+2;
+    ref.x = (double *) malloc(sizeof(double)*(size_t) ref.cap), ref.dir = (int *) malloc(sizeof(int)*(size_t) ref.cap);
+    sdf.x = (double *) malloc(sizeof(double)*(size_t) sdf.cap), sdf.dir = (int *) malloc(sizeof(int)*(size_t) sdf.cap);
+    for (int row = 0; row < h-1; ++row)
+        for (int subRow = 0; subRow < scanlinesPerRow; ++subRow) {
+            double bt = (subRow+.5)*subRowSize;
+            double y = (row+bt+.5)/sy-ty;
+            shape_scanline(shape, &ref, y);
+            scanline_preprocess(&ref);
+            scanline_from_sdf(&sdf, px, w, h, N, sy, ty, sx, tx, y, shape->inverse_y);
+            double v = 1-overlapFactor*scanline_overlap(&ref, &sdf, xFrom, xTo, fillRule);
+            if (per_line)
+                per_line[(size_t) row*scanlinesPerRow+subRow] = v;
+            error += v;
+        }
+    free(ref.x), free(ref.dir), free(sdf.x), free(sdf.dir);
+    return error/((h-1)*scanlinesPerRow);
+}

@@ -185,6 +185,19 @@ class Oracle:
         n = self.lib.orc_shape_prepare(C.byref(s), int(normalize), int(coloring), float(angle), int(seed), _p(offs, _ip), _p(pts, _dp), _p(types, _ip), _p(colors, _ip))
         return FlatArrays(offs, pts[:n], types[:n], colors[:n], bool(f.inverse_y))
 
+    def estimate_sdf_error(self, shape, sdf, xf, scanlines_per_row=1, fill_rule=0, per_line=False):
+        """estimateSDFError (core/sdf-error-estimation.h:18-20) of sdf (h, w, N), memory rows."""
+        f = _flat(shape)
+        px = _arr(sdf, np.float32)
+        h, w, n = px.shape
+        x4 = _arr(np.asarray(xf, np.float64).reshape(-1)[:4], np.float64)
+        s = f.orc()
+        lines = np.zeros(max((h-1)*scanlines_per_row, 1))
+        self.lib.orc_estimate_sdf_error.restype = C.c_double
+        self.lib.orc_estimate_sdf_error.argtypes = [C.POINTER(_OrcShape), _fp, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp]
+        v = self.lib.orc_estimate_sdf_error(C.byref(s), _p(px, _fp), w, h, n, _p(x4, _dp), scanlines_per_row, fill_rule, _p(lines, _dp))
+        return (v, lines[:max(h-1, 0)*scanlines_per_row]) if per_line else v
+
     def render_sdf(self, sdf, ow, oh, n_out, range_lower=0., range_upper=0., threshold=.5):
         """renderSDF (core/render-sdf.h:12-17): (oh, ow, n_out) float32 from sdf (sh, sw, Ns)."""
         sdf = _arr(sdf, np.float32)
@@ -423,6 +436,19 @@ class Ref:
         fa = self.flatten(h)
         self.free(h)
         return fa
+
+    def estimate_sdf_error(self, shape, sdf, xf, scanlines_per_row=1, fill_rule=0):
+        """The reference's estimateSDFError (core/sdf-error-estimation.h:18-20) of sdf (h, w, N), memory rows."""
+        hd, own = self._handle(shape)
+        px = _arr(sdf, np.float32)
+        h, w, n = px.shape
+        x4 = _arr(np.asarray(xf, np.float64).reshape(-1)[:4], np.float64)
+        self.lib.ref_estimate_sdf_error.restype = C.c_double
+        self.lib.ref_estimate_sdf_error.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int]
+        v = self.lib.ref_estimate_sdf_error(hd, _p(px, _fp), w, h, n, _p(x4, _dp), scanlines_per_row, fill_rule)
+        if own:
+            self.free(hd)
+        return v
 
     def render_sdf(self, sdf, ow, oh, n_out, range_lower=0., range_upper=0., threshold=.5):
         """renderSDF (core/render-sdf.h:12-17): (oh, ow, n_out) float32 from sdf (sh, sw, Ns)."""

@@ -28,6 +28,7 @@
 #include "core/MSDFErrorCorrection.h"
 #include "core/pixel-conversion.hpp"
 #include "core/render-sdf.h"
+#include "core/sdf-error-estimation.h"
 #include "core/equation-solver.h"
 
 using namespace msdfgen;
@@ -221,6 +222,16 @@ int ref_render_sdf(float *out, int ow, int oh, int No, const float *sdf, int sw,
     else return -1;
     #undef RENDER
     return 0;
+}
+
+double ref_estimate_sdf_error(void *s, const float *px, int w, int h, int N, const double *xf, int scanlinesPerRow, int fillRule) {
+    const Shape &shape = *(Shape *) s;
+    Projection proj(Vector2(xf[0], xf[1]), Vector2(xf[2], xf[3]));
+    switch (N) {
+        case 1: return estimateSDFError(BitmapConstSection<float, 1>(px, w, h), shape, proj, scanlinesPerRow, (FillRule) fillRule);
+        case 3: return estimateSDFError(BitmapConstSection<float, 3>(px, w, h), shape, proj, scanlinesPerRow, (FillRule) fillRule);
+        default: return estimateSDFError(BitmapConstSection<float, 4>(px, w, h), shape, proj, scanlinesPerRow, (FillRule) fillRule);
+    }
 }
 
 void ref_simulate_8bit(float *px, int w, int h, int N) {

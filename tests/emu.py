@@ -106,3 +106,11 @@ class Emu:
         n = self.lib.emu_shape_prepare(*args, int(normalize), int(coloring), C.c_double(angle), C.c_ulonglong(int(seed)), _p(offs, C.c_int32), _p(pts, C.c_double),
                                        _p(types, C.c_uint8), _p(colors, C.c_uint8))
         return FlatShape(offs, pts[:n], types[:n].astype(np.int32), colors[:n].astype(np.int32))
+
+    def estimate_sdf_error(self, s, sdf, xf, scanlines_per_row=1, fill_rule=0):
+        px = np.ascontiguousarray(sdf, np.float32)
+        h, w, n = px.shape
+        x4 = np.ascontiguousarray(np.asarray(xf, np.float64).reshape(-1)[:4])
+        keep, args = self._shape(s)
+        self.lib.emu_estimate_sdf_error.restype = C.c_double
+        return self.lib.emu_estimate_sdf_error(n, _p(px, C.c_float), w, h, int(bool(s.inverse_y)), *args, _p(x4, C.c_double), int(scanlines_per_row), int(fill_rule))

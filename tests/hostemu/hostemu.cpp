@@ -519,3 +519,28 @@ extern "C" int emu_shape_prepare(int nC, const int32_t *co, const double *points
         colourContour(norm, co1[c], co1[c+1]-co1[c], out, outCo[c], crossThreshold, color, seed);
     return outCo[nC];
 }
+
+// Mirrors k_sdf_error_lines + k_sdf_error_sum: a "lane" per scanline (lists with stride 1 here), then the sequential sum per glyph.
+extern "C" double emu_estimate_sdf_error(int N, const float *px, int w, int h, int yDown, int nC, const int32_t *co, const double *points,
+                                         const uint8_t *types, const uint8_t *colors, const double *xf, int scanlinesPerRow, int fillRule) {
+    if (w <= 1 || h <= 1 || scanlinesPerRow < 1)
+        return 0;
+    Digest d = digest(nC, co, points, types, colors);
+    const int nE = co[nC];
+    std::vector<double> rx(3*(size_t) nE+1), sx(3*(size_t) w+2);
+    std::vector<int> rd(3*(size_t) nE+1), sd(3*(size_t) w+2);
+    double error = 0;
+    for (int row = 0; row < h-1; ++row)
+        for (int subRow = 0; subRow < scanlinesPerRow; ++subRow) {
+            StridedList refList = { rx.data(), rd.data(), 1, 0 }, sdfList = { sx.data(), sd.data(), 1, 0 };
+            double v;
+            if (N == 1)
+                v = sdfErrorOfLine<1>(d.recs.data(), nE, px, w, h, xf[0], xf[1], xf[2], xf[3], yDown != 0, row, subRow, scanlinesPerRow, fillRule, refList, sdfList);
+            else if (N == 3)
+                v = sdfErrorOfLine<3>(d.recs.data(), nE, px, w, h, xf[0], xf[1], xf[2], xf[3], yDown != 0, row, subRow, scanlinesPerRow, fillRule, refList, sdfList);
+            else
+                v = sdfErrorOfLine<4>(d.recs.data(), nE, px, w, h, xf[0], xf[1], xf[2], xf[3], yDown != 0, row, subRow, scanlinesPerRow, fillRule, refList, sdfList);
+            error += v;
+        }
+    return error/((h-1)*scanlinesPerRow);
+}

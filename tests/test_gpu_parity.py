@@ -604,3 +604,29 @@ def test_render_sdf_and_simulate_8bit(latin, oracle, n_out, mode):
     with pytest.raises(M.MsdfHipError):
         M.render_sdf(tiles, 8, 8, 2)
     gb.close()
+
+
+def test_estimate_sdf_error_on_device(latin, oracle):
+    """estimateSDFError of every tile of a batch without leaving the device, exact doubles vs the oracle:
+    msdf / mtsdf / sdf, 1 and 3 scanlines per row, two fill rules, clean and perturbed fields, an inverse-Y glyph set."""
+    import torch
+    batch, xf64, _ = latin
+    for inv in (False, True):
+        sub = batch.select(range(30, 60))
+        sub.inverse_y[:] = inv
+        gb = M.GlyphBatch(sub)
+        w, h = 40, 36
+        xfs = np.stack([autoframe(b, w, h, 4) for b in latin[2][30:60]])
+        for mode in (3, 4, 1):
+            tiles = gb.generate(mode, w, h, xfs)
+            noisy = (tiles+torch.randn_like(tiles)*.12).contiguous()
+            for field in (tiles, noisy):
+                src = field.cpu().numpy()
+                for spr, rule in ((1, 0), (3, 1)):
+                    got = gb.estimate_sdf_error(field, xfs, spr, rule).cpu().numpy()
+                    want = np.array([oracle.estimate_sdf_error(sub.shape(g), src[g], xfs[g], spr, rule) for g in range(sub.n_glyphs)])
+                    assert (got == want).all(), "mode %d spr %d rule %d inverse_y %s: %d of %d glyphs differ" % (mode, spr, rule, inv, int((got != want).sum()), len(got))
+            if mode == 3 and not inv:
+                print("mean fill error of clean msdf tiles: %.3g, of perturbed: %.3g" % (
+                    float(gb.estimate_sdf_error(tiles, xfs).mean()), float(gb.estimate_sdf_error(noisy, xfs).mean())))
+        gb.close()

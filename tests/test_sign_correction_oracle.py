@@ -124,3 +124,39 @@ def test_render_sdf_oracle_vs_reference(oracle, ref, latin, n_out, n_sdf):
                 assert_bit_equal(b, a, "renderSDF %d<-%d %dx%d range (%g,%g)" % (n_out, n_sdf, ow, oh, lo, hi))
         noisy = sdf+rng.normal(0, .3, sdf.shape).astype(np.float32)
         assert_bit_equal(oracle.simulate_8bit(noisy), ref.simulate_8bit(noisy), "simulate8bit")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_estimate_sdf_error_oracle_vs_reference(oracle, ref, seed):
+    """estimateSDFError (core/sdf-error-estimation.cpp): sdf / msdf / mtsdf fields, several scanlines per row, fill rules, inverse-Y
+    shapes, noisy fields (many spurious crossings: the consistency check of scanlineMSDF), flat fields (no crossing at all)."""
+    rng = np.random.default_rng(400+seed)
+    s = synth.random_shape(6400+seed, n_contours=1+seed % 4, kinds=(1, 2, 3), holes=bool(seed & 1))
+    s.inverse_y = bool(seed & 2)
+    w, h = int(rng.integers(12, 48)), int(rng.integers(12, 48))
+    xf = autoframe(s.bounds(), w, h, 3)
+    for mode in (1, 3, 4):
+        clean = ref.generate(s, mode, w, h, xf, y_down=bool(seed & 2))
+        fields = [clean, clean+rng.normal(0, .15, clean.shape).astype(np.float32), np.full_like(clean, .25), 1-clean]
+        for f in fields:
+            for spr, rule in ((1, 0), (3, 1), (2, 2)):
+                a = ref.estimate_sdf_error(s, f, xf, spr, rule)
+                b, lines = oracle.estimate_sdf_error(s, f, xf, spr, rule, per_line=True)
+                assert a == b, "seed %d mode %d spr %d rule %d: %r vs %r" % (seed, mode, spr, rule, a, b)
+                assert len(lines) == (h-1)*spr
+    assert oracle.estimate_sdf_error(s, clean[:1], xf) == 0 == ref.estimate_sdf_error(s, clean[:1], xf)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_device_estimate_sdf_error_host(oracle, emu, seed):
+    """The product's per-scanline error code (msdf_scanline.hpp: sdfErrorOfLine) on the host against the oracle, exact doubles."""
+    rng = np.random.default_rng(500+seed)
+    s = synth.random_shape(6500+seed, n_contours=1+seed % 4, kinds=(1, 2, 3), holes=bool(seed & 1))
+    s.inverse_y = bool(seed & 2)
+    w, h = int(rng.integers(12, 48)), int(rng.integers(12, 48))
+    xf = autoframe(s.bounds(), w, h, 3)
+    for mode in (1, 3, 4):
+        clean = oracle.generate(s, mode, w, h, xf, y_down=bool(seed & 2))
+        for f in (clean, clean+rng.normal(0, .15, clean.shape).astype(np.float32), np.full_like(clean, .75), 1-clean):
+            for spr, rule in ((1, 0), (3, 1), (2, 3)):
+                assert emu.estimate_sdf_error(s, f, xf, spr, rule) == oracle.estimate_sdf_error(s, f, xf, spr, rule), (seed, mode, spr, rule)

@@ -91,6 +91,17 @@ def main():
     report("cfg4: 8192 CJK-like synthetic glyphs msdf 48x48 default EC", cj, 3, 48, 48, cx, reps=max(2, args.reps//3))
     report("cfg4 shapes, simple combiner (overlapSupport=false)", cj, 3, 48, 48, cx, config=M.MSDFGeneratorConfig(False), reps=max(2, args.reps//3))
     report("cfg4 shapes, sdf 48x48", cj, 1, 48, 48, cx, reps=max(2, args.reps//3))
+    if not args.only or "quality" in args.only:                       # row f4: the reference's own quality metric, on the device
+        gb = M.GlyphBatch(b)
+        tiles = gb.generate(3, 64, 64, x)
+        ms = timed(lambda: gb.estimate_sdf_error(tiles, x), max(2, args.reps//3))
+        err = gb.estimate_sdf_error(tiles, x)
+        view = M.render_sdf(tiles, 256, 256, 1, 4.)
+        ms_render = timed(lambda: M.render_sdf(tiles, 256, 256, 1, 4., out=view), max(2, args.reps//3))
+        print(json.dumps({"config": "quality: estimateSDFError (1 scanline per row) of the 8192 headline msdf tiles on the device", "ms": round(ms, 3),
+                          "mean_error": float(err.mean()), "max_error": float(err.max()),
+                          "renderSDF_8192_tiles_to_256x256_ms": round(ms_render, 3)}), flush=True)
+        gb.close()
     if not args.only or "prep" in args.only:                          # row f3: raw outlines -> prepared, digested batch (host call, incl. copies)
         import time
         z = np.load(os.path.join(ROOT, "tests", "golden", "prep.npz"))
