@@ -41,7 +41,7 @@ def main():
         w, h = int(rng.integers(8, 72)), int(rng.integers(8, 72))
         overlap = bool(rng.integers(0, 2))
         ec_mode, ec_dist = int(rng.integers(0, 4)), int(rng.integers(0, 3))
-        px_range = float(rng.choice([2, 4, 8, 1.5]))
+        px_range = min(float(rng.choice([2, 4, 8, 1.5])), .45*min(w, h))      # autoframe needs room for the range inside the tile
         kind = int(rng.integers(0, 4))
         shapes = []
         for i in range(n):
