@@ -248,10 +248,15 @@ k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, i
     edges.cstart = cstart;
     edges.list = LDSREC ? (const int *) 0 : list;
     double d[NCH];
+#if defined(MSDF_ABLATE_PHASE2)                                     // measurement only: what phase 1 + the launch cost alone
+    for (int ch = 0; ch < NCH; ++ch)
+        d[ch] = (double) nSurv;
+#else
     if (OVERLAP)
         shapeDistanceOverlap<SEL>(rec, edges, batch.windings+c0, C, p, res+lane, WAVE, d);
     else
         shapeDistanceSimple<SEL>(rec, edges, C, p, d);
+#endif
     const int yn = gd.flip ? height-1-y : y;                        // output.reorient(shape orientation), msdfgen.cpp:55
     float *px = toScratch ? dst+(((size_t) wk.g*height+yn)*width+x)*NCH
                           : dst+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) NCH*x;
