@@ -136,7 +136,13 @@ int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan) {
     const size_t idxBytes = ((size_t) b->maxEdges+(size_t) b->maxContours+2)*sizeof(int);   // survivor list + per-contour offsets
     const size_t limit = (size_t) gLdsLimit.load();
     plan.resBytes = resBytes;
-    plan.globalRes = overlap && resBytes+idxBytes > 96*1024;     // beyond 96 KB a workgroup would own most of the CU's LDS: spill the scratch to HBM
+    // The combiner scratch lives in LDS only while 12 wavefronts (3 per SIMD, the register-limited occupancy) fit a CU's 160 KB:
+    // beyond ~13 KB per wavefront LDS would cap the occupancy (a 20-contour glyph set ran at 1.25 wavefronts/SIMD), so it moves to a
+    // global workspace instead -- written and read once per contour with lane-consecutive addresses.
+    size_t ldsBudget = 13*1024;
+    if (const char *env = getenv("MSDFHIP_RES_LDS_BUDGET"))      // experiment knob (bytes)
+        ldsBudget = (size_t) atol(env);
+    plan.globalRes = overlap && resBytes+idxBytes > ldsBudget;
     if (idxBytes > limit)
         return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours / %d edges: the survivor list needs %zu B of LDS per wavefront, device limit is %zu B",
                     b->maxContours, b->maxEdges, idxBytes, limit);

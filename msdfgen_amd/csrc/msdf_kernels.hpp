@@ -487,7 +487,7 @@ k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, c
         const int g = (int) (unit/K);
         const unsigned k = (unsigned) (unit-(size_t) g*K);
         const unsigned count = header[1+g];
-        if (k >= count)
+        if (k >= count)                                             // (in lane-per-candidate mode: chunk k of 64 would start past k*64 >= k)
             continue;
         const EcCandidate *segment = cands+ecHeaderRecords(batch.nGlyphs)+(size_t) g*seg;
         const int c0 = batch.glyphContourOffsets[g], C = batch.glyphContourOffsets[g+1]-c0;
@@ -504,6 +504,35 @@ k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, c
         SdfView sdf;
         sdf.px = src+(size_t) g*texelsPerGlyph*N;
         sdf.w = width, sdf.h = height, sdf.N = N, sdf.flip = gd.flip;
+        // Two ways to spend the wavefront on this glyph's candidates: lanes = edges of one candidate at a time (cooperative: one round
+        // and one cross-lane merge per contour and candidate) or lane = candidate (every lane walks all edges; uniform control flow
+        // and scalar record loads since the whole wavefront is on one glyph). The first wins for the usual handful of candidates on a
+        // glyph of few contours, the second for many candidates / many small contours (CJK-like shapes: 14 contours of 6 edges).
+        const int nE = coff[C]-coff[0];
+        const bool lanePerCandidate = (size_t) count*C*2 > (size_t) nE*K;
+        if (lanePerCandidate) {
+            PsdfQuery<OVERLAP> query;
+            query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.res = smem+threadIdx.x;
+            for (unsigned base = k*WAVE; base < count; base += K*WAVE) {
+                const unsigned i = base+threadIdx.x;
+                if (i >= count)
+                    continue;
+                const EcCandidate cand = segment[i];
+                const size_t texel = cand.texel;
+                const int rem = (int) (texel-(size_t) g*texelsPerGlyph);
+                const int yn = rem/width, x = rem%width;
+                const int ys = gd.flip ? height-1-yn : yn;
+                if (ecEvaluateCandidate(sdf, p, x, ys, cand.t, (cand.dir&3)-1, ((cand.dir>>2)&3)-1, query)) {
+                    const float *in = sdf.native(x, yn);
+                    const float m = medianf(in[0], in[1], in[2]);
+                    float *px = out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
+                    px[0] = m, px[1] = m, px[2] = m;
+                    if (stencilOut)
+                        stencilOut[texel] |= (uint8_t) EC_ERROR;
+                }
+            }
+            continue;
+        }
         PsdfQueryCooperative<OVERLAP> query;
         query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.lane = threadIdx.x;
         query.res = smem+threadIdx.x;
