@@ -97,6 +97,10 @@ struct MsdfHipBatch {
     mutable size_t gresBytes;
     mutable size_t deferredCap;
     mutable std::mutex scratchMutex;
+    mutable std::vector<int> hContours; // contours per glyph (host copy, fetched on first need)
+    mutable int bucketLimit;          // the contour limit dBucket was built for (-1 = none)
+    mutable int *dBucket;             // [nSmall glyph indices with <= bucketLimit contours][the others]
+    mutable int nSmall, smallMaxC;
 };
 
 namespace {
@@ -127,22 +131,25 @@ int digest(MsdfHipBatch *b, hipStream_t stream) {
 }
 
 // LDS plan for a launch: bytes of dynamic LDS and whether the records are staged in LDS or read from global memory.
-struct LdsPlan { size_t bytes; bool ldsRec; bool globalRes; size_t resBytes; };
+struct LdsPlan { size_t bytes; bool ldsRec; bool globalRes; size_t resBytes, ldsBudget, idxBytes; };
 const size_t GRES_WORKSPACE_CAP = (size_t) 1<<30;   // bound of the global combiner scratch; larger launches are chunked
 
-int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan) {
-    const size_t resBytes = overlap ? (size_t) b->maxContours*nch*WAVE*sizeof(double) : 0;
+int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan, int maxContours = -1) {
+    if (maxContours < 0)
+        maxContours = b->maxContours;
+    const size_t resBytes = overlap ? (size_t) maxContours*nch*WAVE*sizeof(double) : 0;
     const size_t recBytes = (size_t) b->maxEdges*sizeof(EdgeRec);
     const size_t idxBytes = ((size_t) b->maxEdges+(size_t) b->maxContours+2)*sizeof(int);   // survivor list + per-contour offsets
+    plan.ldsBudget = 13*1024;
     const size_t limit = (size_t) gLdsLimit.load();
     plan.resBytes = resBytes;
     // The combiner scratch lives in LDS only while 12 wavefronts (3 per SIMD, the register-limited occupancy) fit a CU's 160 KB:
     // beyond ~13 KB per wavefront LDS would cap the occupancy (a 20-contour glyph set ran at 1.25 wavefronts/SIMD), so it moves to a
     // global workspace instead -- written and read once per contour with lane-consecutive addresses.
-    size_t ldsBudget = 13*1024;
     if (const char *env = getenv("MSDFHIP_RES_LDS_BUDGET"))      // experiment knob (bytes)
-        ldsBudget = (size_t) atol(env);
-    plan.globalRes = overlap && resBytes+idxBytes > ldsBudget;
+        plan.ldsBudget = (size_t) atol(env);
+    plan.globalRes = overlap && resBytes+idxBytes > plan.ldsBudget;
+    plan.idxBytes = idxBytes;
     if (idxBytes > limit)
         return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours / %d edges: the survivor list needs %zu B of LDS per wavefront, device limit is %zu B",
                     b->maxContours, b->maxEdges, idxBytes, limit);
@@ -174,6 +181,7 @@ int ensureGres(const MsdfHipBatch *b, size_t bytes, double **out) {
         if (b->dGres)
             hipFree(b->dGres);
         b->dGres = NULL, b->gresBytes = 0;
+    b->bucketLimit = -1, b->dBucket = NULL, b->nSmall = 0, b->smallMaxC = 0;
         HIPCHK(hipMalloc((void **) &b->dGres, bytes));
         b->gresBytes = bytes;
     }
@@ -182,9 +190,13 @@ int ensureGres(const MsdfHipBatch *b, size_t bytes, double **out) {
 }
 
 template <int SEL, bool OVERLAP, bool LDSREC, bool GRES>
-int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, const LdsPlan &plan, hipStream_t stream) {
+int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, const LdsPlan &plan, hipStream_t stream,
+                   const int *dGlyphMap = NULL, int nMapped = 0) {
     const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE, tiles = tilesX*tilesY;
-    const size_t blocks = (size_t) ((b->nGlyphs+7)/8)*8u*(size_t) tiles;
+    const int nG = dGlyphMap ? nMapped : b->nGlyphs;
+    if (nG == 0)
+        return MSDFHIP_OK;
+    const size_t blocks = (size_t) ((nG+7)/8)*8u*(size_t) tiles;
     if (blocks > 0x7fffffffull)
         return fail(MSDFHIP_ERR_INVALID, "launch of %zu tiles exceeds the grid limit; split the batch", blocks);
     int rc = setLds(k_distance<SEL, OVERLAP, LDSREC, GRES>, plan.bytes);
@@ -203,13 +215,42 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
         if (rc != MSDFHIP_OK)
             return rc;
     }
-    ScopedTimer timer(stream, 0);
     for (size_t base = 0; base < blocks; base += chunk) {
         const size_t n = blocks-base < chunk ? blocks-base : chunk;
         hipLaunchKernelGGL((k_distance<SEL, OVERLAP, LDSREC, GRES>), dim3((unsigned) n), dim3(WAVE), plan.bytes, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles,
-                           b->maxEdges, dst, toScratch, (unsigned) base, gres, stride);
+                           b->maxEdges, dst, toScratch, (unsigned) base, gres, stride, dGlyphMap, nMapped);
     }
     HIPCHK(hipGetLastError());
+    return MSDFHIP_OK;
+}
+
+// Glyph indices sorted into "combiner scratch fits the LDS budget" (<= limit contours) and the rest; cached per limit.
+int ensureBuckets(const MsdfHipBatch *b, int limit) {
+    std::lock_guard<std::mutex> lock(b->scratchMutex);
+    if (b->bucketLimit == limit && b->dBucket)
+        return MSDFHIP_OK;
+    if (b->hContours.empty() && b->nGlyphs > 0) {                // batch created from device arrays: read the glyph offsets back once
+        std::vector<int32_t> gco((size_t) b->nGlyphs+1);
+        HIPCHK(hipMemcpy(gco.data(), b->dGlyphContourOffsets, sizeof(int32_t)*gco.size(), hipMemcpyDeviceToHost));
+        b->hContours.resize((size_t) b->nGlyphs);
+        for (int g = 0; g < b->nGlyphs; ++g)
+            b->hContours[g] = gco[g+1]-gco[g];
+    }
+    std::vector<int> order((size_t) b->nGlyphs);
+    int nSmall = 0, smallMaxC = 0;
+    for (int g = 0; g < b->nGlyphs; ++g)
+        if (b->hContours[g] <= limit) {
+            order[nSmall++] = g;
+            smallMaxC = b->hContours[g] > smallMaxC ? b->hContours[g] : smallMaxC;
+        }
+    int at = nSmall;
+    for (int g = 0; g < b->nGlyphs; ++g)
+        if (b->hContours[g] > limit)
+            order[at++] = g;
+    if (!b->dBucket)
+        HIPCHK(hipMalloc((void **) &b->dBucket, sizeof(int)*(size_t) (b->nGlyphs > 0 ? b->nGlyphs : 1)));
+    HIPCHK(hipMemcpy(b->dBucket, order.data(), sizeof(int)*(size_t) b->nGlyphs, hipMemcpyHostToDevice));
+    b->bucketLimit = limit, b->nSmall = nSmall, b->smallMaxC = smallMaxC;
     return MSDFHIP_OK;
 }
 
@@ -219,8 +260,30 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     int rc = planLds(b, SelTraits<SEL>::NCH, overlap, plan);
     if (rc != MSDFHIP_OK)
         return rc;
-    if (plan.globalRes)
+    ScopedTimer timer(stream, 0);                                // the distance pass of one generate call (one or more launches)
+    if (plan.globalRes) {
+        // Only the glyphs whose combiner scratch does not fit the LDS budget take the global-workspace kernel; the others (usually
+        // nearly all of a font: a handful of many-contour symbols must not slow the rest down) run the LDS variant.
+        const size_t perContour = (size_t) SelTraits<SEL>::NCH*WAVE*sizeof(double);
+        const int limit = plan.ldsBudget > plan.idxBytes ? (int) ((plan.ldsBudget-plan.idxBytes)/perContour) : 0;
+        if (limit >= 1 && b->nGlyphs > 1) {
+            rc = ensureBuckets(b, limit);
+            if (rc != MSDFHIP_OK)
+                return rc;
+            if (b->nSmall > 0) {
+                LdsPlan small;
+                rc = planLds(b, SelTraits<SEL>::NCH, overlap, small, b->smallMaxC);
+                if (rc != MSDFHIP_OK)
+                    return rc;
+                rc = small.ldsRec ? launchDistance<SEL, true, true, false>(b, dGlyphs, w, h, dst, toScratch, small, stream, b->dBucket, b->nSmall)
+                                  : launchDistance<SEL, true, false, false>(b, dGlyphs, w, h, dst, toScratch, small, stream, b->dBucket, b->nSmall);
+                if (rc != MSDFHIP_OK)
+                    return rc;
+                return launchDistance<SEL, true, false, true>(b, dGlyphs, w, h, dst, toScratch, plan, stream, b->dBucket+b->nSmall, b->nGlyphs-b->nSmall);
+            }
+        }
         return launchDistance<SEL, true, false, true>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
+    }
     if (overlap)
         return plan.ldsRec ? launchDistance<SEL, true, true, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream)
                            : launchDistance<SEL, true, false, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
@@ -467,6 +530,7 @@ int msdfhip_batch_create_device(MsdfHipBatch **batch, int n_glyphs, int n_contou
     b->dTypes = const_cast<uint8_t *>(d_types);
     b->dColors = const_cast<uint8_t *>(d_colors);
     b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0, b->dEcParams = NULL, b->dGres = NULL, b->gresBytes = 0;
+    b->bucketLimit = -1, b->dBucket = NULL, b->nSmall = 0, b->smallMaxC = 0;
     rc = digest(b, (hipStream_t) stream);
     if (rc != MSDFHIP_OK) {
         msdfhip_batch_destroy(b);
@@ -504,6 +568,7 @@ int msdfhip_batch_create(MsdfHipBatch **batch, int n_glyphs, const int32_t *gco,
     b->ownsInputs = true;
     b->dGlyphContourOffsets = NULL, b->dContourOffsets = NULL, b->dPoints = NULL, b->dTypes = NULL, b->dColors = NULL;
     b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0, b->dEcParams = NULL, b->dGres = NULL, b->gresBytes = 0;
+    b->bucketLimit = -1, b->dBucket = NULL, b->nSmall = 0, b->smallMaxC = 0;
     const size_t eAlloc = nE > 0 ? nE : 1;
     #define ALLOC_COPY(dst, src, bytes, used) do { \
         hipError_t e_ = hipMalloc((void **) &(dst), (bytes) ? (bytes) : 16); \
@@ -635,6 +700,7 @@ int msdfhip_batch_create_prepared(MsdfHipBatch **batch, int n_glyphs, const int3
     b->dGlyphContourOffsets = dGco, b->dContourOffsets = dFinalCo, b->dPoints = fin.points, b->dTypes = fin.types, b->dColors = fin.colors;
     dev.release(dGco), dev.release(dFinalCo), dev.release(fin.points), dev.release(fin.types), dev.release(fin.colors);
     b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0, b->dEcParams = NULL, b->dGres = NULL, b->gresBytes = 0;
+    b->bucketLimit = -1, b->dBucket = NULL, b->nSmall = 0, b->smallMaxC = 0;
     rc = digest(b, NULL);
     if (rc == MSDFHIP_OK && hipStreamSynchronize(NULL) != hipSuccess)
         rc = fail(MSDFHIP_ERR_HIP, "edge digestion failed: %s", hipGetErrorString(hipGetLastError()));
@@ -700,6 +766,7 @@ void msdfhip_batch_destroy(MsdfHipBatch *b) {
     hipFree(b->dDeferred);
     hipFree(b->dEcParams);
     hipFree(b->dGres);
+    hipFree(b->dBucket);
     delete b;
 }
 
@@ -1074,6 +1141,14 @@ static int runGroup(ShapeCall *const *calls, int n) {
     b.deferredCap = correct ? candCap : 0;
     b.dEcParams = reinterpret_cast<EcGlyphParams *>(a.dev+dParams);
     b.dGres = NULL, b.gresBytes = 0;
+    b.bucketLimit = -1, b.dBucket = NULL, b.nSmall = 0, b.smallMaxC = 0;
+    b.hContours.resize((size_t) n);
+    for (int g = 0; g < n; ++g)
+        b.hContours[g] = calls[g]->nC;
+    struct Owned {                                               // workspaces the launches may have allocated for this view (many-contour shapes)
+        MsdfHipBatch &b;
+        ~Owned() { hipFree(b.dGres); hipFree(b.dBucket); }
+    } owned = { b };
     const MsdfHipGlyph *dGlyph = reinterpret_cast<const MsdfHipGlyph *>(a.dev+hGlyph);
     float *dOut = reinterpret_cast<float *>(a.dev+hOut);
     uint8_t *dStencil = anyStencil ? reinterpret_cast<uint8_t *>(a.dev+hStencil) : NULL;

@@ -148,12 +148,14 @@ __device__ inline float floatAbove(double d) {
 template <int SEL, bool OVERLAP, bool LDSREC, bool GRES = false>
 __global__ void __launch_bounds__(WAVE, MSDF_DISTANCE_WAVES_PER_SIMD)
 k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges, float *dst, int toScratch,
-           unsigned blockBase, double *gres, size_t gresStride) {
+           unsigned blockBase, double *gres, size_t gresStride, const int *glyphMap, int nMapped) {
     enum { NCH = SelTraits<SEL>::NCH };
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const GlyphWork wk = decodeBlock(batch.nGlyphs, tilesPerGlyph, blockBase);
+    GlyphWork wk = decodeBlock(glyphMap ? nMapped : batch.nGlyphs, tilesPerGlyph, blockBase);
     if (!wk.valid)
         return;
+    if (glyphMap)
+        wk.g = glyphMap[wk.g];                                          // this launch covers a subset of the batch (bucketed by contour count)
     const int c0 = batch.glyphContourOffsets[wk.g], C = batch.glyphContourOffsets[wk.g+1]-c0;
     const int32_t *coff = batch.contourOffsets+c0;
     const int e0 = coff[0];

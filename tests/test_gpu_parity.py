@@ -630,3 +630,26 @@ def test_estimate_sdf_error_on_device(latin, oracle):
                 print("mean fill error of clean msdf tiles: %.3g, of perturbed: %.3g" % (
                     float(gb.estimate_sdf_error(tiles, xfs).mean()), float(gb.estimate_sdf_error(noisy, xfs).mean())))
         gb.close()
+
+
+def test_mixed_batch_is_bucketed_by_contour_count(latin, oracle):
+    """A batch of mostly few-contour glyphs plus some many-contour ones: the kernels split it (LDS scratch for the former, global
+    workspace for the latter); the result must not depend on that -- compared per glyph with the oracle, msdf and mtsdf, and through
+    the single-shape entry point (which owns and frees its workspaces per call)."""
+    batch, xf64, bounds = latin
+    many = [synth.cjk_like_shape(8600+i) for i in range(5)]+[synth.random_shape(8700, n_contours=30, edges_per_contour=(3, 5), kinds=(1, 2))]
+    shapes = [batch.shape(g) for g in range(0, 40)]
+    for i, s in enumerate(many):
+        shapes.insert(3+6*i, s)
+    w = h = 32
+    xfs = np.stack([autoframe(s.bounds(), w, h, 4) for s in shapes])
+    gb = M.GlyphBatch(ShapeBatch.from_shapes(shapes))
+    assert gb.max_contours >= 20
+    for mode in (3, 4):
+        got = gb.generate(mode, w, h, xfs).cpu().numpy()
+        for g, s in enumerate(shapes):
+            close(got[g], oracle.generate(s, mode, w, h, xfs[g]), "mixed batch glyph %d (%d contours) mode %d" % (g, s.n_contours, mode))
+    gb.close()
+    for s, xf in zip(many[:3], xfs[3::6]):
+        for _ in range(3):
+            close(gen(3, s, w, h, xf), oracle.generate(s, 3, w, h, xf), "single call, %d contours" % s.n_contours)
