@@ -337,7 +337,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
         const unsigned cap = GRES ? slowGrid : 16384u;
         const unsigned slowBlocks = (unsigned) ((allTexels+WAVE-1)/WAVE < cap ? (allTexels+WAVE-1)/WAVE : cap);
         hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowBlocks), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
-                           (const EcCandidate *) NULL, 0, gres, gresStride);
+                           (const EcCandidate *) NULL, 0u, 0, gres, gresStride);
         HIPCHK(hipGetLastError());
         return MSDFHIP_OK;
     }
@@ -366,7 +366,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     hipLaunchKernelGGL((k_ec_query<N, OVERLAP, GRES>), dim3(queryBlocks), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
                        (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, K, gres, gresStride);
     hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowGrid), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
-                       (const EcCandidate *) deferred, 1, gres, gresStride);
+                       (const EcCandidate *) deferred, seg, 1, gres, gresStride);
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
 }

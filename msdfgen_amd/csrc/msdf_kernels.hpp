@@ -355,7 +355,7 @@ struct EcCandidate {
 static_assert(sizeof(EcCandidate) == 16, "EcCandidate layout");
 
 MSDF_HD size_t ecHeaderRecords(int nGlyphs) { return ((size_t) (nGlyphs+1)*sizeof(unsigned)+sizeof(EcCandidate)-1)/sizeof(EcCandidate); }
-MSDF_HD unsigned ecSegment(size_t texelsPerGlyph) { return (unsigned) (texelsPerGlyph/16 > 64 ? (texelsPerGlyph/16+63)/64*64 : 64); }
+MSDF_HD unsigned ecSegment(size_t texelsPerGlyph) { return (unsigned) (texelsPerGlyph/8 > 64 ? (texelsPerGlyph/8+63)/64*64 : 64); }
 
 struct CandidateSink {
     unsigned *header;           // [0] overflow, [1+g] counts
@@ -481,15 +481,13 @@ k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, c
     extern __shared__ double smemLds[];                             // [maxContours][64] combiner scratch (overlap only)
     double *smem = GRES ? gres+(size_t) blockIdx.x*gresStride : smemLds;
     const unsigned *header = reinterpret_cast<const unsigned *>(cands);
-    if (header[0])
-        return;                                                     // overflow: k_ec_slow redoes every texel
     const size_t texelsPerGlyph = (size_t) width*height;
     const size_t units = (size_t) batch.nGlyphs*K;
     for (size_t unit = blockIdx.x; unit < units; unit += gridDim.x) {
         const int g = (int) (unit/K);
         const unsigned k = (unsigned) (unit-(size_t) g*K);
         const unsigned count = header[1+g];
-        if (k >= count)                                             // (in lane-per-candidate mode: chunk k of 64 would start past k*64 >= k)
+        if (k >= count || count > seg)                              // nothing to do / segment overflowed: k_ec_slow redoes this glyph
             continue;
         const EcCandidate *segment = cands+ecHeaderRecords(batch.nGlyphs)+(size_t) g*seg;
         const int c0 = batch.glyphContourOffsets[g], C = batch.glyphContourOffsets[g+1]-c0;
@@ -561,16 +559,19 @@ k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, c
 template <int N, bool OVERLAP, bool GRES = false>
 __global__ void __launch_bounds__(WAVE)
 k_ec_slow(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, const float *src, float *out, uint8_t *stencilOut,
-          MsdfHipConfig cfg, const EcCandidate *cands, int overflowOnly, double *gres, size_t gresStride) {
+          MsdfHipConfig cfg, const EcCandidate *cands, unsigned seg, int overflowOnly, double *gres, size_t gresStride) {
     extern __shared__ double smemLds[];                             // [maxContours][64] combiner scratch (overlap only)
     double *smem = GRES ? gres+(size_t) blockIdx.x*gresStride : smemLds;
     const size_t texelsPerGlyph = (size_t) width*height;
     const size_t allTexels = texelsPerGlyph*batch.nGlyphs;
-    if (overflowOnly && reinterpret_cast<const unsigned *>(cands)[0] == 0)
+    const unsigned *header = reinterpret_cast<const unsigned *>(cands);
+    if (overflowOnly && header[0] == 0)
         return;                                                     // the candidate segments held everything: k_ec_query did the job
     for (size_t i = (size_t) blockIdx.x*WAVE+threadIdx.x; i < allTexels; i += (size_t) gridDim.x*WAVE) {
         const size_t texel = i;
         const int g = (int) (texel/texelsPerGlyph);
+        if (overflowOnly && header[1+g] <= seg)
+            continue;                                               // only the glyphs whose segment overflowed are redone
         const int rem = (int) (texel%texelsPerGlyph);
         const int yn = rem/width, x = rem%width;
         const int c0 = batch.glyphContourOffsets[g], C = batch.glyphContourOffsets[g+1]-c0;

@@ -653,3 +653,33 @@ def test_mixed_batch_is_bucketed_by_contour_count(latin, oracle):
     for s, xf in zip(many[:3], xfs[3::6]):
         for _ in range(3):
             close(gen(3, s, w, h, xf), oracle.generate(s, 3, w, h, xf), "single call, %d contours" % s.n_contours)
+
+
+def test_candidate_segment_overflow_is_handled_per_glyph(latin, oracle):
+    """The deferred distance checks of a glyph live in a fixed-size segment; a glyph that overflows it is redone by the full
+    per-texel pipeline, the other glyphs of the batch are not affected. Overlapping strokes rendered WITHOUT overlap support produce
+    hundreds of artifacts per tile; a heavily perturbed field does the same through the standalone correction."""
+    batch, xf64, bounds = latin
+    shapes = [batch.shape(g) for g in range(10, 26)]
+    shapes.insert(5, synth.cjk_like_shape(8801))
+    shapes.insert(11, synth.cjk_like_shape(8802))
+    w = h = 48
+    xfs = np.stack([autoframe(s.bounds(), w, h, 4) for s in shapes])
+    gb = M.GlyphBatch(ShapeBatch.from_shapes(shapes))
+    c = cfg(overlap=False, ec_mode=M.EC_EDGE_PRIORITY, ec_dist=M.ALWAYS_CHECK_DISTANCE)
+    got = gb.generate(3, w, h, xfs, config=c).cpu().numpy()
+    changed = 0
+    for g, s in enumerate(shapes):
+        want = oracle.generate(s, 3, w, h, xfs[g], overlap=False, ec_mode=2, ec_dist=2)
+        close(got[g], want, "glyph %d (%d contours)" % (g, s.n_contours))
+        changed += int((bits(want) != bits(oracle.generate(s, 3, w, h, xfs[g], overlap=False, ec_mode=0))).any(axis=2).sum()) if s.n_contours > 6 else 0
+    assert changed > 200, "the stroke glyphs were meant to need many corrections (%d)" % changed
+    gb.close()
+    rng = np.random.default_rng(9)
+    s = batch.shape(33)
+    xf = autoframe(bounds[33], 32, 32, 4)
+    noisy = oracle.generate(s, 3, 32, 32, xf, ec_mode=0)+rng.normal(0, .2, (32, 32, 3)).astype(np.float32)
+    for dist in (M.CHECK_DISTANCE_AT_EDGE, M.ALWAYS_CHECK_DISTANCE):
+        want = oracle.error_correction(s, noisy, xf, ec_mode=2, ec_dist=dist)
+        got = M.msdf_error_correction(noisy.copy(), s, M.SDFTransformation.from_xf(xf), cfg(ec_dist=dist))
+        close(got, want, "standalone correction of a noisy field, distance check %d" % dist)
