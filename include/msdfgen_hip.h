@@ -210,6 +210,9 @@ typedef struct MsdfHipPrepConfig {
 int msdfhip_batch_create_prepared(MsdfHipBatch **batch, int n_glyphs, const int32_t *glyph_contour_offsets, const int32_t *contour_offsets,
                                   const double *points, const uint8_t *types, const uint8_t *colors, const uint64_t *seeds,
                                   const MsdfHipPrepConfig *cfg);
+/* Diagnostics: after an error-correction pass, counts[0] = 1 if some glyph's candidate segment overflowed (those glyphs were redone by
+ * the full per-texel pipeline), counts[1+g] = deferred distance checks pushed for glyph g. counts holds n_glyphs+1 entries. */
+int msdfhip_batch_candidate_counts(const MsdfHipBatch *batch, uint32_t *counts);
 int msdfhip_batch_info(const MsdfHipBatch *batch, int *n_glyphs, int *n_contours, int *n_edges, int *max_contours, int *max_edges);
 int msdfhip_batch_download(const MsdfHipBatch *batch, int32_t *contour_offsets, double *points, uint8_t *types, uint8_t *colors);
 

@@ -404,6 +404,12 @@ class GlyphBatch:
                                                                 out.data_ptr(), s))
         return out
 
+    def candidate_counts(self):
+        """Diagnostics of the last error-correction pass: (overflow flag, per-glyph number of deferred distance checks)."""
+        out = np.zeros(self.n_glyphs+1, np.uint32)
+        _lib.check(_lib.load().msdfhip_batch_candidate_counts(self._handle, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return bool(out[0]), out[1:]
+
     def to_bytes(self, tiles, atlas, out_offsets, row_stride, stream=None):
         """pixelFloatToByte (core/pixel-conversion.hpp:8-10) of packed float tiles (G, H, W, N) + blit of glyph g's rectangle into the
         uint8 device tensor `atlas` at byte offset out_offsets[g] with `row_stride` bytes per atlas row. Returns `atlas`."""

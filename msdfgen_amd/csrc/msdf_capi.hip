@@ -347,7 +347,10 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     rc = ensureDeferred(b, cap, &deferred);
     if (rc != MSDFHIP_OK)
         return rc;
-    rc = setLds(k_ec_query<N, OVERLAP, GRES>, slowLds);
+    // k_ec_query parks the single-edge selector states of a glyph in LDS (48 B per edge) when the glyph has at most slotCap edges
+    const int slotCap = b->maxEdges < 170 ? (b->maxEdges > 0 ? b->maxEdges : 1) : 170;
+    const size_t slotOffset = slowLds/sizeof(double), queryLds = slowLds+(size_t) slotCap*sizeof(PBSlot);
+    rc = setLds(k_ec_query<N, OVERLAP, GRES>, queryLds);
     if (rc != MSDFHIP_OK)
         return rc;
     HIPCHK(hipMemsetAsync(deferred, 0, ecHeaderRecords(b->nGlyphs)*sizeof(EcCandidate), stream));
@@ -363,8 +366,8 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     hipLaunchKernelGGL(k_ec_params, dim3((b->nGlyphs+255)/256), dim3(256), 0, stream, b->dEcParams, dGlyphs, b->nGlyphs, cfg);
     hipLaunchKernelGGL((k_ec_fast<N>), dim3(blocks), dim3(WAVE), fastLds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, src, out, stencil, cfg,
                        (const EcGlyphParams *) b->dEcParams, deferred, seg);
-    hipLaunchKernelGGL((k_ec_query<N, OVERLAP, GRES>), dim3(queryBlocks), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
-                       (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, K, gres, gresStride);
+    hipLaunchKernelGGL((k_ec_query<N, OVERLAP, GRES>), dim3(queryBlocks), dim3(WAVE), queryLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
+                       (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, K, gres, gresStride, slotCap, slotOffset);
     hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowGrid), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
                        (const EcCandidate *) deferred, seg, 1, gres, gresStride);
     HIPCHK(hipGetLastError());
@@ -709,6 +712,19 @@ int msdfhip_batch_create_prepared(MsdfHipBatch **batch, int n_glyphs, const int3
         return rc;
     }
     *batch = b;
+    return MSDFHIP_OK;
+}
+
+int msdfhip_batch_candidate_counts(const MsdfHipBatch *b, uint32_t *counts) {
+    if (!b || !counts)
+        return fail(MSDFHIP_ERR_INVALID, "NULL argument");
+    if (!b->dDeferred)
+        return fail(MSDFHIP_ERR_INVALID, "no error-correction pass has run on this batch");
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(counts, b->dDeferred, sizeof(uint32_t)*(size_t) (b->nGlyphs+1), hipMemcpyDeviceToHost));
     return MSDFHIP_OK;
 }
 

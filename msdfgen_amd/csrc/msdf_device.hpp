@@ -499,13 +499,25 @@ MSDF_HD void pbMerge(PB &b, const PB &o) {                                   // 
         b.pos = o.pos;
 }
 
-MSDF_HD double pbCompute(const PB &b, const EdgeRec *rec, V2 o) {            // edge-selectors.cpp:108-117
+// The nearest edge's true distance converted to a perpendicular distance where the reference does so (edge-selectors.cpp:111-113).
+MSDF_HD double pbNearestPerp(const PB &b, const EdgeRec *rec, V2 o) {
+    SD sd = { b.td, b.tdot };
+    distanceToPerpendicular(rec[b.near], sd, o, b.param);
+    return sd.d;
+}
+
+// Where an Edges policy gets that value from: by default from the nearest edge's record (a per-lane gather).
+struct PerpFromRecords {
+    MSDF_HD double nearestPerp(const PB &b, const EdgeRec *rec, V2 o) const { return pbNearestPerp(b, rec, o); }
+};
+
+template <class Edges>
+MSDF_HD double pbCompute(const PB &b, const EdgeRec *rec, V2 o, const Edges &edges) {   // edge-selectors.cpp:108-117
     double m = b.td < 0 ? b.neg : b.pos;
     if (b.near >= 0) {
-        SD sd = { b.td, b.tdot };
-        distanceToPerpendicular(rec[b.near], sd, o, b.param);
-        if (fabs(sd.d) < fabs(m))
-            m = sd.d;
+        const double perp = edges.nearestPerp(b, rec, o);
+        if (fabs(perp) < fabs(m))
+            m = perp;
     }
     return m;
 }
@@ -643,14 +655,14 @@ MSDF_HD void selMerge(Selector<SEL> &s, const Selector<SEL> &o) {            // 
 }
 
 // distance(): edge-selectors.cpp:36, :162, :235-260. out has NCH entries.
-template <int SEL>
-MSDF_HD void selDistance(const Selector<SEL> &s, const EdgeRec *rec, V2 o, double *out) {
+template <int SEL, class Edges>
+MSDF_HD void selDistance(const Selector<SEL> &s, const EdgeRec *rec, V2 o, double *out, const Edges &edges) {
     if (SEL == 1) {
         out[0] = s.m.d;
         return;
     }
     for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
-        out[i] = pbCompute(s.c[i], rec, o);
+        out[i] = pbCompute(s.c[i], rec, o, edges);
     if (SEL == 4) {                                                           // trueDistance(), :243-250
         SD t = { s.c[0].td, s.c[0].tdot };
         SD g = { s.c[SEL == 4 ? 1 : 0].td, s.c[SEL == 4 ? 1 : 0].tdot };
@@ -677,13 +689,13 @@ MSDF_HD double resolve(const double *d) {                                    // 
 // res:      per-lane scratch for the per-contour distances of the overlapping combiner, element (c, ch) at res[(c*NCH+ch)*rstride].
 
 // Edge enumeration of one glyph for the per-texel loops: contour c owns positions [begin(c), end(c)); at(k) is the record index.
-struct EdgesAll {                       // every edge, straight from the CSR offsets
+struct EdgesAll : PerpFromRecords {     // every edge, straight from the CSR offsets
     const int32_t *coff;
     MSDF_HD int begin(int c) const { return coff[c]-coff[0]; }
     MSDF_HD int end(int c) const { return coff[c+1]-coff[0]; }
     MSDF_HD int at(int k) const { return k; }
 };
-struct EdgesCulled {                    // survivors of the per-tile cull (msdf_cull.hpp), still grouped by contour and in visit order
+struct EdgesCulled : PerpFromRecords {  // survivors of the per-tile cull (msdf_cull.hpp), still grouped by contour and in visit order
     const int *cstart;                  // C+1 compacted offsets
     const int *list;                    // record index per position, or NULL if the surviving records were copied in this order
     MSDF_HD int begin(int c) const { return MSDF_UNIFORM(cstart[c]); }
@@ -711,7 +723,7 @@ MSDF_HD void shapeDistanceSimple(const EdgeRec *rec, const Edges &edges, int C, 
     selInit(sel);
     for (int c = 0; c < C; ++c)
         selAddContour(sel, rec, edges, c, o);
-    selDistance(sel, rec, o, out);
+    selDistance(sel, rec, o, out, edges);
 }
 
 template <int SEL, class Edges>
@@ -732,7 +744,7 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
         selInit(sel);
         selAddContour(sel, rec, edges, c, o);
         double d[NCH];
-        selDistance(sel, rec, o, d);
+        selDistance(sel, rec, o, d, edges);
         for (int ch = 0; ch < NCH; ++ch)
             res[(c*NCH+ch)*rstride] = d[ch];
         const double m = resolve<SEL>(d);
@@ -744,9 +756,9 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
             selMerge(outerSel, sel);
     }
     double shapeD[NCH], innerD[NCH], outerD[NCH];
-    selDistance(shapeSel, rec, o, shapeD);
-    selDistance(innerSel, rec, o, innerD);
-    selDistance(outerSel, rec, o, outerD);
+    selDistance(shapeSel, rec, o, shapeD, edges);
+    selDistance(innerSel, rec, o, innerD, edges);
+    selDistance(outerSel, rec, o, outerD, edges);
     const double innerScalar = resolve<SEL>(innerD);
     const double outerScalar = resolve<SEL>(outerD);
     double dist[NCH];

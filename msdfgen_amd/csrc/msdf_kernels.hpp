@@ -291,14 +291,49 @@ struct PsdfQuery {                                                  // ShapeDist
 // states are merged across lanes in visit order. pbMerge keeps the earlier state on ties exactly like the sequential pbAddTrue
 // (strict SignedDistance <, edge-selectors.cpp:81-87, :96-106) and max/min of the perpendicular distances do not depend on the
 // order, so the merged state -- identical in every lane afterwards -- equals the sequential one bit for bit.
+struct PBSlot { double td, tdot, neg, pos, param, perp; int near, pad; };   // a single-edge selector state parked in LDS (56 B); perp: pbNearestPerp of it
+
 struct EdgesCooperative {
     const int32_t *coff;
     int lane;
+    PBSlot *slots;                      // LDS: one slot per edge of the glyph, or NULL (glyph too large: per-contour lane merge instead)
+    int nE;
     MSDF_HD int begin(int c) const { return coff[c]-coff[0]; }
     MSDF_HD int end(int c) const { return coff[c+1]-coff[0]; }
+    // The winner of any merge is one of the single-edge states, whose converted distance was evaluated alongside it (same operands:
+    // the edge's own true distance, dot, param and the query point) -- no second visit to the record.
+    __device__ double nearestPerp(const PB &b, const EdgeRec *rec, V2 o) const { return slots ? slots[b.near].perp : pbNearestPerp(b, rec, o); }
 };
 
 __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const EdgesCooperative &edges, int c, V2 o) {
+    if (edges.slots) {
+        // All edges of the glyph at once (lanes = edges, whatever their contour), states parked in LDS; every contour then merges its
+        // own slots in visit order -- a handful of uniform LDS reads per edge instead of a cross-lane reduction per contour.
+        if (c == 0) {
+            for (int base = 0; base < edges.nE; base += WAVE) {
+                const int i = base+edges.lane;
+                if (i < edges.nE) {
+                    Selector<2> mine;
+                    selInit(mine);
+                    selAddEdge(mine, rec[i], i, o);
+                    const PB &m = mine.c[0];
+                    PBSlot slot;
+                    slot.td = m.td, slot.tdot = m.tdot, slot.neg = m.neg, slot.pos = m.pos, slot.param = m.param, slot.near = m.near, slot.pad = 0;
+                    slot.perp = m.near >= 0 ? pbNearestPerp(m, rec, o) : 0.;
+                    edges.slots[i] = slot;
+                }
+            }
+            waveSync();
+        }
+        const int e = edges.end(c);
+        for (int i = edges.begin(c); i < e; ++i) {
+            const PBSlot slot = edges.slots[i];
+            PB one;
+            one.td = slot.td, one.tdot = slot.tdot, one.neg = slot.neg, one.pos = slot.pos, one.param = slot.param, one.near = slot.near;
+            pbMerge(sel.c[0], one);
+        }
+        return;
+    }
     const int e = edges.end(c);
     for (int base = edges.begin(c); base < e; base += WAVE) {
         Selector<2> mine;
@@ -330,10 +365,13 @@ struct PsdfQueryCooperative {                                       // same quer
     const int8_t *windings;
     int C, lane;
     double *res;
+    PBSlot *slots;
     __device__ double operator()(V2 q) const {
         double out[1];
         EdgesCooperative edges;
-        edges.coff = coff, edges.lane = lane;
+        edges.coff = coff, edges.lane = lane, edges.slots = slots, edges.nE = coff[C]-coff[0];
+        if (slots)
+            waveSync();                                             // the previous query's slot reads are done
         if (OVERLAP)
             shapeDistanceOverlap<2>(rec, edges, windings, C, q, res, WAVE, out);
         else
@@ -477,9 +515,11 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
 template <int N, bool OVERLAP, bool GRES = false>
 __global__ void __launch_bounds__(WAVE, 2)
 k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, const float *src, float *out, uint8_t *stencilOut,
-           MsdfHipConfig cfg, const EcGlyphParams *glyphParams, const EcCandidate *cands, unsigned seg, unsigned K, double *gres, size_t gresStride) {
-    extern __shared__ double smemLds[];                             // [maxContours][64] combiner scratch (overlap only)
+           MsdfHipConfig cfg, const EcGlyphParams *glyphParams, const EcCandidate *cands, unsigned seg, unsigned K, double *gres, size_t gresStride,
+           int slotCap, size_t slotOffset) {
+    extern __shared__ double smemLds[];                             // [maxContours][64] combiner scratch (overlap only), then slotCap PBSlots
     double *smem = GRES ? gres+(size_t) blockIdx.x*gresStride : smemLds;
+    PBSlot *slotBuf = reinterpret_cast<PBSlot *>(smemLds+slotOffset);
     const unsigned *header = reinterpret_cast<const unsigned *>(cands);
     const size_t texelsPerGlyph = (size_t) width*height;
     const size_t units = (size_t) batch.nGlyphs*K;
@@ -509,7 +549,9 @@ k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, c
         // and scalar record loads since the whole wavefront is on one glyph). The first wins for the usual handful of candidates on a
         // glyph of few contours, the second for many candidates / many small contours (CJK-like shapes: 14 contours of 6 edges).
         const int nE = coff[C]-coff[0];
-        const bool lanePerCandidate = (size_t) count*C*2 > (size_t) nE*K;
+        const bool slotted = nE <= slotCap;                         // the glyph's single-edge states fit the LDS slots
+        const bool lanePerCandidate = slotted ? (size_t) count*((nE+WAVE-1)/WAVE*4+C) > (size_t) 16*nE*K
+                                              : (size_t) count*C*2 > (size_t) nE*K;
         if (lanePerCandidate) {
             PsdfQuery<OVERLAP> query;
             query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.res = smem+threadIdx.x;
@@ -536,6 +578,7 @@ k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, c
         PsdfQueryCooperative<OVERLAP> query;
         query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.lane = threadIdx.x;
         query.res = smem+threadIdx.x;
+        query.slots = slotted ? slotBuf : NULL;
         for (unsigned i = k; i < count; i += K) {                    // one candidate at a time, the wavefront shares its edges
             const EcCandidate cand = segment[i];
             const size_t texel = cand.texel;

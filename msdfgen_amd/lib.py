@@ -71,6 +71,7 @@ _PROTOS = {
     "msdfhip_batch_create": (C.c_int, [C.POINTER(_vp), C.c_int, _ip, _ip, _dp, _bp, _bp]),
     "msdfhip_batch_create_device": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "msdfhip_batch_create_prepared": (C.c_int, [C.POINTER(_vp), C.c_int, _ip, _ip, _dp, _bp, _bp, C.POINTER(C.c_uint64), C.POINTER(PrepConfig)]),
+    "msdfhip_batch_candidate_counts": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "msdfhip_batch_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "msdfhip_batch_download": (C.c_int, [_vp, _ip, _dp, _bp, _bp]),
     "msdfhip_batch_digest": (C.c_int, [_vp, _vp]),

@@ -87,11 +87,11 @@ class Emu:
         self.lib.emu_rasterize(_p(out, C.c_float), w, h, w, int(bool(s.inverse_y) != bool(y_down)), *args, _p(x6, C.c_double), int(rule))
         return out
 
-    def psdf_cooperative(self, s, overlap, pts):
+    def psdf_cooperative(self, s, overlap, pts, slotted=False):
         keep, args = self._shape(s)
         pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2)
         out = np.zeros(len(pts))
-        self.lib.emu_psdf_cooperative(int(overlap), *args, len(pts), _p(pts, C.c_double), _p(out, C.c_double))
+        self.lib.emu_psdf_cooperative(int(overlap)+2*int(slotted), *args, len(pts), _p(pts, C.c_double), _p(out, C.c_double))
         return out
 
     def shape_prepare(self, s, normalize=True, coloring=1, angle=3.0, seed=0):

@@ -432,11 +432,24 @@ extern "C" void emu_rasterize(float *pixels, int w, int h, int rowStride, int fl
 // are merged with the kernel's shuffle tree (lane l <- merge(l, l+off), off = 1, 2, ... 32), chunk results are merged in order.
 namespace msdfhip {
 struct EdgesCoopEmu {
+    bool slotted;                       // true: the kernel's LDS-slot path (all edges first, then a serial merge per contour)
+    std::vector<double> *perps;         // slotted: pbNearestPerp of every single-edge state (PBSlot::perp)
+    double nearestPerp(const PB &b, const EdgeRec *rec, V2 o) const { return slotted ? (*perps)[b.near] : pbNearestPerp(b, rec, o); }
     const int32_t *coff;
     int begin(int c) const { return coff[c]-coff[0]; }
     int end(int c) const { return coff[c+1]-coff[0]; }
 };
 inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const EdgesCoopEmu &edges, int c, V2 o) {
+    if (edges.slotted) {
+        for (int i = edges.begin(c); i < edges.end(c); ++i) {
+            Selector<2> mine;
+            selInit(mine);
+            selAddEdge(mine, rec[i], i, o);
+            (*edges.perps)[i] = mine.c[0].near >= 0 ? pbNearestPerp(mine.c[0], rec, o) : 0.;
+            pbMerge(sel.c[0], mine.c[0]);
+        }
+        return;
+    }
     const int e = edges.end(c);
     for (int base = edges.begin(c); base < e; base += 64) {
         PB lanes[64];
@@ -468,6 +481,10 @@ extern "C" void emu_psdf_cooperative(int overlap, int nC, const int32_t *co, con
     std::vector<double> res((size_t) (nC+1)*4);
     EdgesCoopEmu edges;
     edges.coff = co;
+    edges.slotted = overlap >= 2;
+    overlap &= 1;
+    std::vector<double> perps((size_t) co[nC]+1);
+    edges.perps = &perps;
     for (int i = 0; i < n; ++i) {
         double o[1] = { 0 };
         const V2 q = mk(pts[2*i], pts[2*i+1]);

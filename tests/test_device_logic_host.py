@@ -221,3 +221,4 @@ def test_cooperative_psdf_query_equals_sequential(emu, oracle, latin):
             want = oracle.shape_distance(s, 2, overlap, pts)[:, 0]
             got = emu.psdf_cooperative(s, overlap, pts)
             assert_bit_equal(got, want, "cooperative PSDF, overlap=%s, %d edges" % (overlap, s.n_edges))
+            assert_bit_equal(emu.psdf_cooperative(s, overlap, pts, slotted=True), want, "slotted cooperative PSDF, overlap=%s" % overlap)

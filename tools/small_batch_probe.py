@@ -1,20 +1,28 @@
-"""Kernel-level timing of SMALL batches (what the micro-batcher produces): run under rocprofv3 --kernel-trace.
-    python tools/small_batch_probe.py [n_glyphs]"""
+"""Diagnostics: distribution of deferred distance checks per glyph (the work of k_ec_query) for the headline and the CJK-like config."""
 import os
 import sys
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch  # noqa: E402
+import torch  # noqa: E402,F401
 import msdfgen_amd as M  # noqa: E402
+from msdfgen_amd import synth  # noqa: E402
+from msdfgen_amd.shape import ShapeBatch, autoframe  # noqa: E402
 from bench import load_latin, tile_batch  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 M.init(0)
 latin, xf64 = load_latin()
-b, x = tile_batch(latin, xf64, n, offset=11)
+b, x = tile_batch(latin, xf64, 940)
 gb = M.GlyphBatch(b)
-for _ in range(20):
-    gb.digest()
-    out = gb.generate(3, 64, 64, x)
-    torch.cuda.synchronize()
+gb.generate(3, 64, 64, x)
+ov, c = gb.candidate_counts()
+print("latin 64x64: overflow %s, candidates/glyph mean %.1f p50 %d p99 %d max %d" % (ov, c.mean(), np.percentile(c, 50), np.percentile(c, 99), c.max()))
+base = [synth.cjk_like_shape(20000+i) for i in range(512)]
+cj = ShapeBatch.from_shapes(base)
+cx = np.stack([autoframe(s.bounds(), 48, 48, 4) for s in base])
+gb = M.GlyphBatch(cj)
+gb.generate(3, 48, 48, cx)
+ov, c = gb.candidate_counts()
+print("cjk-like 48x48: overflow %s, candidates/glyph mean %.1f p50 %d p99 %d max %d" % (ov, c.mean(), np.percentile(c, 50), np.percentile(c, 99), c.max()))
