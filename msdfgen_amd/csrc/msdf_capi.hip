@@ -120,12 +120,10 @@ int digest(MsdfHipBatch *b, hipStream_t stream) {
         HIPCHK(hipMalloc((void **) &b->dRecs, sizeof(EdgeRec)*(size_t) (b->nEdges > 0 ? b->nEdges : 1)));
     if (!b->dWindings)
         HIPCHK(hipMalloc((void **) &b->dWindings, (size_t) (b->nContours > 0 ? b->nContours : 1)));
-    if (b->nEdges > 0)
-        hipLaunchKernelGGL(k_prep_records, dim3((b->nEdges+255)/256), dim3(256), 0, stream, b->dRecs, b->nEdges, b->nContours,
-                           b->dContourOffsets, b->dPoints, b->dTypes, b->dColors);
-    if (b->nContours > 0)
-        hipLaunchKernelGGL(k_windings, dim3((b->nContours+255)/256), dim3(256), 0, stream, b->dWindings, b->nContours,
-                           b->dContourOffsets, b->dPoints, b->dTypes, b->dColors);
+    const int edgeBlocks = (b->nEdges+255)/256, contourBlocks = (b->nContours+255)/256;
+    if (edgeBlocks+contourBlocks > 0)                            // records and windings in one launch
+        hipLaunchKernelGGL(k_prep_records, dim3(edgeBlocks+contourBlocks), dim3(256), 0, stream, b->dRecs, b->nEdges, b->nContours,
+                           b->dContourOffsets, b->dPoints, b->dTypes, b->dColors, b->dWindings, edgeBlocks);
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
 }
@@ -353,7 +351,6 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     rc = setLds(k_ec_query<N, OVERLAP, GRES>, queryLds);
     if (rc != MSDFHIP_OK)
         return rc;
-    HIPCHK(hipMemsetAsync(deferred, 0, ecHeaderRecords(b->nGlyphs)*sizeof(EcCandidate), stream));
     const size_t fastLds = (size_t) (b->maxEdges > 0 ? b->maxEdges : 1)*2*sizeof(int);
     rc = setLds(k_ec_fast<N>, fastLds);
     if (rc != MSDFHIP_OK)
@@ -363,7 +360,8 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     K = K < 4 ? 4 : K > seg ? seg : K;
     const size_t units = (size_t) b->nGlyphs*K;
     const unsigned queryBlocks = (unsigned) (GRES ? (units < queryGrid ? units : queryGrid) : (units < 0x7fffffffull ? units : 0x7fffffffull));
-    hipLaunchKernelGGL(k_ec_params, dim3((b->nGlyphs+255)/256), dim3(256), 0, stream, b->dEcParams, dGlyphs, b->nGlyphs, cfg);
+    hipLaunchKernelGGL(k_ec_params, dim3((b->nGlyphs+255)/256), dim3(256), 0, stream, b->dEcParams, dGlyphs, b->nGlyphs, cfg,
+                       reinterpret_cast<unsigned *>(deferred));   // also zeroes the candidate header
     hipLaunchKernelGGL((k_ec_fast<N>), dim3(blocks), dim3(WAVE), fastLds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, src, out, stencil, cfg,
                        (const EcGlyphParams *) b->dEcParams, deferred, seg);
     hipLaunchKernelGGL((k_ec_query<N, OVERLAP, GRES>), dim3(queryBlocks), dim3(WAVE), queryLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,

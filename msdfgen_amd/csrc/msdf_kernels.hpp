@@ -1,6 +1,6 @@
 // msdf_kernels.hpp -- gfx950 kernels of the MSDF hot path.
 //
-//   k_prep_records / k_windings   once per batch upload: raw CSR edge buffer -> EdgeRec records (+ contour windings) in HBM
+//   k_prep_records (+ windings)   once per batch upload: raw CSR edge buffer -> EdgeRec records (+ contour windings) in HBM
 //   k_distance<SEL,OVERLAP,LDSREC>  one wavefront = one 8x8 texel tile of one glyph; lane = texel. The glyph's edge records are
 //                                 staged through LDS once per workgroup and then read with wave-uniform (broadcast) ds_reads while
 //                                 every lane runs the full per-contour nearest-edge selection in fp64 registers. The overlapping
@@ -45,8 +45,16 @@ struct BatchView {
 
 // ------------------------------------------------------------------------------------------------------------- prep
 
+// The first edgeBlocks workgroups digest one edge per thread; the workgroups after them compute one contour winding per thread
+// (k_windings' job, folded into the same launch: the single-shape entry points are launch-latency bound).
 __global__ void k_prep_records(EdgeRec *recs, int nEdges, int nContours, const int32_t *contourOffsets,
-                               const double *points, const uint8_t *types, const uint8_t *colors) {
+                               const double *points, const uint8_t *types, const uint8_t *colors, int8_t *windings, int edgeBlocks) {
+    if ((int) blockIdx.x >= edgeBlocks) {
+        const int c = ((int) blockIdx.x-edgeBlocks)*blockDim.x+threadIdx.x;
+        if (c < nContours)
+            windings[c] = (int8_t) contourWinding(c, contourOffsets, points, types, colors);
+        return;
+    }
     int slot = blockIdx.x*blockDim.x+threadIdx.x;
     if (slot >= nEdges)
         return;
@@ -59,13 +67,6 @@ __global__ void k_prep_records(EdgeRec *recs, int nEdges, int nContours, const i
             hi = mid-1;
     }
     prepRecord(recs, slot, lo, contourOffsets, points, types, colors);
-}
-
-__global__ void k_windings(int8_t *windings, int nContours, const int32_t *contourOffsets,
-                           const double *points, const uint8_t *types, const uint8_t *colors) {
-    int c = blockIdx.x*blockDim.x+threadIdx.x;
-    if (c < nContours)
-        windings[c] = (int8_t) contourWinding(c, contourOffsets, points, types, colors);
 }
 
 // ---------------------------------------------------------------------------------------------------------- helpers
@@ -420,10 +421,15 @@ struct EcGlyphParams {
 };
 static_assert(sizeof(EcGlyphParams) == 56, "EcGlyphParams layout");
 
-__global__ void k_ec_params(EcGlyphParams *out, const MsdfHipGlyph *glyphs, int nGlyphs, MsdfHipConfig cfg) {
+__global__ void k_ec_params(EcGlyphParams *out, const MsdfHipGlyph *glyphs, int nGlyphs, MsdfHipConfig cfg, unsigned *candidateHeader) {
     const int g = blockIdx.x*blockDim.x+threadIdx.x;
     if (g >= nGlyphs)
         return;
+    if (candidateHeader) {                                          // zero the candidate counters for k_ec_fast (saves a memset launch)
+        candidateHeader[1+g] = 0;
+        if (g == 0)
+            candidateHeader[0] = 0;
+    }
     EcParams p;
     p.t = loadXform(glyphs[g]);
     p.minDeviationRatio = cfg.min_deviation_ratio;
