@@ -445,8 +445,11 @@ __global__ void k_ec_params(EcGlyphParams *out, const MsdfHipGlyph *glyphs, int 
 // Writes corrected texels to the caller's bitmap (msdfErrorCorrectionInner, core/msdf-error-correction.cpp:12-48) and, if stencilOut,
 // the stencil byte [g][h][w] (native rows). Candidates whose verdict needs an exact shape-distance query are appended to `cands`
 // and judged by k_ec_query; a texel with a cheaply decided ERROR never needs them (the flag is an OR).
+#ifndef MSDF_EC_FAST_WAVES_PER_SIMD
+#define MSDF_EC_FAST_WAVES_PER_SIMD 5   // 96 VGPRs (6 spilled). Measured, ms per 8192 glyphs of the whole correction pass: 4 waves 2.58, 5 waves 2.40, 6 waves 2.85, 8 waves 4.22
+#endif
 template <int N>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(WAVE, MSDF_EC_FAST_WAVES_PER_SIMD)
 k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph,
           const float *src, float *out, uint8_t *stencilOut, MsdfHipConfig cfg, const EcGlyphParams *glyphParams, EcCandidate *cands, unsigned seg) {
     extern __shared__ int smemCorners[];                            // (l, b) per colour-change corner of the glyph
