@@ -197,7 +197,8 @@ int msdfhip_batch_generate_host(const MsdfHipBatch *batch, int mode, int width, 
 
 /* Shape preparation on the device: what callers run on every glyph before the generators.
  *   normalize  Shape::normalize (core/Shape.cpp:65-92): single-edge contours split in thirds, convergent edges pushed apart
- *   coloring   0 keep `colors`, 1 edgeColoringSimple(shape, angle_threshold, seed) (core/edge-coloring.cpp:68-142)
+ *   coloring   0 keep `colors`, 1 edgeColoringSimple(shape, angle_threshold, seed) (core/edge-coloring.cpp:68-142),
+ *              2 edgeColoringInkTrap(shape, angle_threshold, seed) (core/edge-coloring.cpp:151-258)
  * msdfhip_batch_create_prepared uploads RAW outlines (colors may be NULL = all WHITE), prepares them on the device and returns a
  * digested batch of the prepared shapes; seeds: one per glyph, or NULL to use cfg->seed for every glyph. The prepared shapes can be
  * read back with msdfhip_batch_info (sizes) + msdfhip_batch_download (arrays sized from those; any pointer may be NULL). */

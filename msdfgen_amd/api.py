@@ -316,8 +316,8 @@ class GlyphBatch:
 
     @classmethod
     def from_raw(cls, raw: ShapeBatch, normalize=True, coloring=1, angle_threshold=3.0, seeds=None, seed=0, device=None):
-        """Uploads RAW outlines and prepares them on the device: Shape::normalize (core/Shape.cpp:65-92) and, with coloring=1,
-        edgeColoringSimple(shape, angle_threshold, seed) (core/edge-coloring.cpp:68-142; `seeds`: one per glyph). The prepared
+        """Uploads RAW outlines and prepares them on the device: Shape::normalize (core/Shape.cpp:65-92) and edgeColoringSimple
+        (coloring=1, core/edge-coloring.cpp:68-142) or edgeColoringInkTrap (coloring=2, :151-258) with (angle_threshold, seed; `seeds`: one per glyph). The prepared
         shapes are read back once into `.shapes` (they are small); the batch is digested and ready for generate()."""
         import torch
         if not torch.cuda.is_available():

@@ -596,8 +596,8 @@ int msdfhip_batch_create_prepared(MsdfHipBatch **batch, int n_glyphs, const int3
                                   const uint8_t *colors, const uint64_t *seeds, const MsdfHipPrepConfig *cfg) {
     if (!batch || n_glyphs < 0 || !gco || !co || !cfg)
         return fail(MSDFHIP_ERR_INVALID, "bad arguments to msdfhip_batch_create_prepared");
-    if (cfg->coloring < 0 || cfg->coloring > 1)
-        return fail(MSDFHIP_ERR_INVALID, "coloring %d (0 keep, 1 edgeColoringSimple)", cfg->coloring);
+    if (cfg->coloring < 0 || cfg->coloring > 2)
+        return fail(MSDFHIP_ERR_INVALID, "coloring %d (0 keep, 1 edgeColoringSimple, 2 edgeColoringInkTrap)", cfg->coloring);
     int rc = ensureDevice();
     if (rc != MSDFHIP_OK)
         return rc;
@@ -678,9 +678,16 @@ int msdfhip_batch_create_prepared(MsdfHipBatch **batch, int n_glyphs, const int3
             PREP_CHK(dev.alloc((void **) &dSeeds, sizeof(unsigned long long)*(size_t) n_glyphs));
             PREP_CHK(hipMemcpy(dSeeds, seeds, sizeof(unsigned long long)*(size_t) n_glyphs, hipMemcpyHostToDevice));
         }
+        CornerWork corners = { NULL, NULL, NULL, NULL };
+        if (cfg->coloring == 2) {                                 // edgeColoringInkTrap keeps a list of corners per contour (at most one per edge)
+            PREP_CHK(dev.alloc((void **) &corners.index, sizeof(int)*eNorm));
+            PREP_CHK(dev.alloc((void **) &corners.length, sizeof(double)*eNorm));
+            PREP_CHK(dev.alloc((void **) &corners.minor, eNorm));
+            PREP_CHK(dev.alloc((void **) &corners.color, eNorm));
+        }
         if (n_glyphs)
             hipLaunchKernelGGL(k_prep_colour, dim3((n_glyphs+63)/64), dim3(64), 0, 0, norm, (const int32_t *) dGco, (const int32_t *) dCo1, (const int32_t *) dCo2,
-                               n_glyphs, crossThreshold, (const unsigned long long *) dSeeds, (unsigned long long) cfg->seed, fin);
+                               n_glyphs, crossThreshold, (const unsigned long long *) dSeeds, (unsigned long long) cfg->seed, fin, cfg->coloring == 2 ? 1 : 0, corners);
         finalCo = co2.data();
         dFinalCo = dCo2;
     } else

@@ -838,16 +838,21 @@ __global__ void k_prep_count(EdgeArrays norm, const int32_t *co1, int nContours,
         count[c] = colouredCount(norm, co1[c], co1[c+1]-co1[c], crossThreshold);
 }
 
-// edgeColoringSimple, one thread per glyph: the colour / seed state runs through the glyph's contours (edge-coloring.cpp:68-72).
+// edgeColoringSimple / edgeColoringInkTrap, one thread per glyph: the colour / seed state runs through the glyph's contours
+// (edge-coloring.cpp:68-72, :151-155).
 __global__ void k_prep_colour(EdgeArrays norm, const int32_t *gco, const int32_t *co1, const int32_t *co2, int nGlyphs, double crossThreshold,
-                              const unsigned long long *seeds, unsigned long long seedAll, EdgeArrays out) {
+                              const unsigned long long *seeds, unsigned long long seedAll, EdgeArrays out, int inkTrap, CornerWork corners) {
     const int g = blockIdx.x*blockDim.x+threadIdx.x;
     if (g >= nGlyphs)
         return;
     unsigned long long seed = seeds ? seeds[g] : seedAll;
     int color = initColor(seed);
-    for (int c = gco[g]; c < gco[g+1]; ++c)
-        colourContour(norm, co1[c], co1[c+1]-co1[c], out, co2[c], crossThreshold, color, seed);
+    for (int c = gco[g]; c < gco[g+1]; ++c) {
+        if (inkTrap)
+            colourContourInkTrap(norm, co1[c], co1[c+1]-co1[c], out, co2[c], crossThreshold, color, seed, corners, co1[c]);
+        else
+            colourContour(norm, co1[c], co1[c+1]-co1[c], out, co2[c], crossThreshold, color, seed);
+    }
 }
 
 // ------------------------------------------------------------------------------------------- 8-bit atlas output (row f2)

@@ -359,4 +359,87 @@ MSDF_HD void colourContour(const EdgeArrays &in, int ib, int n, const EdgeArrays
     }
 }
 
+// ---- edgeColoringInkTrap (edge-coloring.cpp:151-258)
+
+MSDF_HD double estimateEdgeLength(const PrepEdge &e) {                                // :26-34, MSDFGEN_EDGE_LENGTH_PRECISION 4
+    double len = 0;
+    V2 prev = edgePoint(e, 0);
+    for (int i = 1; i <= 4; ++i) {
+        const V2 cur = edgePoint(e, 1./4*i);
+        len += vlen(cur-prev);
+        prev = cur;
+    }
+    return len;
+}
+
+// Per-corner work arrays (EdgeColoringInkTrapCorner, :144-149); a contour with n edges has at most n corners: slots [base, base+n).
+struct CornerWork {
+    int *index;
+    double *length;          // prevEdgeLengthEstimate
+    uint8_t *minor, *color;
+};
+
+// edgeColoringInkTrap of one contour: same contract as colourContour; cw: scratch for this contour's corners at `cb`.
+MSDF_HD void colourContourInkTrap(const EdgeArrays &in, int ib, int n, const EdgeArrays &out, int ob, double crossThreshold, int &color, unsigned long long &seed,
+                                  const CornerWork &cw, int cb) {
+    if (n == 0)
+        return;
+    double splineLength = 0;
+    int nCorners = 0;
+    {
+        V2 prevDirection = edgeDirection(loadEdge(in, ib+n-1), 1);
+        for (int i = 0; i < n; ++i) {
+            const PrepEdge e = loadEdge(in, ib+i);
+            if (isCorner(normalize(prevDirection, false), normalize(edgeDirection(e, 0), false), crossThreshold)) {
+                cw.index[cb+nCorners] = i, cw.length[cb+nCorners] = splineLength, cw.minor[cb+nCorners] = 0, cw.color[cb+nCorners] = 0;
+                ++nCorners;
+                splineLength = 0;
+            }
+            splineLength += estimateEdgeLength(e);
+            prevDirection = edgeDirection(e, 1);
+        }
+    }
+    if (nCorners <= 1) {                                                              // smooth / teardrop: exactly edgeColoringSimple's branches (:174-213)
+        colourContour(in, ib, n, out, ob, crossThreshold, color, seed);
+        return;
+    }
+    const int cornerCount = nCorners;
+    int majorCornerCount = cornerCount;
+    if (cornerCount > 3) {
+        cw.length[cb] += splineLength;
+        for (int i = 0; i < cornerCount; ++i)
+            if (cw.length[cb+i] > cw.length[cb+(i+1)%cornerCount] && cw.length[cb+(i+1)%cornerCount] < cw.length[cb+(i+2)%cornerCount]) {
+                cw.minor[cb+i] = 1;
+                --majorCornerCount;
+            }
+    }
+    int initialColor = 0;
+    for (int i = 0; i < cornerCount; ++i)
+        if (!cw.minor[cb+i]) {
+            --majorCornerCount;
+            switchColorBanned(color, seed, !majorCornerCount*initialColor);
+            cw.color[cb+i] = (uint8_t) color;
+            if (!initialColor)
+                initialColor = color;
+        }
+    for (int i = 0; i < cornerCount; ++i) {
+        if (cw.minor[cb+i]) {
+            const int nextColor = cw.color[cb+(i+1)%cornerCount];
+            cw.color[cb+i] = (uint8_t) ((color&nextColor)^7);
+        } else
+            color = cw.color[cb+i];
+    }
+    int spline = 0;
+    const int start = cw.index[cb];
+    color = cw.color[cb];
+    for (int i = 0; i < n; ++i) {
+        const int index = (start+i)%n;
+        if (spline+1 < cornerCount && cw.index[cb+spline+1] == index)
+            color = cw.color[cb+(++spline)];
+        PrepEdge e = loadEdge(in, ib+index);
+        e.color = color;
+        storeEdge(out, ob+index, e);
+    }
+}
+
 } // namespace msdfhip

@@ -1807,14 +1807,118 @@ static int color_contour_simple(edge_t *edges, int n, int *corners, double cross
     return n;
 }
 
-/* normalize (if do_normalize) then edgeColoringSimple (if coloring == 1) of one shape. Output arrays: out_offsets[C+1], out_points[3E*8],
+static double estimate_edge_length(const edge_t *e) {                                         /* edge-coloring.cpp:26-34, MSDFGEN_EDGE_LENGTH_PRECISION 4 */
+    double len = 0;
+    v2 prev = edge_point(e, 0);
+    for (int i = 1; i <= 4; ++i) {
+        v2 cur = edge_point(e, 1./4*i);
+        len += vlen(vsub(cur, prev));
+        prev = cur;
+    }
+    return len;
+}
+
+typedef struct { int index; double prevEdgeLengthEstimate; int minor; int color; } inktrap_corner;   /* edge-coloring.cpp:144-149 */
+
+/* edgeColoringInkTrap on one contour (edge-coloring.cpp:156-257); corners[] has room for n entries. Returns the new edge count. */
+static int color_contour_inktrap(edge_t *edges, int n, inktrap_corner *corners, double crossThreshold, int *color, unsigned long long *seed) {
+    if (n == 0)
+        return 0;
+    double splineLength = 0;
+    int nCorners = 0;
+    v2 prevDirection = edge_direction(&edges[n-1], 1);
+    for (int i = 0; i < n; ++i) {
+        if (is_corner(vnormalize(prevDirection, 0), vnormalize(edge_direction(&edges[i], 0), 0), crossThreshold)) {
+            inktrap_corner c = { i, splineLength, 0, 0 };
+            corners[nCorners++] = c;
+            splineLength = 0;
+        }
+        splineLength += estimate_edge_length(&edges[i]);
+        prevDirection = edge_direction(&edges[i], 1);
+    }
+    if (nCorners == 0) {
+        switch_color(color, seed);
+        for (int i = 0; i < n; ++i)
+            edges[i].color = *color;
+    } else if (nCorners == 1) {
+        int colors[3];
+        switch_color(color, seed);
+        colors[0] = *color;
+        colors[1] = 7;
+        switch_color(color, seed);
+        colors[2] = *color;
+        int corner = corners[0].index;
+        if (n >= 3) {
+            for (int i = 0; i < n; ++i)
+                edges[(corner+i)%n].color = colors[1+symmetrical_trichotomy(i, n)];
+        } else {
+            edge_t parts[6];
+            split_in_thirds(&edges[0], parts+3*corner);
+            if (n >= 2) {
+                split_in_thirds(&edges[1], parts+3-3*corner);
+                parts[0].color = parts[1].color = colors[0];
+                parts[2].color = parts[3].color = colors[1];
+                parts[4].color = parts[5].color = colors[2];
+                for (int i = 0; i < 6; ++i)
+                    edges[i] = parts[i];
+                return 6;
+            }
+            parts[0].color = colors[0];
+            parts[1].color = colors[1];
+            parts[2].color = colors[2];
+            for (int i = 0; i < 3; ++i)
+                edges[i] = parts[i];
+            return 3;
+        }
+    } else {
+        int cornerCount = nCorners, majorCornerCount = nCorners;
+        if (cornerCount > 3) {
+            corners[0].prevEdgeLengthEstimate += splineLength;
+            for (int i = 0; i < cornerCount; ++i) {
+                if (corners[i].prevEdgeLengthEstimate > corners[(i+1)%cornerCount].prevEdgeLengthEstimate &&
+                    corners[(i+1)%cornerCount].prevEdgeLengthEstimate < corners[(i+2)%cornerCount].prevEdgeLengthEstimate) {
+                    corners[i].minor = 1;
+                    --majorCornerCount;
+                }
+            }
+        }
+        int initialColor = 0;
+        for (int i = 0; i < cornerCount; ++i) {
+            if (!corners[i].minor) {
+                --majorCornerCount;
+                switch_color_banned(color, seed, !majorCornerCount*initialColor);
+                corners[i].color = *color;
+                if (!initialColor)
+                    initialColor = *color;
+            }
+        }
+        for (int i = 0; i < cornerCount; ++i) {
+            if (corners[i].minor) {
+                int nextColor = corners[(i+1)%cornerCount].color;
+                corners[i].color = (*color&nextColor)^7;
+            } else
+                *color = corners[i].color;
+        }
+        int spline = 0, start = corners[0].index;
+        *color = corners[0].color;
+        for (int i = 0; i < n; ++i) {
+            int index = (start+i)%n;
+            if (spline+1 < cornerCount && corners[spline+1].index == index)
+                *color = corners[++spline].color;
+            edges[index].color = *color;
+        }
+    }
+    return n;
+}
+
+/* normalize (if do_normalize) then edgeColoringSimple (coloring == 1) or edgeColoringInkTrap (coloring == 2) of one shape. Output arrays: out_offsets[C+1], out_points[3E*8],
  * out_types[3E], out_colors[3E]. Returns the number of output edges. */
 int orc_shape_prepare(const orc_shape *in, int do_normalize, int coloring, double angle_threshold, unsigned long long seed,
                       int32_t *out_offsets, double *out_points, int32_t *out_types, int32_t *out_colors) {
     const int C = in->n_contours;
     double crossThreshold = sin(angle_threshold);
     int color = 0;
-    if (coloring == 1) {                                                                     /* initColor, edge-coloring.cpp:48-51 */
+    if (coloring == 1 || coloring == 2) {                                                    /* initColor, edge-coloring.cpp:48-51 */
         static const int colors[3] = { 6, 5, 3 };
         color = colors[seed_extract3(&seed)];
     }
@@ -1831,6 +1935,11 @@ int orc_shape_prepare(const orc_shape *in, int do_normalize, int coloring, doubl
             n = normalize_contour(edges, n);
         if (coloring == 1)
             n = color_contour_simple(edges, n, corners, crossThreshold, &color, &seed);
+        else if (coloring == 2) {
+            inktrap_corner *ic = (inktrap_corner *) malloc(sizeof(inktrap_corner)*(size_t) (n > 2 ? n : 6));
+            n = color_contour_inktrap(edges, n, ic, crossThreshold, &color, &seed);
+            free(ic);
+        }
         for (int i = 0; i < n; ++i, ++at) {
             for (int k = 0; k < 4; ++k) {
                 out_points[8*(size_t) at+2*k] = k <= edges[i].type ? edges[i].p[k].x : 0;

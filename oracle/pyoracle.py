@@ -432,7 +432,9 @@ class Ref:
     def shape_prepare(self, shape, normalize=True, coloring=1, angle=3.0, seed=0):
         """The reference's own Shape::normalize + edgeColoringSimple on a copy of `shape` -> FlatArrays."""
         h = self.shape_from_flat(shape)
-        self.prepare(h, angle, seed, normalize=normalize, color=bool(coloring))
+        self.prepare(h, angle, seed, normalize=normalize, color=coloring == 1)
+        if coloring == 2:
+            self.lib.ref_shape_color_inktrap(h, angle, seed)
         fa = self.flatten(h)
         self.free(h)
         return fa

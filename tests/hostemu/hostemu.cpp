@@ -532,8 +532,16 @@ extern "C" int emu_shape_prepare(int nC, const int32_t *co, const double *points
     for (int c = 0; c < nC; ++c)
         outCo[c+1] = outCo[c]+colouredCount(norm, co1[c], co1[c+1]-co1[c], crossThreshold);
     int color = initColor(seed);
-    for (int c = 0; c < nC; ++c)
-        colourContour(norm, co1[c], co1[c+1]-co1[c], out, outCo[c], crossThreshold, color, seed);
+    std::vector<int> ci(co1[nC]+1);
+    std::vector<double> cl(co1[nC]+1);
+    std::vector<uint8_t> cm(co1[nC]+1), cc(co1[nC]+1);
+    CornerWork cw = { ci.data(), cl.data(), cm.data(), cc.data() };
+    for (int c = 0; c < nC; ++c) {
+        if (coloring == 2)
+            colourContourInkTrap(norm, co1[c], co1[c+1]-co1[c], out, outCo[c], crossThreshold, color, seed, cw, co1[c]);
+        else
+            colourContour(norm, co1[c], co1[c+1]-co1[c], out, outCo[c], crossThreshold, color, seed);
+    }
     return outCo[nC];
 }
 

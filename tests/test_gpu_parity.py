@@ -557,6 +557,10 @@ def test_shape_preparation_on_device_matches_reference_fixture(oracle):
     gb = M.GlyphBatch.from_raw(raw, True, 0)
     _same_batch(gb.shapes, norm, "normalize only")
     gb.close()
+    gb = M.GlyphBatch.from_raw(raw, True, 2, 3.0, seeds=seeds)          # edgeColoringInkTrap
+    want = [oracle.shape_prepare(raw.shape(g), True, 2, 3.0, int(seeds[g])) for g in range(raw.n_glyphs)]
+    _same_batch(gb.shapes, ShapeBatch.from_shapes([FlatShape(f.contour_offsets, f.points, f.types, f.colors) for f in want]), "normalize + edgeColoringInkTrap")
+    gb.close()
     gb = M.GlyphBatch.from_raw(prep, False, 0)                          # nothing to do: a plain upload
     _same_batch(gb.shapes, prep, "identity")
     gb.close()
