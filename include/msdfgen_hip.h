@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MSDFHIP_ABI_VERSION 2
+#define MSDFHIP_ABI_VERSION 3
 
 /* mode: which generator (msdfgen.h:46-56) */
 #define MSDFHIP_MODE_SDF   1 /* generateSDF   msdfgen.h:47  (TrueDistanceSelector)          1 channel  */

@@ -119,7 +119,7 @@ def load(build_if_missing=True):
             fn = getattr(lib, name)  # AttributeError here == a symbol of include/msdfgen_hip.h is missing from the library
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.msdfhip_abi_version() != 2:
+        if lib.msdfhip_abi_version() != 3:
             raise MsdfHipError(ERR_INVALID, "ABI version mismatch")
         _lib = lib
         return lib
