@@ -185,6 +185,10 @@ def main():
             "valu_fp64": {"achieved": gflops, "peak": FP64_VECTOR_PEAK_GFLOPS, "unit": "GFLOP/s (algorithmic estimate, SURVEY.md 8d)", "frac": gflops/FP64_VECTOR_PEAK_GFLOPS},
             "kernel_ms": {"distance": dist_ms, "error_correction": kc.value},
         }
+        # outside the timed region: the reference-defined quality of what was just rendered (estimateSDFError, core/sdf-error-estimation.h)
+        err = gb.estimate_sdf_error(out, xfs)
+        res["quality"] = {"metric": "estimateSDFError of the rendered tiles (1 scanline per row, non-zero fill), evaluated on the device",
+                          "mean": float(err.mean()), "max": float(err.max())}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(batch, xfs, w, h)
         print(json.dumps(res))
