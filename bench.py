@@ -55,10 +55,29 @@ def algorithmic_flops(batch, w, h):
     return float(w*h)*(30.*(t == 1).sum()+300.*(t == 2).sum()+900.*(t == 3).sum()+60.*batch.n_contours+40.*batch.n_glyphs)
 
 
+def available_cores():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box reports 256 hardware threads
+    but runs the container under cpu.max = 16 CPUs; more threads than that only get throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota)/int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota//period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(batch, xfs, w, h, budget_s=15.):
     """Reference (or oracle port) on the host cores, glyph-parallel thread pool, on a bounded sample of the same workload."""
     from oracle.pyoracle import Oracle, Ref
-    cores = os.cpu_count() or 1
+    cores = available_cores()
     try:
         impl = Ref() if Ref.available() else Oracle()
     except Exception:  # noqa: BLE001
@@ -72,7 +91,8 @@ def cpu_baseline(batch, xfs, w, h, budget_s=15.):
     _, secs = impl.generate_batch_timed([shapes[i] for i in idx], 3, w, h, xfs[idx], threads=cores)
     return {"value": n/secs, "unit": "glyphs/s", "cores": cores, "kind": impl.kind,
             "sample": "%d glyphs of the same workload (Basic-Latin shapes cycled, msdf %dx%d, default error correction) through %s, "
-                      "glyph-parallel thread pool on %d threads, %.1f s" % (n, w, h, "the compiled reference (oracle/_ref)" if impl.kind == "reference" else "the plain-C oracle", cores, secs)}
+                      "glyph-parallel thread pool on %d threads (= the CPUs the container may use: %d hardware threads visible, cgroup quota applied), %.1f s" % (
+                          n, w, h, "the compiled reference (oracle/_ref)" if impl.kind == "reference" else "the plain-C oracle", cores, os.cpu_count() or 0, secs)}
 
 
 def pmc_traffic(args, w, h):
