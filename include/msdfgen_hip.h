@@ -188,7 +188,9 @@ int msdfhip_batch_windings(const MsdfHipBatch *batch, int32_t *windings);
  * d_glyphs (device, MsdfHipGlyph[n_glyphs]), d_out (device floats), d_stencil (device, n_glyphs*width*height bytes, or NULL),
  * d_scratch: device floats for the intermediate fields: one tile extent (n_glyphs*width*height*N) if error correction OR sign
  * correction runs, two if both do; may be NULL, then internal buffers are used.
- * Asynchronous on `stream` (hipStream_t or NULL = default stream). Replaces a loop of msdfgen.h:46-53 calls. */
+ * Asynchronous on `stream` (hipStream_t or NULL = default stream). Replaces a loop of msdfgen.h:46-53 calls.
+ * Thread safety: a batch keeps per-batch work buffers (candidate lists, bucket lists, the internal scratch); issue its calls from one
+ * stream at a time. Different batches, and the single-shape entry points above, are independent of each other. */
 int msdfhip_batch_generate(const MsdfHipBatch *batch, int mode, int width, int height, const MsdfHipGlyph *d_glyphs,
                            float *d_out, uint8_t *d_stencil, float *d_scratch, const MsdfHipConfig *cfg, void *stream);
 /* Convenience: same but with HOST descriptors and HOST output (tiles copied back; synchronous). */
