@@ -351,7 +351,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     rc = setLds(k_ec_query<N, OVERLAP, GRES>, queryLds);
     if (rc != MSDFHIP_OK)
         return rc;
-    const size_t fastLds = (size_t) (b->maxEdges > 0 ? b->maxEdges : 1)*2*sizeof(int);
+    const size_t fastLds = ecFastLdsBytes(b->maxEdges, N);
     rc = setLds(k_ec_fast<N>, fastLds);
     if (rc != MSDFHIP_OK)
         return rc;
@@ -363,7 +363,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     hipLaunchKernelGGL(k_ec_params, dim3((b->nGlyphs+255)/256), dim3(256), 0, stream, b->dEcParams, dGlyphs, b->nGlyphs, cfg,
                        reinterpret_cast<unsigned *>(deferred));   // also zeroes the candidate header
     hipLaunchKernelGGL((k_ec_fast<N>), dim3(blocks), dim3(WAVE), fastLds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, src, out, stencil, cfg,
-                       (const EcGlyphParams *) b->dEcParams, deferred, seg);
+                       (const EcGlyphParams *) b->dEcParams, deferred, seg, b->maxEdges);
     hipLaunchKernelGGL((k_ec_query<N, OVERLAP, GRES>), dim3(queryBlocks), dim3(WAVE), queryLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
                        (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, K, gres, gresStride, slotCap, slotOffset);
     hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowGrid), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,

@@ -112,7 +112,7 @@ MSDF_HD int edgeBetweenTexelsFast(const float *a, const float *b) {
 // candidates that need the distance check are handed to `sink(t)`.
 template <class Sink>
 MSDF_HD int diagonalPairFast(const FastCtx &cx, float am, float dm, const float *a, const float *l, const float *q,
-                             float dA, float dBC, float dD, int i0, int i1, Sink &sink) {
+                             float dA, float dBC, float dD, float l0, float q0, float l1, float q1, Sink &sink) {
     const double qa = dD-dBC+dA, qb = dBC-dA-dA, qc = dA;   // float expressions promoted, exactly as passed at :295
     if (!quadraticMayHaveRootInRange(qa, qb, qc))
         return 0;
@@ -123,7 +123,7 @@ MSDF_HD int diagonalPairFast(const FastCtx &cx, float am, float dm, const float 
         if (t[i] > MSDF_ARTIFACT_T_EPSILON && t[i] < 1-MSDF_ARTIFACT_T_EPSILON) {
             const float xm = interpolatedMedianQuad(a, l, q, t[i]);
             int rangeFlags = rangeTest2(cx, 0, 1, t[i], am, dm, xm);
-            const double tEx0 = -.5*l[i0]/q[i0], tEx1 = -.5*l[i1]/q[i1];   // :361-365
+            const double tEx0 = -.5*l0/q0, tEx1 = -.5*l1/q1;               // :361-365 (l, q of the two channels of the pair)
             if (tEx0 > 0 && tEx0 < 1) {
                 double tEnd0 = 0, tEnd1 = 1;
                 float em0 = am, em1 = dm;
@@ -205,76 +205,120 @@ MSDF_HD bool protectedByEdgesNb(const Neighbourhood &nb, const EcParams &p) {
     return prot;
 }
 
-// Fused findErrors for the texel at the centre of `nb`, enumerated in native row order (the set of neighbour tests and their operands
-// is the same in either orientation). Returns bit0: ERROR decided, bit1: some candidate needs the distance check; every such
-// candidate is reported as sink(t, dx, dyShape) with the neighbour direction in SHAPE orientation (MSDFErrorCorrection.cpp:446-453).
+// ---- fused findErrors, in two stages so that a wavefront can COMPACT the expensive part ----------------------------------------------
+// A texel is tested against its 8 neighbours x 3 channel pairs. Nearly all of those 24 tests are settled by a sign comparison
+// (stage 1); the few survivors need fp64 interpolation / a quadratic solve (stage 2). Run per texel in a wavefront, stage 2 executes
+// for a test if ANY of the 64 texels needs it, with a handful of lanes active (measured: 7 of the 24 tests per tile, 37 surviving
+// (texel, test) items per tile). The kernel therefore queues the items of all its texels and evaluates them densely, one item per lane.
+//
+// Neighbour k (native row order): 0..3 = (-1,0), (0,-1), (1,0), (0,1); 4..7 = diagonals (k&1 ? +1 : -1, k&2 ? +1 : -1).
+// Channel pair j: (j, j+1 mod 3), i.e. (1,0), (2,1), (0,2) in the reference's (minuend, subtrahend) order.
+MSDF_HD int ecNeighbourDx(int k) { return k < 4 ? (k == 0 ? -1 : k == 2 ? 1 : 0) : ((k&1) ? 1 : -1); }
+MSDF_HD int ecNeighbourDy(int k) { return k < 4 ? (k == 1 ? -1 : k == 3 ? 1 : 0) : ((k&2) ? 1 : -1); }
+
+// Stage 1: emit(k, j) for every test of the centre texel of `nb` that the cheap conditions cannot settle. Exact skips only:
+//  * the neighbour must exist and the centre must be the texel farther from the edge (:335, :349);
+//  * linear: t = dA/(dA-dB) lies in (0, 1) only if dA and dB have strictly opposite signs;
+//  * diagonal: 0 == 0 has no usable root (equation-solver.cpp:13-17); Bernstein sign test (bernsteinMayHaveRoot).
+template <class Emit>
+MSDF_HD void texelCandidatePairs(const Neighbourhood &nb, Emit &emit) {
+    const float *c = nb.v[1][1];
+    const float cdev = fabsf(medianf(c[0], c[1], c[2])-.5f);
+    MSDF_UNROLL
+    for (int k = 0; k < 4; ++k) {
+        const int dx = k == 0 ? -1 : k == 2 ? 1 : 0, dy = k == 1 ? -1 : k == 3 ? 1 : 0;
+        if (!(nb.valid&(1u<<((dy+1)*3+(dx+1)))))
+            continue;
+        const float *b = nb.v[dy+1][dx+1];
+        if (!(cdev >= fabsf(medianf(b[0], b[1], b[2])-.5f)))
+            continue;
+        MSDF_UNROLL
+        for (int j = 0; j < 3; ++j) {
+            const int i0 = j, i1 = j == 2 ? 0 : j+1;
+            const float dA = c[i1]-c[i0], dB = b[i1]-b[i0];
+            if ((dA > 0 && dB < 0) || (dA < 0 && dB > 0))
+                emit(k, j);
+        }
+    }
+    MSDF_UNROLL
+    for (int k = 4; k < 8; ++k) {
+        const int dx = (k&1) ? 1 : -1, dy = (k&2) ? 1 : -1;
+        if (!(nb.valid&(1u<<((dy+1)*3+(dx+1)))))
+            continue;
+        const float *d = nb.v[dy+1][dx+1];
+        if (!(cdev >= fabsf(medianf(d[0], d[1], d[2])-.5f)))
+            continue;
+        const float *b = nb.v[1][dx+1], *cc = nb.v[dy+1][1];
+        MSDF_UNROLL
+        for (int j = 0; j < 3; ++j) {
+            const int i0 = j, i1 = j == 2 ? 0 : j+1;
+            const float dA = c[i1]-c[i0], dBC = b[i1]-b[i0]+cc[i1]-cc[i0], dD = d[i1]-d[i0];
+            if (dA == 0 && dBC == 0 && dD == 0)
+                continue;
+            if (bernsteinMayHaveRoot(dA, dBC, dD))
+                emit(k, j);
+        }
+    }
+}
+
+MSDF_HD float pick3(const float *v, int i) { return i == 0 ? v[0] : i == 1 ? v[1] : v[2]; }
+
+// Stage 2: one surviving test. c: centre texel, n: the neighbour k, hb / vc: the horizontal / vertical neighbours on the way to a
+// diagonal one (unused for k < 4); any memory (registers, LDS). Returns judge() bits (1: ERROR decided, 2: needs the distance check, then
+// also reported as sink(t, dx, dyShape)). Same operands and operations as hasLinearArtifact / hasDiagonalArtifact (:330-381).
 template <class Sink>
-MSDF_HD int texelFindFast(const Neighbourhood &nb, const EcParams &p, bool p1, int flip, Sink &sink) {
+MSDF_HD int evaluatePair(const float *c, const float *n, const float *hb, const float *vc, const EcParams &p, bool p1, int flip, int k, int j, Sink &sink) {
     FastCtx cx;
     cx.basePass = ecHasBasePass(p);
     cx.shapePass = ecHasShapePass(p);
     cx.p1 = p1;
     cx.pShape = (p.distanceCheck == EC_CHECK_AT_EDGE) ? true : p1;   // protectAll() precedes the shape pass only in that mode (:38-39, :33)
-    const float *c = nb.v[1][1];
-    const float cm = medianf(c[0], c[1], c[2]);
-    const float cdev = fabsf(cm-.5f);
-    int verdict = 0;
-    MSDF_UNROLL
-    for (int k = 0; k < 4; ++k) {                        // horizontal / vertical neighbours
-        const int dx = k == 0 ? -1 : k == 2 ? 1 : 0, dy = k == 1 ? -1 : k == 3 ? 1 : 0;
-        if (!(nb.valid&(1u<<((dy+1)*3+(dx+1)))) || (verdict&1))
-            continue;
-        const float *b = nb.v[dy+1][dx+1];
-        const float bm = medianf(b[0], b[1], b[2]);
-        if (!(cdev >= fabsf(bm-.5f)))                    // :335
-            continue;
+    const int dx = ecNeighbourDx(k), dy = ecNeighbourDy(k);
+    const int i0 = j, i1 = j == 2 ? 0 : j+1;
+    const float cm = medianf(c[0], c[1], c[2]), nm = medianf(n[0], n[1], n[2]);
+    if (k < 4) {
         cx.span = dy == 0 ? p.hSpan : p.vSpan;
-        MSDF_UNROLL
-        for (int j = 0; j < 3; ++j) {                    // channel pairs (1,0), (2,1), (0,2)
-            const int i0 = j, i1 = j == 2 ? 0 : j+1;
-            const float dA = c[i1]-c[i0], dB = b[i1]-b[i0];
-            if (!((dA > 0 && dB < 0) || (dA < 0 && dB > 0)))
-                continue;                                // t = dA/(dA-dB) cannot lie in (0, 1)
-            const double t = (double) dA/(dA-dB);        // :281
-            if (t > MSDF_ARTIFACT_T_EPSILON && t < 1-MSDF_ARTIFACT_T_EPSILON) {
-                const float xm = interpolatedMedianLin(c, b, t);
-                const int v = judge(rangeTest2(cx, 0, 1, t, cm, bm, xm));
-                if (v&2)
-                    sink(t, dx, flip ? -dy : dy);
-                verdict |= v;
-            }
+        const float dA = pick3(c, i1)-pick3(c, i0), dB = pick3(n, i1)-pick3(n, i0);
+        const double t = (double) dA/(dA-dB);            // :281
+        if (t > MSDF_ARTIFACT_T_EPSILON && t < 1-MSDF_ARTIFACT_T_EPSILON) {
+            const float xm = interpolatedMedianLin(c, n, t);
+            const int v = judge(rangeTest2(cx, 0, 1, t, cm, nm, xm));
+            if (v&2)
+                sink(t, dx, flip ? -dy : dy);
+            return v;
         }
+        return 0;
     }
     cx.span = p.dSpan;
-    MSDF_UNROLL
-    for (int k = 0; k < 4; ++k) {                        // diagonal neighbours
-        const int dx = (k&1) ? 1 : -1, dy = (k&2) ? 1 : -1;
-        if (!(nb.valid&(1u<<((dy+1)*3+(dx+1)))) || (verdict&1))
-            continue;
-        const float *d = nb.v[dy+1][dx+1];
-        const float dm = medianf(d[0], d[1], d[2]);
-        if (!(cdev >= fabsf(dm-.5f)))                    // :349
-            continue;
-        const float *a = c, *b = nb.v[1][dx+1], *cc = nb.v[dy+1][1];   // (texel, horizontal, vertical, diagonal neighbour), :404-407
-        const float abc[3] = { a[0]-b[0]-cc[0], a[1]-b[1]-cc[1], a[2]-b[2]-cc[2] };
-        const float l[3] = { -a[0]-abc[0], -a[1]-abc[1], -a[2]-abc[2] };
-        const float q[3] = { d[0]+abc[0], d[1]+abc[1], d[2]+abc[2] };
-        struct DirSink {
-            Sink &sink;
-            int dx, dy;
-            MSDF_HD void operator()(double t) { sink(t, dx, dy); }
-        } dirSink = { sink, dx, flip ? -dy : dy };
-        MSDF_UNROLL
-        for (int j = 0; j < 3; ++j) {
-            const int i0 = j, i1 = j == 2 ? 0 : j+1;
-            const float dA = a[i1]-a[i0], dBC = b[i1]-b[i0]+cc[i1]-cc[i0], dD = d[i1]-d[i0];
-            if (dA == 0 && dBC == 0 && dD == 0)
-                continue;                                // 0 == 0: solveQuadratic reports no usable root (equation-solver.cpp:13-17)
-            if (!bernsteinMayHaveRoot(dA, dBC, dD))
-                continue;
-            if (!(verdict&1))
-                verdict |= diagonalPairFast(cx, cm, dm, a, l, q, dA, dBC, dD, i0, i1, dirSink);
-        }
+    const float *a = c, *b = hb, *cc = vc, *d = n;       // (texel, horizontal, vertical, diagonal neighbour), :404-407
+    const float abc[3] = { a[0]-b[0]-cc[0], a[1]-b[1]-cc[1], a[2]-b[2]-cc[2] };
+    const float l[3] = { -a[0]-abc[0], -a[1]-abc[1], -a[2]-abc[2] };
+    const float q[3] = { d[0]+abc[0], d[1]+abc[1], d[2]+abc[2] };
+    const float a3[3] = { a[0], a[1], a[2] };
+    struct DirSink {
+        Sink &sink;
+        int dx, dy;
+        MSDF_HD void operator()(double t) { sink(t, dx, dy); }
+    } dirSink = { sink, dx, flip ? -dy : dy };
+    const float dA = pick3(a, i1)-pick3(a, i0), dBC = pick3(b, i1)-pick3(b, i0)+pick3(cc, i1)-pick3(cc, i0), dD = pick3(d, i1)-pick3(d, i0);
+    return diagonalPairFast(cx, cm, nm, a3, l, q, dA, dBC, dD, pick3(l, i0), pick3(q, i0), pick3(l, i1), pick3(q, i1), dirSink);
+}
+
+// Both stages for one texel, test after test (host walk; the kernel queues the items instead). Returns bit0: ERROR decided, bit1: some
+// candidate needs the distance check; every such candidate is reported as sink(t, dx, dyShape) (MSDFErrorCorrection.cpp:446-453).
+template <class Sink>
+MSDF_HD int texelFindFast(const Neighbourhood &nb, const EcParams &p, bool p1, int flip, Sink &sink) {
+    struct Items {
+        unsigned char k[24], j[24];
+        int n;
+        MSDF_HD void operator()(int kk, int jj) { k[n] = (unsigned char) kk, j[n] = (unsigned char) jj; ++n; }
+    } items;
+    items.n = 0;
+    texelCandidatePairs(nb, items);
+    int verdict = 0;
+    for (int i = 0; i < items.n; ++i) {
+        const int k = items.k[i], dx = ecNeighbourDx(k), dy = ecNeighbourDy(k);
+        verdict |= evaluatePair(nb.v[1][1], nb.v[dy+1][dx+1], nb.v[1][dx+1], nb.v[dy+1][1], p, p1, flip, k, items.j[i], sink);
     }
     return verdict;
 }

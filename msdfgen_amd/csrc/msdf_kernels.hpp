@@ -448,14 +448,25 @@ __global__ void k_ec_params(EcGlyphParams *out, const MsdfHipGlyph *glyphs, int 
 #ifndef MSDF_EC_FAST_WAVES_PER_SIMD
 #define MSDF_EC_FAST_WAVES_PER_SIMD 5   // 96 VGPRs (6 spilled). Measured, ms per 8192 glyphs of the whole correction pass: 4 waves 2.58, 5 waves 2.40, 6 waves 2.85, 8 waves 4.22
 #endif
+// LDS of k_ec_fast per wavefront: corner list | 10x10 halo tile of the field | per-texel verdict words | item count | item queue.
+enum { EC_HALO = TILE+2, EC_QUEUE_CAP = WAVE*24 };
+__host__ __device__ inline size_t ecFastLdsBytes(int maxEdges, int n) {
+    return (size_t) (maxEdges > 0 ? maxEdges : 1)*2*sizeof(int)+(size_t) EC_HALO*EC_HALO*n*sizeof(float)+(WAVE+4)*sizeof(int)+EC_QUEUE_CAP*sizeof(unsigned short);
+}
+
 template <int N>
 __global__ void __launch_bounds__(WAVE, MSDF_EC_FAST_WAVES_PER_SIMD)
 k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph,
-          const float *src, float *out, uint8_t *stencilOut, MsdfHipConfig cfg, const EcGlyphParams *glyphParams, EcCandidate *cands, unsigned seg) {
-    extern __shared__ int smemCorners[];                            // (l, b) per colour-change corner of the glyph
+          const float *src, float *out, uint8_t *stencilOut, MsdfHipConfig cfg, const EcGlyphParams *glyphParams, EcCandidate *cands, unsigned seg,
+          int maxEdges) {
+    extern __shared__ int smemCorners[];                            // (l, b) per colour-change corner of the glyph, then the regions below
     const GlyphWork wk = decodeBlock(batch.nGlyphs, tilesPerGlyph);
     if (!wk.valid)
         return;
+    float *halo = reinterpret_cast<float *>(smemCorners+2*(maxEdges > 0 ? maxEdges : 1));   // [EC_HALO*EC_HALO][N]
+    int *verdictLds = reinterpret_cast<int *>(halo+EC_HALO*EC_HALO*N);                      // [WAVE]: bits 0-1 judge(), bit 8 protected
+    int *itemCount = verdictLds+WAVE;
+    unsigned short *queue = reinterpret_cast<unsigned short *>(itemCount+4);               // [EC_QUEUE_CAP]: lane | k<<6 | j<<9
     const int c0 = batch.glyphContourOffsets[wk.g], C = batch.glyphContourOffsets[wk.g+1]-c0;
     const int32_t *coff = batch.contourOffsets+c0;
     const int e0 = coff[0], nE = coff[C]-e0;
@@ -485,23 +496,99 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
             }
             nCorners += __popcll(mask);
         }
-        __syncthreads();
     }
 
+    // ---- the tile and its one-texel halo go to LDS once (native rows); texels outside the bitmap are never read back
     const int tx = wk.tile%tilesX, ty = wk.tile/tilesX;
-    const int x = tx*TILE+(lane&(TILE-1)), yn = ty*TILE+(lane>>3);
-    if (x >= width || yn >= height)
+    const float *field = src+(size_t) wk.g*height*width*N;
+    for (int idx = lane; idx < EC_HALO*EC_HALO; idx += WAVE) {
+        const int hx = tx*TILE+idx%EC_HALO-1, hy = ty*TILE+idx/EC_HALO-1;
+        if (hx >= 0 && hy >= 0 && hx < width && hy < height) {
+            const float *t = field+((size_t) hy*width+hx)*N;
+            for (int ch = 0; ch < N; ++ch)
+                halo[idx*N+ch] = t[ch];
+        }
+    }
+    if (lane == 0)
+        itemCount[0] = 0;
+    waveSync();
+
+    // ---- phase A (lane = texel): protection flags and stage 1 of findErrors; the surviving tests are queued
+    const int lx = lane&(TILE-1), ly = lane>>3;
+    const int x = tx*TILE+lx, yn = ty*TILE+ly;
+    const bool inside = x < width && yn < height;
+    const int ys = gd.flip ? height-1-yn : yn;
+    int st = 0;
+    if (inside) {
+        Neighbourhood nb;
+        nb.valid = 0;
+        MSDF_UNROLL
+        for (int dy = -1; dy <= 1; ++dy) {
+            MSDF_UNROLL
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int nx = x+dx, ny = yn+dy;
+                const bool in = nx >= 0 && ny >= 0 && nx < width && ny < height;
+                const float *t = halo+((ly+1+(in ? dy : 0))*EC_HALO+lx+1+(in ? dx : 0))*N;
+                nb.v[dy+1][dx+1][0] = t[0], nb.v[dy+1][dx+1][1] = t[1], nb.v[dy+1][dx+1][2] = t[2];
+                if (in)
+                    nb.valid |= 1u<<((dy+1)*3+(dx+1));
+            }
+        }
+        if (p.mode == EC_MODE_EDGE_PRIORITY) {
+            for (int i = 0; i < nCorners; ++i) {
+                const int l = smemCorners[2*i], b = smemCorners[2*i+1];
+                if ((x == l || x == l+1) && (ys == b || ys == b+1)) {
+                    st |= EC_PROTECTED;
+                    break;
+                }
+            }
+            if (!(st&EC_PROTECTED) && protectedByEdgesNb(nb, p))
+                st |= EC_PROTECTED;
+        } else if (p.mode == EC_MODE_EDGE_ONLY)
+            st |= EC_PROTECTED;
+        struct Push {
+            unsigned short *queue;
+            int *count;
+            int lane;
+            __device__ void operator()(int k, int j) { queue[atomicAdd(count, 1)] = (unsigned short) (lane|k<<6|j<<9); }
+        } push = { queue, itemCount, lane };
+        texelCandidatePairs(nb, push);
+    }
+    verdictLds[lane] = (st&EC_PROTECTED) ? 0x100 : 0;
+    waveSync();
+
+    // ---- phase C (lane = queued test): stage 2, densely; verdicts are OR-ed into the owning texel's word
+    const int nItems = itemCount[0];
+    for (int base = 0; base < nItems; base += WAVE) {
+        const int it = base+lane;
+        if (it >= nItems)
+            continue;
+        const unsigned item = queue[it];
+        const int s = item&63, k = (item>>6)&7, jp = item>>9;
+        const int sx = s&(TILE-1), sy = s>>3;
+        const int dx = ecNeighbourDx(k), dy = ecNeighbourDy(k);
+        const float *c = halo+((sy+1)*EC_HALO+sx+1)*N, *n = halo+((sy+1+dy)*EC_HALO+sx+1+dx)*N;
+        const float *hb = halo+((sy+1)*EC_HALO+sx+1+dx)*N, *vc = halo+((sy+1+dy)*EC_HALO+sx+1)*N;
+        CandidateSink sink;
+        sink.header = reinterpret_cast<unsigned *>(cands);
+        sink.segment = cands+ecHeaderRecords(batch.nGlyphs)+(size_t) wk.g*seg;
+        sink.seg = seg, sink.g = wk.g;
+        sink.texel = (unsigned) (((size_t) wk.g*height+ty*TILE+sy)*width+tx*TILE+sx);
+        const int v = evaluatePair(c, n, hb, vc, p, (verdictLds[s]&0x100) != 0, gd.flip, k, jp, sink);
+        if (v)
+            atomicOr(&verdictLds[s], v);
+    }
+    waveSync();
+
+    if (!inside)
         return;
-    SdfView sdf;
-    sdf.px = src+(size_t) wk.g*height*width*N;
-    sdf.w = width, sdf.h = height, sdf.N = N, sdf.flip = gd.flip;
+    const int verdict = verdictLds[lane];
+    if (ecHasBasePass(p) && p.distanceCheck == EC_CHECK_AT_EDGE)
+        st |= EC_PROTECTED;                                         // protectAll (:38-39)
+    if (verdict&1)
+        st |= EC_ERROR;
     const size_t texel = ((size_t) wk.g*height+yn)*width+x;
-    CandidateSink sink;
-    sink.header = reinterpret_cast<unsigned *>(cands);
-    sink.segment = cands+ecHeaderRecords(batch.nGlyphs)+(size_t) wk.g*seg;
-    sink.seg = seg, sink.texel = (unsigned) texel, sink.g = wk.g;
-    int st = ecTexelFast(sdf, p, smemCorners, nCorners, x, yn, sink);
-    const float *in = sdf.native(x, yn);
+    const float *in = halo+((ly+1)*EC_HALO+lx+1)*N;
     float v[N];
     for (int i = 0; i < N; ++i)
         v[i] = in[i];
@@ -512,7 +599,6 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
     float *px = out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
     for (int i = 0; i < N; ++i)
         px[i] = v[i];
-    st &= ~EC_DEFER;
     if (stencilOut)
         stencilOut[texel] = (uint8_t) st;
 }
