@@ -446,7 +446,7 @@ __global__ void k_ec_params(EcGlyphParams *out, const MsdfHipGlyph *glyphs, int 
 // the stencil byte [g][h][w] (native rows). Candidates whose verdict needs an exact shape-distance query are appended to `cands`
 // and judged by k_ec_query; a texel with a cheaply decided ERROR never needs them (the flag is an OR).
 #ifndef MSDF_EC_FAST_WAVES_PER_SIMD
-#define MSDF_EC_FAST_WAVES_PER_SIMD 5   // 96 VGPRs (6 spilled). Measured, ms per 8192 glyphs of the whole correction pass: 4 waves 2.58, 5 waves 2.40, 6 waves 2.85, 8 waves 4.22
+#define MSDF_EC_FAST_WAVES_PER_SIMD 8   // 64 VGPRs (6 spilled). Measured, ms per 8192 glyphs of the whole correction pass: 4-6 waves 1.83, 7 waves 1.77, 8 waves 1.75
 #endif
 // LDS of k_ec_fast per wavefront: corner list | 10x10 halo tile of the field | per-texel verdict words | item count | item queue.
 enum { EC_HALO = TILE+2, EC_QUEUE_CAP = WAVE*24 };
