@@ -177,12 +177,13 @@ MSDF_HD void loadNeighbourhood(Neighbourhood &nb, const SdfView &sdf, int x, int
     }
 }
 
-// protectEdges (MSDFErrorCorrection.cpp:189-250) as a gather, from the register neighbourhood; see protectedByEdges in msdf_ec.hpp.
-MSDF_HD bool protectedByEdgesNb(const Neighbourhood &nb, const EcParams &p) {
+// protectEdges (MSDFErrorCorrection.cpp:189-250) as a gather, from the register neighbourhood; see protectedByEdges in msdf_ec.hpp. Two
+// stages like findErrors below: stage 1 emits the neighbours m = (dy+1)*3+(dx+1) whose pair passes the radius test (:201, :217, :233),
+// stage 2 (evaluateProtectPair) runs edgeBetweenTexels on such a pair -- up to three fp64 divisions -- and is queued by the kernel.
+template <class Emit>
+MSDF_HD void texelProtectPairs(const Neighbourhood &nb, const EcParams &p, Emit &emit) {
     const float *self = nb.v[1][1];
-    const float sm = medianf(self[0], self[1], self[2]);
-    const float sdev = fabsf(sm-.5f);
-    bool prot = false;
+    const float sdev = fabsf(medianf(self[0], self[1], self[2])-.5f);
     MSDF_UNROLL
     for (int dy = -1; dy <= 1; ++dy) {
         MSDF_UNROLL
@@ -193,16 +194,36 @@ MSDF_HD bool protectedByEdgesNb(const Neighbourhood &nb, const EcParams &p) {
                 continue;
             const float radius = dy == 0 ? p.radiusH : dx == 0 ? p.radiusV : p.radiusD;
             const float *other = nb.v[dy+1][dx+1];
-            const float om = medianf(other[0], other[1], other[2]);
+            const float odev = fabsf(medianf(other[0], other[1], other[2])-.5f);
             const bool selfIsA = dy > 0 || (dy == 0 && dx > 0);
-            const float sum = selfIsA ? sdev+fabsf(om-.5f) : fabsf(om-.5f)+sdev;     // fabsf(am-.5f)+fabsf(bm-.5f)
-            if (!prot && sum < radius) {
-                const int mask = selfIsA ? edgeBetweenTexelsFast(self, other) : edgeBetweenTexelsFast(other, self);
-                prot = extremeChannelInMask(self, sm, mask);
-            }
+            const float sum = selfIsA ? sdev+odev : odev+sdev;                     // fabsf(am-.5f)+fabsf(bm-.5f)
+            if (sum < radius)
+                emit((dy+1)*3+(dx+1));
         }
     }
-    return prot;
+}
+
+// Is `self` protected through its pair with neighbour m (`other`)? Pair orientation as the reference's sweeps: `a` is the texel of the
+// lower native row (same row: the left one).
+MSDF_HD bool evaluateProtectPair(const float *self, const float *other, int m) {
+    const int dy = m/3-1, dx = m%3-1;
+    const bool selfIsA = dy > 0 || (dy == 0 && dx > 0);
+    const int mask = selfIsA ? edgeBetweenTexelsFast(self, other) : edgeBetweenTexelsFast(other, self);
+    return extremeChannelInMask(self, medianf(self[0], self[1], self[2]), mask);
+}
+
+MSDF_HD bool protectedByEdgesNb(const Neighbourhood &nb, const EcParams &p) {
+    struct Items {
+        unsigned char m[8];
+        int n;
+        MSDF_HD void operator()(int mm) { m[n++] = (unsigned char) mm; }
+    } items;
+    items.n = 0;
+    texelProtectPairs(nb, p, items);
+    for (int i = 0; i < items.n; ++i)
+        if (evaluateProtectPair(nb.v[1][1], nb.v[items.m[i]/3][items.m[i]%3], items.m[i]))
+            return true;
+    return false;
 }
 
 // ---- fused findErrors, in two stages so that a wavefront can COMPACT the expensive part ----------------------------------------------

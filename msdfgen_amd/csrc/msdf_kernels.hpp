@@ -449,9 +449,10 @@ __global__ void k_ec_params(EcGlyphParams *out, const MsdfHipGlyph *glyphs, int 
 #define MSDF_EC_FAST_WAVES_PER_SIMD 8   // 64 VGPRs (6 spilled). Measured, ms per 8192 glyphs of the whole correction pass: 4-6 waves 1.83, 7 waves 1.77, 8 waves 1.75
 #endif
 // LDS of k_ec_fast per wavefront: corner list | 10x10 halo tile of the field | per-texel verdict words | item count | item queue.
-enum { EC_HALO = TILE+2, EC_QUEUE_CAP = WAVE*24 };
+enum { EC_HALO = TILE+2, EC_QUEUE_CAP = WAVE*24, EC_PROTECT_QUEUE_CAP = WAVE*8 };
 __host__ __device__ inline size_t ecFastLdsBytes(int maxEdges, int n) {
-    return (size_t) (maxEdges > 0 ? maxEdges : 1)*2*sizeof(int)+(size_t) EC_HALO*EC_HALO*n*sizeof(float)+(WAVE+4)*sizeof(int)+EC_QUEUE_CAP*sizeof(unsigned short);
+    return (size_t) (maxEdges > 0 ? maxEdges : 1)*2*sizeof(int)+(size_t) EC_HALO*EC_HALO*n*sizeof(float)+(WAVE+4)*sizeof(int)
+           +(EC_QUEUE_CAP+EC_PROTECT_QUEUE_CAP)*sizeof(unsigned short);
 }
 
 template <int N>
@@ -467,6 +468,7 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
     int *verdictLds = reinterpret_cast<int *>(halo+EC_HALO*EC_HALO*N);                      // [WAVE]: bits 0-1 judge(), bit 8 protected
     int *itemCount = verdictLds+WAVE;
     unsigned short *queue = reinterpret_cast<unsigned short *>(itemCount+4);               // [EC_QUEUE_CAP]: lane | k<<6 | j<<9
+    unsigned short *protectQueue = queue+EC_QUEUE_CAP;                                      // [EC_PROTECT_QUEUE_CAP]: lane | m<<6
     const int c0 = batch.glyphContourOffsets[wk.g], C = batch.glyphContourOffsets[wk.g+1]-c0;
     const int32_t *coff = batch.contourOffsets+c0;
     const int e0 = coff[0], nE = coff[C]-e0;
@@ -509,11 +511,11 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
                 halo[idx*N+ch] = t[ch];
         }
     }
-    if (lane == 0)
-        itemCount[0] = 0;
+    if (lane < 2)
+        itemCount[lane] = 0;
     waveSync();
 
-    // ---- phase A (lane = texel): protection flags and stage 1 of findErrors; the surviving tests are queued
+    // ---- phase A (lane = texel): corner protection and the sign / radius stages of findErrors and protectEdges; survivors are queued
     const int lx = lane&(TILE-1), ly = lane>>3;
     const int x = tx*TILE+lx, yn = ty*TILE+ly;
     const bool inside = x < width && yn < height;
@@ -542,8 +544,15 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
                     break;
                 }
             }
-            if (!(st&EC_PROTECTED) && protectedByEdgesNb(nb, p))
-                st |= EC_PROTECTED;
+            if (!(st&EC_PROTECTED)) {
+                struct PushProtect {
+                    unsigned short *queue;
+                    int *count;
+                    int lane;
+                    __device__ void operator()(int m) { queue[atomicAdd(count, 1)] = (unsigned short) (lane|m<<6); }
+                } pushProtect = { protectQueue, itemCount+1, lane };
+                texelProtectPairs(nb, p, pushProtect);
+            }
         } else if (p.mode == EC_MODE_EDGE_ONLY)
             st |= EC_PROTECTED;
         struct Push {
@@ -555,6 +564,21 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
         texelCandidatePairs(nb, push);
     }
     verdictLds[lane] = (st&EC_PROTECTED) ? 0x100 : 0;
+    waveSync();
+
+    // ---- phase B (lane = queued pair): protectEdges' edgeBetweenTexels tests, densely; a hit protects the owning texel
+    const int nProtect = itemCount[1];
+    for (int base = 0; base < nProtect; base += WAVE) {
+        const int it = base+lane;
+        if (it >= nProtect)
+            continue;
+        const unsigned item = protectQueue[it];
+        const int s = item&63, m = item>>6;
+        const int sx = s&(TILE-1), sy = s>>3;
+        const float *self = halo+((sy+1)*EC_HALO+sx+1)*N, *other = halo+((sy+m/3)*EC_HALO+sx+m%3)*N;
+        if (evaluateProtectPair(self, other, m))
+            atomicOr(&verdictLds[s], 0x100);
+    }
     waveSync();
 
     // ---- phase C (lane = queued test): stage 2, densely; verdicts are OR-ed into the owning texel's word
@@ -583,8 +607,8 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
     if (!inside)
         return;
     const int verdict = verdictLds[lane];
-    if (ecHasBasePass(p) && p.distanceCheck == EC_CHECK_AT_EDGE)
-        st |= EC_PROTECTED;                                         // protectAll (:38-39)
+    if ((verdict&0x100) || (ecHasBasePass(p) && p.distanceCheck == EC_CHECK_AT_EDGE))
+        st |= EC_PROTECTED;                                         // protectEdges hit (phase B) / protectAll (:38-39)
     if (verdict&1)
         st |= EC_ERROR;
     const size_t texel = ((size_t) wk.g*height+yn)*width+x;
