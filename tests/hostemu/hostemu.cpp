@@ -569,3 +569,41 @@ extern "C" double emu_estimate_sdf_error(int N, const float *px, int w, int h, i
         }
     return error/((h-1)*scanlinesPerRow);
 }
+
+// Diagnostics (tools only): lockstep walk of phase 2 of k_distance over one glyph, per-contour selectors as in the overlapping
+// combiner: for every surviving edge that the wavefront evaluates (some lane finds it relevant), how many of the 64 lanes did?
+// out[0] = edges evaluated by wavefronts, out[1] = lane-evaluations that were relevant, out[2] = edges skipped by the wave vote.
+extern "C" void emu_lane_relevance_stats(int w, int h, int nC, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors,
+                                         const double *xf, long *out) {
+    Digest d = digest(nC, co, points, types, colors);
+    Xform t = { xf[0], xf[1], xf[2], xf[3], xf[4], xf[5] };
+    for (int ty = 0; ty < (h+7)/8; ++ty)
+        for (int tx = 0; tx < (w+7)/8; ++tx) {
+            TileCull tc = cullTile<3>(d, co, nC, true, t, tx, ty, 8);
+            for (int c = 0; c < nC; ++c) {
+                Selector<3> sel[64];
+                for (int l = 0; l < 64; ++l)
+                    selInit(sel[l]);
+                for (int k = tc.cstart[c]; k < tc.cstart[c+1]; ++k) {
+                    const int i = tc.list[k];
+                    int relevant = 0;
+                    bool rel[64];
+                    for (int l = 0; l < 64; ++l) {
+                        const V2 p = unproject(t, mk(tx*8+(l&7)+.5, ty*8+(l>>3)+.5));
+                        rel[l] = selEdgeRelevant(sel[l], d.recs[i], p);
+                        relevant += rel[l];
+                    }
+                    if (!relevant) {
+                        ++out[2];
+                        continue;
+                    }
+                    ++out[0];
+                    out[1] += relevant;
+                    for (int l = 0; l < 64; ++l) {
+                        const V2 p = unproject(t, mk(tx*8+(l&7)+.5, ty*8+(l>>3)+.5));
+                        selAddEdge(sel[l], d.recs[i], i, p);
+                    }
+                }
+            }
+        }
+}
