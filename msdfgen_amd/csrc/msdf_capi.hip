@@ -129,15 +129,15 @@ int digest(MsdfHipBatch *b, hipStream_t stream) {
 }
 
 // LDS plan for a launch: bytes of dynamic LDS and whether the records are staged in LDS or read from global memory.
-struct LdsPlan { size_t bytes; bool ldsRec; bool globalRes; size_t resBytes, ldsBudget, idxBytes; };
+struct LdsPlan { size_t bytes; bool globalRes; size_t resBytes, ldsBudget, idxBytes; };
 const size_t GRES_WORKSPACE_CAP = (size_t) 1<<30;   // bound of the global combiner scratch; larger launches are chunked
 
 int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan, int maxContours = -1) {
     if (maxContours < 0)
         maxContours = b->maxContours;
     const size_t resBytes = overlap ? (size_t) maxContours*nch*WAVE*sizeof(double) : 0;
-    const size_t recBytes = (size_t) b->maxEdges*sizeof(EdgeRec);
-    const size_t idxBytes = ((size_t) b->maxEdges+(size_t) b->maxContours+2)*sizeof(int);   // survivor list + per-contour offsets
+    const size_t idxOne = ((size_t) b->maxEdges+(size_t) b->maxContours+2)*sizeof(int);   // survivor list + per-contour offsets of one tile
+    const size_t idxBytes = (size_t) QUAD*idxOne;                // the LDS-scratch variant culls a quad of tiles per wavefront
     plan.ldsBudget = 13*1024;
     const size_t limit = (size_t) gLdsLimit.load();
     plan.resBytes = resBytes;
@@ -148,21 +148,11 @@ int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan, int max
         plan.ldsBudget = (size_t) atol(env);
     plan.globalRes = overlap && resBytes+idxBytes > plan.ldsBudget;
     plan.idxBytes = idxBytes;
-    if (idxBytes > limit)
+    if (idxOne > limit)
         return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours / %d edges: the survivor list needs %zu B of LDS per wavefront, device limit is %zu B",
-                    b->maxContours, b->maxEdges, idxBytes, limit);
-    if (plan.globalRes) {
-        plan.ldsRec = false;
-        plan.bytes = idxBytes;
-        return MSDFHIP_OK;
-    }
-    // Measured on MI355X (profiles/): reading the surviving records straight from global memory with wave-uniform
-    // (scalar) loads beats staging them in LDS, because the LDS footprint of the worst-case glyph caps occupancy. Staging stays
-    // available as an experiment knob (MSDFHIP_LDSREC=1) while it fits in 40 KB.
-    plan.ldsRec = false;
-    if (const char *force = getenv("MSDFHIP_LDSREC"))
-        plan.ldsRec = force[0] == '1' && resBytes+recBytes+idxBytes <= 40*1024;
-    plan.bytes = resBytes+(plan.ldsRec ? recBytes : 0)+idxBytes;
+                    b->maxContours, b->maxEdges, idxOne, limit);
+    // (Staging the surviving records in LDS instead of reading them with scalar loads was measured slower and is gone.)
+    plan.bytes = plan.globalRes ? idxOne : resBytes+idxBytes;     // the global-scratch variant takes one tile per wavefront
     return MSDFHIP_OK;
 }
 
@@ -187,17 +177,18 @@ int ensureGres(const MsdfHipBatch *b, size_t bytes, double **out) {
     return MSDFHIP_OK;
 }
 
-template <int SEL, bool OVERLAP, bool LDSREC, bool GRES>
+template <int SEL, bool OVERLAP, bool GRES>
 int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, const LdsPlan &plan, hipStream_t stream,
                    const int *dGlyphMap = NULL, int nMapped = 0) {
     const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE, tiles = tilesX*tilesY;
     const int nG = dGlyphMap ? nMapped : b->nGlyphs;
     if (nG == 0)
         return MSDFHIP_OK;
-    const size_t blocks = (size_t) ((nG+7)/8)*8u*(size_t) tiles;
+    const int tpw = GRES ? 1 : (int) QUAD;                        // tiles per wavefront (msdf_kernels.hpp)
+    const size_t blocks = (size_t) ((nG+7)/8)*8u*(size_t) ((tiles+tpw-1)/tpw);
     if (blocks > 0x7fffffffull)
-        return fail(MSDFHIP_ERR_INVALID, "launch of %zu tiles exceeds the grid limit; split the batch", blocks);
-    int rc = setLds(k_distance<SEL, OVERLAP, LDSREC, GRES>, plan.bytes);
+        return fail(MSDFHIP_ERR_INVALID, "launch of %zu tile quads exceeds the grid limit; split the batch", blocks);
+    int rc = setLds(k_distance<SEL, OVERLAP, GRES>, plan.bytes);
     if (rc != MSDFHIP_OK)
         return rc;
     double *gres = NULL;
@@ -215,7 +206,7 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
     }
     for (size_t base = 0; base < blocks; base += chunk) {
         const size_t n = blocks-base < chunk ? blocks-base : chunk;
-        hipLaunchKernelGGL((k_distance<SEL, OVERLAP, LDSREC, GRES>), dim3((unsigned) n), dim3(WAVE), plan.bytes, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles,
+        hipLaunchKernelGGL((k_distance<SEL, OVERLAP, GRES>), dim3((unsigned) n), dim3(WAVE), plan.bytes, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles,
                            b->maxEdges, dst, toScratch, (unsigned) base, gres, stride, dGlyphMap, nMapped);
     }
     HIPCHK(hipGetLastError());
@@ -273,20 +264,17 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
                 rc = planLds(b, SelTraits<SEL>::NCH, overlap, small, b->smallMaxC);
                 if (rc != MSDFHIP_OK)
                     return rc;
-                rc = small.ldsRec ? launchDistance<SEL, true, true, false>(b, dGlyphs, w, h, dst, toScratch, small, stream, b->dBucket, b->nSmall)
-                                  : launchDistance<SEL, true, false, false>(b, dGlyphs, w, h, dst, toScratch, small, stream, b->dBucket, b->nSmall);
+                rc = launchDistance<SEL, true, false>(b, dGlyphs, w, h, dst, toScratch, small, stream, b->dBucket, b->nSmall);
                 if (rc != MSDFHIP_OK)
                     return rc;
-                return launchDistance<SEL, true, false, true>(b, dGlyphs, w, h, dst, toScratch, plan, stream, b->dBucket+b->nSmall, b->nGlyphs-b->nSmall);
+                return launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, plan, stream, b->dBucket+b->nSmall, b->nGlyphs-b->nSmall);
             }
         }
-        return launchDistance<SEL, true, false, true>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
+        return launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
     }
     if (overlap)
-        return plan.ldsRec ? launchDistance<SEL, true, true, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream)
-                           : launchDistance<SEL, true, false, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
-    return plan.ldsRec ? launchDistance<SEL, false, true, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream)
-                       : launchDistance<SEL, false, false, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
+        return launchDistance<SEL, true, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
+    return launchDistance<SEL, false, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
 }
 
 // Records of the per-glyph candidate segments incl. the header (msdf_kernels.hpp, EcCandidate).

@@ -1,11 +1,11 @@
 // msdf_kernels.hpp -- gfx950 kernels of the MSDF hot path.
 //
 //   k_prep_records (+ windings)   once per batch upload: raw CSR edge buffer -> EdgeRec records (+ contour windings) in HBM
-//   k_distance<SEL,OVERLAP,LDSREC>  one wavefront = one 8x8 texel tile of one glyph; lane = texel. The glyph's edge records are
-//                                 staged through LDS once per workgroup and then read with wave-uniform (broadcast) ds_reads while
-//                                 every lane runs the full per-contour nearest-edge selection in fp64 registers. The overlapping
-//                                 contour combiner keeps its per-contour distances in LDS, laid out [contour][channel][lane] so that
-//                                 lane-consecutive 8-byte accesses are bank-conflict free.
+//   k_distance<SEL,OVERLAP,GRES>  one wavefront = four 8x8 texel tiles of one glyph. Phase 1 culls the glyph's edges for the four
+//                                 tiles at once (16 lanes per tile, lanes = edges), phase 2 runs the per-contour nearest-edge
+//                                 selection tile after tile (lanes = texels) in fp64 registers; the surviving edge records are read
+//                                 with wave-uniform scalar loads. The overlapping contour combiner keeps its per-contour distances in
+//                                 LDS, laid out [contour][channel][lane] (lane-consecutive 8-byte accesses: bank-conflict free).
 //   k_ec_fast<N>                  error correction, lean single sweep over all texels (gather form, no atomics on the stencil);
 //                                 texels whose verdict needs an exact shape-distance query (~0.1 %) are appended to a list
 //   k_ec_slow<N,OVERLAP>          full per-texel pipeline incl. the PSDF distance query for the listed texels
@@ -140,19 +140,38 @@ __device__ inline float floatAbove(double d) {
 // dst: tile-major destination. If toScratch, texels go to the tightly packed pre-correction buffer [g][h][w][N] (native rows),
 // else straight to the caller's bitmap at out_offset/row_stride (generateDistanceField, core/msdfgen.cpp:52-76).
 //
-// Phase 1 (lanes = edges): per contour, bound the tile's distance to each channel, cull edges that cannot matter for any texel of
-// the tile (msdf_cull.hpp), and compact the survivors -- in visit order -- into LDS.  Phase 2 (lanes = texels): every lane runs
-// the reference's per-contour nearest-edge selection over the survivors with wave-uniform (broadcast) record reads.
-// LDS: [res: C*NCH*64 doubles (overlap)] [records: maxEdges (LDSREC)] [list: maxEdges ints] [cstart: C+1 ints].
+// Phase 1 (lanes = edges, one 16-lane row per tile of the quad): per contour, bound the tile's distance to each channel, cull edges
+// that cannot matter for any texel of the tile (msdf_cull.hpp), and compact the survivors -- in visit order -- into LDS.  Phase 2
+// (lanes = texels, one tile at a time): every lane runs the reference's per-contour nearest-edge selection over the survivors with
+// wave-uniform (scalar) record reads.
+// LDS: [res: C*NCH*64 doubles (overlap)] [lists: 4 x maxEdges ints] [cstarts: 4 x (C+1) ints].
 // GRES: the combiner scratch of glyphs with very many contours does not fit the CU's LDS; it then lives in a global workspace
 // (gres, one slice per workgroup of the launch chunk) and the launch is chunked (blockBase) to bound that workspace.
-template <int SEL, bool OVERLAP, bool LDSREC, bool GRES = false>
+// Row-wise (16 lanes = one DPP row) minimum of non-negative floats, broadcast to the row.
+__device__ inline float rowMinNonNegative(float v, int lane) {
+    int x = __float_as_int(v);
+    const int inf = 0x7f800000;
+#define MSDF_DPP_MIN(ctrl) { const int y = __builtin_amdgcn_update_dpp(inf, x, ctrl, 0xf, 0xf, false); x = y < x ? y : x; }
+    MSDF_DPP_MIN(0x111)   // row_shr:1
+    MSDF_DPP_MIN(0x112)   // row_shr:2
+    MSDF_DPP_MIN(0x114)   // row_shr:4
+    MSDF_DPP_MIN(0x118)   // row_shr:8   -> lane 15 of every row holds the row minimum
+#undef MSDF_DPP_MIN
+    return __int_as_float(__shfl(x, lane|15));
+}
+
+enum { QUAD = 4 };   // tiles per wavefront of the LDS-scratch variant (the global-scratch variant, GRES, takes one: measured faster there)
+
+template <int SEL, bool OVERLAP, bool GRES = false>
 __global__ void __launch_bounds__(WAVE, MSDF_DISTANCE_WAVES_PER_SIMD)
 k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges, float *dst, int toScratch,
            unsigned blockBase, double *gres, size_t gresStride, const int *glyphMap, int nMapped) {
-    enum { NCH = SelTraits<SEL>::NCH };
+    enum { NCH = SelTraits<SEL>::NCH, TPW = GRES ? 1 : (int) QUAD, ROW = WAVE/TPW };   // tiles per wavefront, lanes per tile in phase 1
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    GlyphWork wk = decodeBlock(glyphMap ? nMapped : batch.nGlyphs, tilesPerGlyph, blockBase);
+    // One wavefront = TPW consecutive tiles of one glyph. Phase 1 culls for all of them at once -- the edges of a contour rarely fill
+    // 64 lanes, so each 16-lane row takes one tile -- and phase 2 then walks the tiles one after the other, lanes = texels.
+    const int quadsPerGlyph = (tilesPerGlyph+TPW-1)/TPW;
+    GlyphWork wk = decodeBlock(glyphMap ? nMapped : batch.nGlyphs, quadsPerGlyph, blockBase);
     if (!wk.valid)
         return;
     if (glyphMap)
@@ -161,110 +180,114 @@ k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, i
     const int32_t *coff = batch.contourOffsets+c0;
     const int e0 = coff[0];
     const int lane = threadIdx.x;
-    const EdgeRec *recGlobal = batch.recs+e0;
+    const EdgeRec *rec = batch.recs+e0;
 
     double *res = GRES ? gres+(size_t) blockIdx.x*gresStride : smem; // [C][NCH][64] (overlap only)
-    double *recLds = smem+(OVERLAP && !GRES ? (size_t) C*NCH*WAVE : 0);
-    int *list = reinterpret_cast<int *>(recLds+(LDSREC ? (size_t) maxEdges*REC_DOUBLES : 0));
-    int *cstart = list+maxEdges;
+    int *lists = reinterpret_cast<int *>(smem+(OVERLAP && !GRES ? (size_t) C*NCH*WAVE : 0));   // [QUAD][maxEdges] survivor indices
+    int *cstarts = lists+(size_t) TPW*maxEdges;                                                 // [TPW][C+1] offsets per contour
 
     const MsdfHipGlyph gd = glyphs[wk.g];
     const Xform t = loadXform(gd);
-    const int tx = wk.tile%tilesX, ty = wk.tile/tilesX;
 
-    // ---- phase 1: cull + compact (lanes = edges)
+    // ---- phase 1: cull + compact (row q of 16 lanes = tile q of the quad; lanes of a row = edges)
     const double rsx = 1/t.sx, rsy = 1/t.sy;                        // two divisions per wavefront; texel positions below use divExact
     const bool fastXf = divSafe(t.sx) && divSafe(t.sy);
-    const V2 tc = mk((tx*TILE+.5*TILE)*rsx-t.tx, (ty*TILE+.5*TILE)*rsy-t.ty);   // tile centre: only has to be accurate to within the cull slack
     const double hx = (.5*TILE-.5)*fabs(rsx), hy = (.5*TILE-.5)*fabs(rsy);
     const double tr = sqrt(hx*hx+hy*hy);
-    int nSurv = 0;
-    // The bounds U[ch] are per contour for the overlapping combiner (one selector per contour, every contour's own distance is
-    // needed) and over the whole shape for the simple combiner (a single selector).
-    double U[3] = { DBL_MAX, DBL_MAX, DBL_MAX };
-    const int groups = OVERLAP ? C : 1;
-    for (int grp = 0; grp < groups; ++grp) {
-        const int cBegin = OVERLAP ? grp : 0, cEnd = OVERLAP ? grp+1 : C;
-        const int b = coff[cBegin]-e0, e = coff[cEnd]-e0;
-        U[0] = U[1] = U[2] = DBL_MAX;
-        for (int base = b; base < e; base += WAVE) {
-            const int i = base+lane;
-            double ub = 0;
-            int mask = 0;
-            if (i < e) {
-                ub = cullUpperDistance(recGlobal[i], tc);
-                mask = cullMask<SEL>(recGlobal[i]);
-            }
-            const float ubf = floatAbove(ub);
-            for (int ch = 0; ch < (SEL <= 2 ? 1 : 3); ++ch)
-                U[ch] = dmin(U[ch], (double) waveMinNonNegative((mask>>ch)&1 ? ubf : __int_as_float(0x7f800000)));
-        }
-        for (int c = cBegin; c < cEnd; ++c) {
-            const int cb = coff[c]-e0, ce = coff[c+1]-e0;
-            if (lane == 0)
-                cstart[c] = nSurv;
-            for (int base = cb; base < ce; base += WAVE) {
-                const int i = base+lane;
-                bool keep = false;
-                if (i < ce) {
-                    const int mask = cullMask<SEL>(recGlobal[i]);
-                    if (mask) {
-                        double umax = 0;
-                        for (int ch = 0; ch < (SEL <= 2 ? 1 : 3); ++ch)
-                            if ((mask>>ch)&1)
-                                umax = dmax(umax, U[ch]);
-#if defined(MSDF_NO_TILE_CULL)
-                        keep = true;
-#else
-                        keep = cullEdgeSurvives<(SEL >= 2)>(recGlobal[i], tc, tr, umax);
-#endif
-                    }
+    {
+        const int q = lane/ROW, col = lane%ROW;
+        const int tileQ = wk.tile*TPW+q;
+        const bool tileValid = tileQ < tilesPerGlyph;
+        const int txq = tileQ%tilesX, tyq = tileQ/tilesX;
+        const V2 tc = mk((txq*TILE+.5*TILE)*rsx-t.tx, (tyq*TILE+.5*TILE)*rsy-t.ty);   // tile centre: only has to be accurate to within the cull slack
+        int *list = lists+(size_t) q*maxEdges, *cstart = cstarts+(size_t) q*(C+1);
+        int nSurv = 0;
+        // The bounds U[ch] are per contour for the overlapping combiner (one selector per contour, every contour's own distance is
+        // needed) and over the whole shape for the simple combiner (a single selector).
+        double U[3] = { DBL_MAX, DBL_MAX, DBL_MAX };
+        const int groups = OVERLAP ? C : 1;
+        for (int grp = 0; grp < groups; ++grp) {
+            const int cBegin = OVERLAP ? grp : 0, cEnd = OVERLAP ? grp+1 : C;
+            const int b = coff[cBegin]-e0, e = coff[cEnd]-e0;
+            U[0] = U[1] = U[2] = DBL_MAX;
+            for (int base = b; base < e; base += ROW) {
+                const int i = base+col;
+                double ub = 0;
+                int mask = 0;
+                if (i < e && tileValid) {
+                    ub = cullUpperDistance(rec[i], tc);
+                    mask = cullMask<SEL>(rec[i]);
                 }
-                const unsigned long long ballot = __ballot(keep);
-                if (keep)
-                    list[nSurv+__popcll(ballot&((1ull<<lane)-1ull))] = i;
-                nSurv += __popcll(ballot);
+                const float ubf = floatAbove(ub);
+                for (int ch = 0; ch < (SEL <= 2 ? 1 : 3); ++ch)
+                    U[ch] = dmin(U[ch], (double) (TPW == 1 ? waveMinNonNegative((mask>>ch)&1 ? ubf : __int_as_float(0x7f800000))
+                                                           : rowMinNonNegative((mask>>ch)&1 ? ubf : __int_as_float(0x7f800000), lane)));
+            }
+            for (int c = cBegin; c < cEnd; ++c) {
+                const int cb = coff[c]-e0, ce = coff[c+1]-e0;
+                if (col == 0)
+                    cstart[c] = nSurv;
+                for (int base = cb; base < ce; base += ROW) {
+                    const int i = base+col;
+                    bool keep = false;
+                    if (i < ce && tileValid) {
+                        const int mask = cullMask<SEL>(rec[i]);
+                        if (mask) {
+                            double umax = 0;
+                            for (int ch = 0; ch < (SEL <= 2 ? 1 : 3); ++ch)
+                                if ((mask>>ch)&1)
+                                    umax = dmax(umax, U[ch]);
+#if defined(MSDF_NO_TILE_CULL)
+                            keep = true;
+#else
+                            keep = cullEdgeSurvives<(SEL >= 2)>(rec[i], tc, tr, umax);
+#endif
+                        }
+                    }
+                    const unsigned long long ballot = __ballot(keep);
+                    const unsigned long long rowBallot = TPW == 1 ? ballot : (ballot>>(ROW*q))&0xffffull;
+                    if (keep)
+                        list[nSurv+__popcll(rowBallot&((1ull<<col)-1ull))] = i;
+                    nSurv += __popcll(rowBallot);
+                }
             }
         }
+        if (col == 0)
+            cstart[C] = nSurv;
     }
-    if (lane == 0)
-        cstart[C] = nSurv;
     waveSync();
-    const EdgeRec *rec = recGlobal;
-    if (LDSREC) {                                                   // stage the surviving records, in list order
-        for (int k = 0; k < nSurv; ++k) {
-            const double *src = reinterpret_cast<const double *>(recGlobal+list[k]);
-            if (lane < REC_DOUBLES)
-                recLds[(size_t) k*REC_DOUBLES+lane] = src[lane];
-        }
-        rec = reinterpret_cast<const EdgeRec *>(__builtin_assume_aligned(recLds, 16));
-        waveSync();
-    }
 
-    // ---- phase 2: per-texel selection over the survivors (lanes = texels)
-    const int x = tx*TILE+(lane&(TILE-1)), y = ty*TILE+(lane>>3);
-    if (x >= width || y >= height)
-        return;
-    const V2 p = fastXf ? mk(divExact(x+.5, t.sx, rsx)-t.tx, divExact(y+.5, t.sy, rsy)-t.ty)
-                        : unproject(t, mk(x+.5, y+.5));             // msdfgen.cpp:68 (coord/scale-translate, correctly rounded either way)
-    EdgesCulled edges;
-    edges.cstart = cstart;
-    edges.list = LDSREC ? (const int *) 0 : list;
-    double d[NCH];
+    // ---- phase 2: per-texel selection over the survivors (lanes = texels), tile after tile
+    MSDF_NOUNROLL
+    for (int q = 0; q < TPW; ++q) {
+        const int tile = wk.tile*TPW+q;
+        if (tile >= tilesPerGlyph)
+            break;
+        const int tx = tile%tilesX, ty = tile/tilesX;
+        const int x = tx*TILE+(lane&(TILE-1)), y = ty*TILE+(lane>>3);
+        if (x >= width || y >= height)
+            continue;
+        const V2 p = fastXf ? mk(divExact(x+.5, t.sx, rsx)-t.tx, divExact(y+.5, t.sy, rsy)-t.ty)
+                            : unproject(t, mk(x+.5, y+.5));         // msdfgen.cpp:68 (coord/scale-translate, correctly rounded either way)
+        EdgesCulled edges;
+        edges.cstart = cstarts+(size_t) q*(C+1);
+        edges.list = lists+(size_t) q*maxEdges;
+        double d[NCH];
 #if defined(MSDF_ABLATE_PHASE2)                                     // measurement only: what phase 1 + the launch cost alone
-    for (int ch = 0; ch < NCH; ++ch)
-        d[ch] = (double) nSurv;
+        for (int ch = 0; ch < NCH; ++ch)
+            d[ch] = (double) edges.cstart[C];
 #else
-    if (OVERLAP)
-        shapeDistanceOverlap<SEL>(rec, edges, batch.windings+c0, C, p, res+lane, WAVE, d);
-    else
-        shapeDistanceSimple<SEL>(rec, edges, C, p, d);
+        if (OVERLAP)
+            shapeDistanceOverlap<SEL>(rec, edges, batch.windings+c0, C, p, res+lane, WAVE, d);
+        else
+            shapeDistanceSimple<SEL>(rec, edges, C, p, d);
 #endif
-    const int yn = gd.flip ? height-1-y : y;                        // output.reorient(shape orientation), msdfgen.cpp:55
-    float *px = toScratch ? dst+(((size_t) wk.g*height+yn)*width+x)*NCH
-                          : dst+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) NCH*x;
-    for (int ch = 0; ch < NCH; ++ch)
-        px[ch] = mapDistance(t, d[ch]);                             // msdfgen.cpp:20-48
+        const int yn = gd.flip ? height-1-y : y;                    // output.reorient(shape orientation), msdfgen.cpp:55
+        float *px = toScratch ? dst+(((size_t) wk.g*height+yn)*width+x)*NCH
+                              : dst+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) NCH*x;
+        for (int ch = 0; ch < NCH; ++ch)
+            px[ch] = mapDistance(t, d[ch]);                         // msdfgen.cpp:20-48
+    }
 }
 
 // --------------------------------------------------------------------------------------------------- error correction
