@@ -1,4 +1,4 @@
-"""Diagnostics: distribution of deferred distance checks per glyph (the work of k_ec_query) for the headline and the CJK-like config."""
+"""Diagnostics (GPU): distribution of deferred distance checks per glyph (the work of k_ec_query) for the headline and the CJK-like config."""
 import os
 import sys
 
