@@ -243,6 +243,11 @@ int msdfhip_batch_estimate_sdf_error(const MsdfHipBatch *batch, int channels, in
 int msdfhip_render_sdf(const float *d_sdf, int n_glyphs, int sdf_width, int sdf_height, int sdf_channels, float *d_out, int out_width, int out_height,
                        int out_channels, double range_lower, double range_upper, float sd_threshold, void *stream);
 int msdfhip_simulate_8bit(float *d_pixels, size_t n, void *stream);
+/* The same two on HOST bitmaps (what the C++ shim's renderSDF / simulate8bit overloads call; synchronous). Strides in floats. */
+int msdfhip_render_sdf_host(float *out, int out_width, int out_height, int out_row_stride, int out_channels,
+                            const float *sdf, int sdf_width, int sdf_height, int sdf_row_stride, int sdf_channels,
+                            double range_lower, double range_upper, float sd_threshold);
+int msdfhip_simulate_8bit_host(float *pixels, int width, int height, int row_stride, int channels);
 
 /* Timing hook for bench.py: average device time in milliseconds of the dominant kernel (the distance-field kernel) and of
  * the passes after it (sign correction + error correction, per error-correction launch) over the launches recorded since the

@@ -1332,6 +1332,70 @@ static int singleShape(int mode, int channels, int op, float *pixels, int w, int
     return submitCall(c);
 }
 
+// Host-pointer forms of renderSDF / simulate8bit (the shim's overloads): rows gathered into the calling thread's arena, one H2D copy,
+// the kernel, one D2H copy. Strides in floats, may be negative (BitmapSection).
+int msdfhip_render_sdf_host(float *out, int ow, int oh, int outStride, int no, const float *sdf, int sw, int sh, int sdfStride, int ns,
+                            double rangeLower, double rangeUpper, float sdThreshold) {
+    if (ow < 0 || oh < 0 || sw < 0 || sh < 0)
+        return fail(MSDFHIP_ERR_INVALID, "bad arguments to msdfhip_render_sdf_host");
+    if (!((no == 1 && (ns == 1 || ns == 3 || ns == 4)) || (no == 3 && (ns == 1 || ns == 3)) || (no == 4 && ns == 4)))
+        return fail(MSDFHIP_ERR_INVALID, "renderSDF has no overload for %d <- %d channels (core/render-sdf.h:12-17)", no, ns);
+    if (ow == 0 || oh == 0)
+        return MSDFHIP_OK;
+    if (!out || !sdf || sw == 0 || sh == 0)
+        return fail(MSDFHIP_ERR_INVALID, "NULL or empty bitmap");
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    const size_t inBytes = sizeof(float)*(size_t) sw*sh*ns, outBytes = sizeof(float)*(size_t) ow*oh*no;
+    Carver c;
+    const size_t offIn = c.take(inBytes), offOut = c.take(outBytes);
+    ThreadArena &a = tlsArena;
+    rc = arenaReserve(a, c.off, c.off);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    for (int y = 0; y < sh; ++y)
+        memcpy(a.pinned+offIn+sizeof(float)*(size_t) y*sw*ns, sdf+(ptrdiff_t) sdfStride*y, sizeof(float)*(size_t) sw*ns);
+    HIPCHK(hipMemcpyAsync(a.dev+offIn, a.pinned+offIn, inBytes, hipMemcpyHostToDevice, a.stream));
+    rc = msdfhip_render_sdf(reinterpret_cast<const float *>(a.dev+offIn), 1, sw, sh, ns, reinterpret_cast<float *>(a.dev+offOut), ow, oh, no,
+                            rangeLower, rangeUpper, sdThreshold, a.stream);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    HIPCHK(hipMemcpyAsync(a.pinned+offOut, a.dev+offOut, outBytes, hipMemcpyDeviceToHost, a.stream));
+    HIPCHK(hipStreamSynchronize(a.stream));
+    for (int y = 0; y < oh; ++y)
+        memcpy(out+(ptrdiff_t) outStride*y, a.pinned+offOut+sizeof(float)*(size_t) y*ow*no, sizeof(float)*(size_t) ow*no);
+    return MSDFHIP_OK;
+}
+
+int msdfhip_simulate_8bit_host(float *pixels, int w, int h, int rowStride, int channels) {
+    if (w < 0 || h < 0 || channels < 1 || channels > 4)
+        return fail(MSDFHIP_ERR_INVALID, "bad arguments to msdfhip_simulate_8bit_host");
+    if (w == 0 || h == 0)
+        return MSDFHIP_OK;
+    if (!pixels)
+        return fail(MSDFHIP_ERR_INVALID, "NULL bitmap");
+    int rc = ensureDevice();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    const size_t bytes = sizeof(float)*(size_t) w*h*channels;
+    ThreadArena &a = tlsArena;
+    rc = arenaReserve(a, bytes, bytes);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    for (int y = 0; y < h; ++y)
+        memcpy(a.pinned+sizeof(float)*(size_t) y*w*channels, pixels+(ptrdiff_t) rowStride*y, sizeof(float)*(size_t) w*channels);
+    HIPCHK(hipMemcpyAsync(a.dev, a.pinned, bytes, hipMemcpyHostToDevice, a.stream));
+    rc = msdfhip_simulate_8bit(reinterpret_cast<float *>(a.dev), (size_t) w*h*channels, a.stream);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    HIPCHK(hipMemcpyAsync(a.pinned, a.dev, bytes, hipMemcpyDeviceToHost, a.stream));
+    HIPCHK(hipStreamSynchronize(a.stream));
+    for (int y = 0; y < h; ++y)
+        memcpy(pixels+(ptrdiff_t) rowStride*y, a.pinned+sizeof(float)*(size_t) y*w*channels, sizeof(float)*(size_t) w*channels);
+    return MSDFHIP_OK;
+}
+
 int msdfhip_generate(int mode, float *pixels, int w, int h, int rowStride, int flip, const int32_t *co, int nC, const double *points,
                      const uint8_t *types, const uint8_t *colors, const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil) {
     if (mode < 1 || mode > 4)

@@ -83,6 +83,8 @@ _PROTOS = {
     "msdfhip_batch_estimate_sdf_error": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "msdfhip_render_sdf": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_float, _vp]),
     "msdfhip_simulate_8bit": (C.c_int, [_vp, C.c_size_t, _vp]),
+    "msdfhip_render_sdf_host": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_float]),
+    "msdfhip_simulate_8bit_host": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "msdfhip_set_kernel_timing": (C.c_int, [C.c_int]),
     "msdfhip_kernel_timing": (C.c_int, [_dp, _dp, C.POINTER(C.c_int), C.c_int]),
 }

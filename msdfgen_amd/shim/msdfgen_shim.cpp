@@ -1,5 +1,5 @@
 // msdfgen_shim.cpp -- C++ drop-in: msdfgen's OWN generator signatures (msdfgen.h:46-69, core/msdf-error-correction.h:15-18,
-// core/rasterization.h:13-27),
+// core/rasterization.h:13-27, core/render-sdf.h:12-22),
 // implemented on the MI355X through the C ABI of libmsdfgen_hip.so.
 //
 // Build against the user's msdfgen checkout (headers only; this file includes <msdfgen.h>) and link it INSTEAD of the reference's
@@ -192,6 +192,26 @@ void msdfErrorCorrection(const BitmapSection<float, 3> &sdf, const Shape &shape,
 void msdfErrorCorrection(const BitmapSection<float, 4> &sdf, const Shape &shape, const Projection &projection, Range range, const MSDFGeneratorConfig &config) {
     correct<4>(sdf, shape, SDFTransformation(projection, range), config);
 }
+
+// ---- core/render-sdf.h:12-22: together these replace the whole of core/render-sdf.cpp
+namespace {
+template <int NO, int NS>
+void render(const BitmapSection<float, NO> &output, const BitmapConstSection<float, NS> &sdf, Range sdfPxRange, float sdThreshold) {
+    check(msdfhip_render_sdf_host(output.pixels, output.width, output.height, output.rowStride, NO, sdf.pixels, sdf.width, sdf.height, sdf.rowStride, NS,
+                                  sdfPxRange.lower, sdfPxRange.upper, sdThreshold),
+          "renderSDF");
+}
+}
+void renderSDF(const BitmapSection<float, 1> &output, const BitmapConstSection<float, 1> &sdf, Range sdfPxRange, float sdThreshold) { render<1, 1>(output, sdf, sdfPxRange, sdThreshold); }
+void renderSDF(const BitmapSection<float, 3> &output, const BitmapConstSection<float, 1> &sdf, Range sdfPxRange, float sdThreshold) { render<3, 1>(output, sdf, sdfPxRange, sdThreshold); }
+void renderSDF(const BitmapSection<float, 1> &output, const BitmapConstSection<float, 3> &sdf, Range sdfPxRange, float sdThreshold) { render<1, 3>(output, sdf, sdfPxRange, sdThreshold); }
+void renderSDF(const BitmapSection<float, 3> &output, const BitmapConstSection<float, 3> &sdf, Range sdfPxRange, float sdThreshold) { render<3, 3>(output, sdf, sdfPxRange, sdThreshold); }
+void renderSDF(const BitmapSection<float, 1> &output, const BitmapConstSection<float, 4> &sdf, Range sdfPxRange, float sdThreshold) { render<1, 4>(output, sdf, sdfPxRange, sdThreshold); }
+void renderSDF(const BitmapSection<float, 4> &output, const BitmapConstSection<float, 4> &sdf, Range sdfPxRange, float sdThreshold) { render<4, 4>(output, sdf, sdfPxRange, sdThreshold); }
+// (the reference walks N*width*height contiguous floats and ignores rowStride, core/render-sdf.cpp:172-188; rows are honoured here)
+void simulate8bit(const BitmapSection<float, 1> &bitmap) { check(msdfhip_simulate_8bit_host(bitmap.pixels, bitmap.width, bitmap.height, bitmap.rowStride, 1), "simulate8bit"); }
+void simulate8bit(const BitmapSection<float, 3> &bitmap) { check(msdfhip_simulate_8bit_host(bitmap.pixels, bitmap.width, bitmap.height, bitmap.rowStride, 3), "simulate8bit"); }
+void simulate8bit(const BitmapSection<float, 4> &bitmap) { check(msdfhip_simulate_8bit_host(bitmap.pixels, bitmap.width, bitmap.height, bitmap.rowStride, 4), "simulate8bit"); }
 
 // ---- core/rasterization.h:13-27: together these replace the whole of core/rasterization.cpp
 void rasterize(BitmapSection<float, 1> output, const Shape &shape, const Projection &projection, FillRule fillRule) {

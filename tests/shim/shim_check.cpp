@@ -30,7 +30,22 @@ int main(int argc, char **argv) {
     SDFTransformation t(Projection(scale, Vector2(tx, ty)), Range(range));
     const int scanline = argc > 11 ? atoi(argv[11]) : 0;
     try {
-        if (scanline) {
+        if (scanline == 9) {                                                // renderSDF + simulate8bit (core/render-sdf.h) of the generated field
+            std::vector<float> field((size_t) w*h*N);
+            switch (mode) {
+                case 1: generateSDF(BitmapSection<float, 1>(field.data(), w, h, yo), shape, t); break;
+                case 3: generateMSDF(BitmapSection<float, 3>(field.data(), w, h, yo), shape, t); break;
+                default: generateMTSDF(BitmapSection<float, 4>(field.data(), w, h, yo), shape, t); break;
+            }
+            px.assign((size_t) 2*w*2*h, 0.f);                               // 1-channel preview at twice the size
+            BitmapSection<float, 1> preview(px.data(), 2*w, 2*h);
+            switch (mode) {
+                case 1: renderSDF(preview, BitmapConstSection<float, 1>(field.data(), w, h), Range(range), .5f); break;
+                case 3: renderSDF(preview, BitmapConstSection<float, 3>(field.data(), w, h), Range(range), .5f); break;
+                default: renderSDF(preview, BitmapConstSection<float, 4>(field.data(), w, h), Range(range), .5f); break;
+            }
+            simulate8bit(preview);
+        } else if (scanline) {
             const FillRule rule = (FillRule) (scanline-1);
             const Projection proj(scale, Vector2(tx, ty));
             MSDFGeneratorConfig gen(false, ErrorCorrectionConfig(ErrorCorrectionConfig::DISABLED)), post;

@@ -61,3 +61,23 @@ def test_reference_client_scanline_flow_through_cpp_shim(tmp_path, oracle, mode,
             want = oracle.error_correction(s, want, xf, overlap=False, ec_mode=2, ec_dist=0)
     assert np.abs(got.astype(np.float64)-want).max() <= 1e-5
     assert (bits(got) == bits(want)).all()
+
+
+@pytest.mark.parametrize("mode", [1, 3, 4])
+def test_reference_client_render_sdf_through_cpp_shim(tmp_path, oracle, mode):
+    """msdfgen::renderSDF / simulate8bit (core/render-sdf.h:12-22) through the shim: a 2x preview of the generated field."""
+    if not os.path.exists(BIN):
+        pytest.skip("tests/shim/shim_check not built (needs the msdfgen headers)")
+    z = load_npz("shape_a.npz")
+    s = FlatShape(z["contour_offsets"], z["points"], z["types"], z["colors"])
+    desc = tmp_path/"a.txt"
+    desc.write_text(str(z["desc"]))
+    out = tmp_path/"a.bin"
+    w, h = 40, 32
+    scale, tx, ty, rng = 2.75, .625, .71875, 1.5
+    r = subprocess.run([BIN, str(desc), str(out), str(mode), str(w), str(h), repr(scale), repr(tx), repr(ty), repr(rng), "0", "9"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(out, np.float32).reshape(2*h, 2*w, 1)
+    field = oracle.generate(s, mode, w, h, [scale, scale, tx, ty, -.5*rng, .5*rng])
+    want = oracle.simulate_8bit(oracle.render_sdf(field, 2*w, 2*h, 1, -.5*rng, .5*rng, .5))
+    assert (bits(got) == bits(want)).all()
