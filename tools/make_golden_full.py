@@ -1,0 +1,107 @@
+"""Full-size parity pins for BASELINE configs 4 and 5, generated ONCE in the authoring container by the UNMODIFIED reference
+(oracle/_ref/libmsdfgen_ref.so, compiled in place from /root/reference).  The fixtures travel to the GPU box; the `-m gpu` tests
+compare EVERY tile / texel of the device output against them (tests/test_gpu_fullsize.py).
+
+    python tools/make_golden_full.py [--threads N]
+
+  dejavu8192.npz   config 4: the first 8 192 glyphs with outlines of DejaVuSans followed by DejaVuSans-Bold (glyph
+                   order), each after Shape::normalize + edgeColoringSimple(3.0, seed 0) by the reference; flattened CSR arrays,
+                   control-point bounds, and per glyph the sha256 of the reference's msdf 48x48 tile (autoframe, 4 px range,
+                   library-default config = overlapping combiner + EDGE_PRIORITY / CHECK_DISTANCE_AT_EDGE error correction) and of
+                   its msdf 64x64 tile (the bench workload re-frames the same glyphs at 64x64).
+  logo1024.npz     config 5: the 926-edge cubic logo (msdfgen_amd.synth.logo_shape(5)), msdf 1024x1024, 8 px range, default error
+                   correction: sha256 of the texels and of the final stencil, per-row sha256 (to localise a mismatch), the
+                   pre-correction field's sha256, a 64x64 crop of the texels and of the stencil, and the shape itself.
+"""
+import argparse
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from fontshapes import font_glyphs  # noqa: E402
+from msdfgen_amd.shape import FlatShape, ShapeBatch, autoframe  # noqa: E402
+from msdfgen_amd import synth  # noqa: E402
+from oracle.pyoracle import Ref  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def sha_bytes(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def dejavu(ref, threads):
+    names, shapes, bounds = [], [], []
+    for font in ("DejaVuSans.ttf", "DejaVuSans-Bold.ttf"):
+        for name, raw in font_glyphs(font):
+            if len(shapes) >= 8192:
+                break
+            h = ref.shape_from_flat(raw)
+            ref.prepare(h, 3.0, 0)
+            fa = ref.flatten(h)
+            b = ref.bounds(h)
+            ref.free(h)
+            names.append(font[:-4]+":"+name), shapes.append(FlatShape(fa.contour_offsets, fa.points, fa.types, fa.colors)), bounds.append(b)
+    assert len(shapes) == 8192, len(shapes)
+    batch = ShapeBatch.from_shapes(shapes, names)
+    out = {"glyph_contour_offsets": batch.glyph_contour_offsets, "contour_offsets": batch.contour_offsets, "points": batch.points,
+           "types": batch.types.astype(np.uint8), "colors": batch.colors.astype(np.uint8), "names": np.array(names), "bounds": np.stack(bounds)}
+    for size in (48, 64):
+        xfs = np.stack([autoframe(b, size, size, 4) for b in bounds])
+        t0 = time.time()
+        tiles, _ = ref.generate_batch_timed(shapes, 3, size, size, xfs, threads=threads)
+        print("dejavu msdf %dx%d: %.1f s" % (size, size, time.time()-t0), flush=True)
+        out["xf%d" % size] = xfs
+        out["sha%d" % size] = np.stack([sha_bytes(t) for t in tiles])
+        out["sha_all%d" % size] = sha_bytes(tiles)
+        if size == 48:
+            out["sample48"] = tiles[::1024].copy()                      # 8 whole tiles for a readable diff when a hash disagrees
+    np.savez_compressed(os.path.join(GOLDEN, "dejavu8192.npz"), **out)
+    print("dejavu8192: %d glyphs, %d contours, %d edges (%.1f per glyph, max %d), max contours %d" % (
+        batch.n_glyphs, batch.n_contours, batch.n_edges, batch.n_edges/batch.n_glyphs,
+        max(s.n_edges for s in shapes), max(s.n_contours for s in shapes)))
+
+
+def logo(ref):
+    s = synth.logo_shape(5)
+    w = h = 1024
+    xf = autoframe(s.bounds(), w, h, 8)
+    t0 = time.time()
+    pre = ref.generate(s, 3, w, h, xf, ec_mode=0)
+    stencil = np.zeros((h, w), np.uint8)
+    out = ref.generate(s, 3, w, h, xf, stencil=stencil)
+    print("logo msdf 1024x1024: %.1f s (%d edges, %d contours)" % (time.time()-t0, s.n_edges, s.n_contours), flush=True)
+    y0, x0 = 480, 480
+    np.savez_compressed(os.path.join(GOLDEN, "logo1024.npz"), contour_offsets=s.contour_offsets, points=s.points, types=s.types.astype(np.uint8),
+                        colors=s.colors.astype(np.uint8), xf=xf, sha_out=sha_bytes(out), sha_stencil=sha_bytes(stencil), sha_pre=sha_bytes(pre),
+                        sha_rows=np.stack([sha_bytes(out[y]) for y in range(h)]), sha_stencil_rows=np.stack([sha_bytes(stencil[y]) for y in range(h)]),
+                        crop_origin=np.array([y0, x0]), crop_out=out[y0:y0+64, x0:x0+64].copy(), crop_stencil=stencil[y0:y0+64, x0:x0+64].copy(),
+                        n_error=np.array(int((stencil & 1).sum())), n_corrected=np.array(int((out != pre).any(axis=2).sum())))
+    print("logo1024: %d ERROR texels, %d texels changed by the correction" % (int((stencil & 1).sum()), int((out != pre).any(axis=2).sum())))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--threads", type=int, default=len(os.sched_getaffinity(0)))
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    ref = Ref()
+    if args.only in ("", "dejavu"):
+        dejavu(ref, args.threads)
+    if args.only in ("", "logo"):
+        logo(ref)
+    for f in ("dejavu8192.npz", "logo1024.npz"):
+        p = os.path.join(GOLDEN, f)
+        if os.path.exists(p):
+            print("%-16s %8d bytes" % (f, os.path.getsize(p)))
+
+
+if __name__ == "__main__":
+    main()
