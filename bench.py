@@ -4,21 +4,32 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--glyphs G]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (BASELINE.json metric "MSDF glyphs/sec (64x64, fp32)"): the 94 prepared DejaVuSans Basic-Latin glyph shapes
-(tests/golden/latin.npz: after Shape::normalize + edgeColoringSimple, 15.6 edges / 1.41 contours per glyph) tiled to G glyphs per
-GPU, mode msdf, 64x64 tiles, 4 px range, library-default config: overlapSupport = true, error correction EDGE_PRIORITY +
-CHECK_DISTANCE_AT_EDGE (i.e. generateMSDF incl. the msdfErrorCorrection pass).
-A step = one pass of the hot path over one batch: on-device digestion of the HBM-resident edge buffer -> distance-field kernel ->
-error-correction kernel -> G tiles in HBM.  Inputs (flattened edge buffer, per-glyph transforms) are resident in HBM before the
-timed region; outputs stay in HBM.  Scaling is weak: every rank renders its own G glyphs (glyph-sharded, no collective in the data
-path); value = N*G*K / max-over-ranks time.
+`--gpus N` with N > 1 and no torchrun environment re-launches itself under torch.distributed.run with N ranks (one per GPU) and fails
+loudly when fewer than N devices are visible, so `python bench.py --gpus 8` is a complete command.
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel = distance field, HIP-event timed
-inside this process) and `cpu_baseline` (the compiled reference, or the oracle port, timed on the host cores on a bounded sample).
+Workload (BASELINE.json metric "MSDF glyphs/sec (64x64, fp32)"): 8 192 DISTINCT glyphs per GPU -- the first 8 192 glyphs with outlines
+of DejaVuSans followed by DejaVuSans-Bold (tests/golden/dejavu8192.npz: prepared by the reference's Shape::normalize +
+edgeColoringSimple; 23.1 edges and 2.41 contours per glyph, up to 543 edges / 43 contours; SURVEY.md 8d: Roboto / NotoSansCJK are not
+on the box) -- mode msdf, 64x64 tiles, 4 px range, library-default config: overlapSupport = true, error correction EDGE_PRIORITY +
+CHECK_DISTANCE_AT_EDGE (generateMSDF incl. the msdfErrorCorrection pass). Every tile of this workload is pinned bit-for-bit to the
+compiled reference (tests/test_gpu_fullsize.py).
+A step = one pass of the hot path over one batch: on-device digestion of the HBM-resident edge buffer -> distance-field kernels ->
+error-correction kernels -> G tiles in HBM. Inputs (flattened edge buffer, per-glyph transforms) are resident in HBM before the timed
+region; outputs stay in HBM. Scaling is weak: the global list is N rotated copies of the glyph list, cut into N contiguous shards of
+equal cost by msdfgen_amd.shard (rank r renders its own shard; no collective in the data path); value = all glyphs / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline      dominant pass = the distance field (HIP-event timed inside this process, algorithmic bytes per SURVEY.md 8d)
+  end_to_end    host CSR arrays -> H2D -> kernels incl. error correction -> D2H into pinned caller-owned tiles (the reference's contract,
+                core/msdfgen.cpp:52-76), and the same with 8-bit output; measured after the timed steps
+  secondary     the Basic-Latin set (94 shapes tiled to G glyphs): round 1's workload, for continuity
+  cpu_baseline  the compiled reference (or the oracle port) on the host cores, bounded sample
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,17 +42,47 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_GFLOPS = 78600.0  # MI355X fp64 vector peak (FMA = 2 flop); the path has no dense contraction, so no MFMA
 
 
-def load_latin():
+def _batch(z, inverse_y=None):
     from msdfgen_amd.shape import ShapeBatch
+    n = len(z["names"])
+    return ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
+                      z["colors"].astype(np.int32), np.zeros(n, bool) if inverse_y is None else inverse_y, [str(v) for v in z["names"]])
+
+
+def load_latin():
     z = np.load(os.path.join(ROOT, "tests", "golden", "latin.npz"))
-    batch = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
-                       z["colors"].astype(np.int32), z["inverse_y"], [str(n) for n in z["names"]])
-    return batch, z["xf64"]
+    return _batch(z, z["inverse_y"]), z["xf64"]
+
+
+def load_dejavu():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "dejavu8192.npz"))
+    return _batch(z), z["xf64"], z["bounds"]
 
 
 def tile_batch(batch, xfs, n, offset=0):
     idx = [(offset+i) % batch.n_glyphs for i in range(n)]
     return batch.select(idx), xfs[idx]
+
+
+def global_list(batch, xfs, glyphs_per_gpu, world):
+    """The weak-scaling workload of `world` GPUs: world*glyphs_per_gpu glyphs = the glyph list repeated with a rotation per copy (so
+    that equal ranges are not identical ranges). Returned as index list into `batch`."""
+    idx = []
+    for r in range(world):
+        rot = (r*1237) % batch.n_glyphs
+        idx.extend(((rot+i) % batch.n_glyphs) for i in range(glyphs_per_gpu))
+    return np.array(idx)
+
+
+def rank_shard(batch, xfs, glyphs_per_gpu, world, rank, w, h):
+    """(sub-batch, xfs, (lo, hi), bounds) of `rank`: contiguous cut of the global list balanced by W*H*E (msdfgen_amd.shard)."""
+    from msdfgen_amd.shard import partition_contiguous
+    idx = global_list(batch, xfs, glyphs_per_gpu, world)
+    gco, co = batch.glyph_contour_offsets, batch.contour_offsets
+    edges = (co[gco[1:]]-co[gco[:-1]]).astype(np.float64)[idx]
+    bounds = partition_contiguous(float(w*h)*(edges+1.), world)
+    lo, hi = int(bounds[rank]), int(bounds[rank+1])
+    return batch.select(idx[lo:hi]), xfs[idx[lo:hi]], (lo, hi), bounds
 
 
 def algorithmic_bytes(batch, w, h, n):
@@ -82,76 +123,37 @@ def cpu_baseline(batch, xfs, w, h, budget_s=15.):
         impl = Ref() if Ref.available() else Oracle()
     except Exception:  # noqa: BLE001
         impl = Oracle()
-    shapes = batch.shapes()[:94*8]                   # the batch is the 94 Basic-Latin shapes tiled: cycle through a slice of it
+    stride = max(1, batch.n_glyphs//1024)
+    pick = list(range(0, batch.n_glyphs, stride))                    # an evenly spaced sample of the distinct glyphs (same mix of contours / edges)
+    shapes, sx = [batch.shape(g) for g in pick], xfs[pick]
     probe = min(len(shapes), 4*cores)
-    _, secs = impl.generate_batch_timed(shapes[:probe], 3, w, h, xfs[:probe], threads=cores)
+    _, secs = impl.generate_batch_timed(shapes[:probe], 3, w, h, sx[:probe], threads=cores)
     rate = probe/max(secs, 1e-9)
     n = int(min(max(probe, rate*budget_s), 200000))
     idx = [i % len(shapes) for i in range(n)]
-    _, secs = impl.generate_batch_timed([shapes[i] for i in idx], 3, w, h, xfs[idx], threads=cores)
+    _, secs = impl.generate_batch_timed([shapes[i] for i in idx], 3, w, h, sx[idx], threads=cores)
     return {"value": n/secs, "unit": "glyphs/s", "cores": cores, "kind": impl.kind,
-            "sample": "%d glyphs of the same workload (Basic-Latin shapes cycled, msdf %dx%d, default error correction) through %s, "
+            "sample": "%d glyphs of the same workload (every %d-th of the distinct glyphs, cycled; msdf %dx%d, default error correction) through %s, "
                       "glyph-parallel thread pool on %d threads (= the CPUs the container may use: %d hardware threads visible, cgroup quota applied), %.1f s" % (
-                          n, w, h, "the compiled reference (oracle/_ref)" if impl.kind == "reference" else "the plain-C oracle", cores, os.cpu_count() or 0, secs)}
+                          n, stride, w, h, "the compiled reference (oracle/_ref)" if impl.kind == "reference" else "the plain-C oracle", cores, os.cpu_count() or 0, secs)}
 
 
-def pmc_traffic(args, w, h):
-    """HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
-    command (tools/pmc_traffic.py writes profiles/pmc_traffic.json; counters cannot be collected from inside the timed process).
-    None when no profile of this exact workload is committed."""
+def profile_counters(args, w, h):
+    """Counters of the dominant pass from the separate rocprofv3 --pmc passes of this very command (tools/pmc_traffic.py writes
+    profiles/pmc_traffic.json; counters cannot be collected from inside the timed process). Only used when the committed profile is of
+    this exact workload; the entry says at which commit it was measured."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         t = json.load(open(path))
-        if t.get("glyphs_per_gpu") == args.glyphs and t.get("tile") == [w, h]:
-            return t["hbm_bytes_per_launch"]
+        if t.get("glyphs_per_gpu") == args.glyphs and t.get("tile") == [w, h] and t.get("workload") == "dejavu8192":
+            return t
     except (OSError, ValueError, KeyError):
         pass
     return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--glyphs", type=int, default=8192, help="glyph tiles per GPU per step")
-    ap.add_argument("--size", type=int, default=64)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--simple-combiner", action="store_true", help="experiment: overlapSupport=false (NOT the headline config)")
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    import msdfgen_amd as M
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: msdfgen_amd has no CPU compute path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
-    M.init(local_rank)
-
-    w = h = args.size
-    latin, xf64 = load_latin()
-    if w != 64:
-        from msdfgen_amd.shape import autoframe
-        bounds = np.load(os.path.join(ROOT, "tests", "golden", "latin.npz"))["bounds"]
-        xf64 = np.stack([autoframe(b, w, h, 4) for b in bounds])
-    # weak scaling: rank r renders its own G glyphs (the global list is rank-major; a static contiguous split gives every rank G)
-    batch, xfs = tile_batch(latin, xf64, args.glyphs, offset=rank*args.glyphs)
-    gb = M.GlyphBatch(batch, dev)
-    desc = gb.descriptors(xfs, w, h, 3)
-    out = torch.empty((batch.n_glyphs, h, w, 3), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream(dev)
-
-    cfg = M.MSDFGeneratorConfig(overlap_support=not args.simple_combiner)
+def timed_steps(M, torch, dist, lib, gb, desc, out, cfg, w, h, steps, warmup, world, dev, stream):
+    import ctypes as C
 
     def step():
         gb.digest(stream)
@@ -163,21 +165,153 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    lib = M.load()
     fence()
     lib.msdfhip_set_kernel_timing(1)
     lib.msdfhip_kernel_timing(None, None, None, 1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     elapsed = time.perf_counter()-t0
     lib.msdfhip_set_kernel_timing(0)
-    import ctypes as C
     kd, kc, kn = C.c_double(), C.c_double(), C.c_int()
     lib.msdfhip_kernel_timing(C.byref(kd), C.byref(kc), C.byref(kn), 1)
+    return elapsed, kd.value, kc.value, kn.value
+
+
+def end_to_end(M, batch, xfs, w, h, reps=3):
+    """The reference's contract (caller-owned host bitmaps): HOST CSR arrays -> msdfhip_batch_create (H2D + digestion) ->
+    msdfhip_batch_generate_host (chunked two-stream pipeline: kernels incl. error correction overlapped with the D2H of the previous
+    chunk) into PINNED host tiles; and the 8-bit atlas variant (float tiles stay on the device, 1/4 of the D2H bytes)."""
+    n = batch.n_glyphs
+    tiles = M.host_alloc((n, h, w, 3))
+    cols = 128
+    rows = (n+cols-1)//cols
+    atlas = M.host_alloc((rows*h, cols*w, 3), np.uint8)
+    offs = np.array([((g//cols)*h*cols*w+(g % cols)*w)*3 for g in range(n)], np.int64)
+    res = {}
+    t_create, t_float, t_bytes = [], [], []
+    for rep in range(reps+1):
+        t0 = time.perf_counter()
+        hb = M.HostBatch(batch)
+        t1 = time.perf_counter()
+        hb.generate_host(M.MODE_MSDF, w, h, xfs, out=tiles)
+        t2 = time.perf_counter()
+        hb.generate_bytes_host(M.MODE_MSDF, w, h, xfs, atlas, offs, cols*w*3)
+        t3 = time.perf_counter()
+        hb.close()
+        if rep:                                                      # the first round pays one-time allocations
+            t_create.append(t1-t0), t_float.append(t2-t1), t_bytes.append(t3-t2)
+    c, f, b = float(np.median(t_create)), float(np.median(t_float)), float(np.median(t_bytes))
+    h2d = 72*batch.n_edges+4*(batch.n_contours+batch.n_glyphs+2)+64*n
+    res["float_tiles"] = {"glyphs_per_s": n/(c+f), "glyphs_per_s_excluding_upload": n/f, "ms_upload_and_digest": 1e3*c, "ms_generate_and_copy_back": 1e3*f,
+                          "h2d_bytes": h2d, "d2h_bytes": int(tiles.nbytes), "d2h_gb_per_s_incl_kernels": tiles.nbytes/f/1e9}
+    res["uint8_atlas"] = {"glyphs_per_s": n/(c+b), "glyphs_per_s_excluding_upload": n/b, "ms_generate_convert_and_copy_back": 1e3*b,
+                          "h2d_bytes": h2d, "d2h_bytes": int(atlas.nbytes), "atlas": [int(atlas.shape[1]), int(atlas.shape[0])]}
+    res["note"] = ("host CSR arrays in pageable memory, outputs in pinned memory (msdfhip_host_alloc), %d glyphs, median of %d runs; chunks of the glyph "
+                   "list alternate between two streams so that kernels overlap the copy back" % (n, reps))
+    M.host_free(tiles)
+    M.host_free(atlas)
+    return res
+
+
+def spawn(args):
+    """`python bench.py --gpus N` outside torchrun: re-launch under torch.distributed.run, one rank per GPU."""
+    if not args.mock:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)]+sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def mock_rank(args, rank, world):
+    """CPU-only rehearsal of the N > 1 control path (tests): gloo ranks, the real shard computation, barrier + max-reduce, rank 0 prints."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    batch, xfs, _ = load_dejavu()
+    sub, sx, (lo, hi), bounds = rank_shard(batch, xfs, args.glyphs, world, rank, args.size, args.size)
+    t = torch.tensor([float(sub.n_edges), float(hi-lo)], dtype=torch.float64)
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    if world > 1:
+        dist.barrier()
+        dist.all_gather(parts, t)
+    else:
+        parts = [t]
+    if rank == 0:
+        print(json.dumps({"mock": True, "n_gpus": world, "bounds": [int(v) for v in bounds], "glyphs_per_rank": [int(p[1]) for p in parts],
+                          "edges_per_rank": [int(p[0]) for p in parts]}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--glyphs", type=int, default=8192, help="glyph tiles per GPU per step")
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / secondary / quality (profiling runs)")
+    ap.add_argument("--simple-combiner", action="store_true", help="experiment: overlapSupport=false (NOT the headline config)")
+    ap.add_argument("--mock", action="store_true", help="CPU rehearsal of the multi-rank control path (gloo, no kernels); used by the tests")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn(args)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%d" % (args.gpus, world))
+    if args.mock:
+        return mock_rank(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+    import msdfgen_amd as M
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: msdfgen_amd has no CPU compute path")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (only %d visible)" % (local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+    M.init(local_rank)
+    lib = M.load()
+
+    w = h = args.size
+    dejavu, xf64, bounds = load_dejavu()
+    if w != 64:
+        from msdfgen_amd.shape import autoframe
+        xf64 = np.stack([autoframe(b, w, h, 4) for b in bounds])
+    batch, xfs, (lo, hi), shard_bounds = rank_shard(dejavu, xf64, args.glyphs, world, rank, w, h)
+    gb = M.GlyphBatch(batch, dev)
+    desc = gb.descriptors(xfs, w, h, 3)
+    out = torch.empty((batch.n_glyphs, h, w, 3), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    cfg = M.MSDFGeneratorConfig(overlap_support=not args.simple_combiner)
+
+    elapsed, dist_ms, ec_ms, launches = timed_steps(M, torch, dist, lib, gb, desc, out, cfg, w, h, args.steps, args.warmup, world, dev, stream)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -186,29 +320,54 @@ def main():
     if rank == 0:
         total_glyphs = world*args.glyphs*args.steps
         ab = algorithmic_bytes(batch, w, h, 3)
-        dist_ms = kd.value
         achieved = ab/(dist_ms*1e-3)/1e9 if dist_ms > 0 else 0.
         gflops = algorithmic_flops(batch, w, h)/(dist_ms*1e-3)/1e9 if dist_ms > 0 else 0.
+        prof = profile_counters(args, w, h)
         res = {
             "metric": "MSDF glyphs/sec (64x64, fp32)", "value": total_glyphs/elapsed, "unit": "glyphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3*elapsed/args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "msdf %dx%d tiles, %d glyphs per GPU per step = DejaVuSans Basic-Latin (94 prepared shapes, 15.6 edges/glyph) tiled; "
+            "config": {"workload": "msdf %dx%d tiles, %d DISTINCT glyphs per GPU per step = the first 8192 glyphs with outlines of DejaVuSans + DejaVuSans-Bold "
+                                   "(%.1f edges, %.2f contours per glyph; tests/golden/dejavu8192.npz, every tile pinned to the compiled reference); "
                                    "overlapSupport=true, error correction EDGE_PRIORITY+CHECK_DISTANCE_AT_EDGE (library defaults); "
-                                   "step = digest + distance field + error correction, inputs/outputs resident in HBM" % (w, h, args.glyphs),
-                       "glyphs_per_gpu": args.glyphs, "tile": [w, h], "mode": "msdf", "parallelism": "glyph-sharded x%d, no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_distance<3,true,false> (msdf, overlapping combiner)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved/HBM_PEAK_GBS, "traffic": pmc_traffic(args, w, h),
-                         "algorithmic_bytes_per_launch": ab, "avg_launch_ms": dist_ms, "launches_timed": kn.value,
-                         "note": "arithmetic intensity ~400 fp64 flop/B: the kernel is fp64-VALU bound, not HBM bound (SURVEY.md 8d); "
+                                   "step = digest + distance field + error correction, inputs/outputs resident in HBM" % (
+                                       w, h, args.glyphs, batch.n_edges/batch.n_glyphs, batch.n_contours/batch.n_glyphs),
+                       "glyphs_per_gpu": args.glyphs, "tile": [w, h], "mode": "msdf",
+                       "parallelism": "glyph-sharded x%d by W*H*E (msdfgen_amd.shard), no collective; rank 0 owns glyphs [%d, %d) of %d" % (world, lo, hi, world*args.glyphs)},
+            "roofline": {"bound": "hbm", "kernel": "k_distance<3,...> distance pass (msdf; three launches: 1-contour glyphs / combiner scratch in LDS / in the global workspace)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS,
+                         "traffic": prof["hbm_bytes_per_launch"] if prof else None,
+                         "traffic_source": ("profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, measured at commit %s "
+                                            "(not collected in this run)" % prof.get("commit", "?")) if prof else None,
+                         "algorithmic_bytes_per_launch": ab, "avg_launch_ms": dist_ms, "launches_timed": launches,
+                         "note": "arithmetic intensity ~400 fp64 flop/B: the pass is fp64-VALU bound, not HBM bound (SURVEY.md 8d); "
                                  "the HBM fraction is reported as the contract asks, the binding resource is in `valu_fp64`"},
-            "valu_fp64": {"achieved": gflops, "peak": FP64_VECTOR_PEAK_GFLOPS, "unit": "GFLOP/s (algorithmic estimate, SURVEY.md 8d)", "frac": gflops/FP64_VECTOR_PEAK_GFLOPS},
-            "kernel_ms": {"distance": dist_ms, "error_correction": kc.value},
+            "valu_fp64": {"achieved": gflops, "peak": FP64_VECTOR_PEAK_GFLOPS, "unit": "GFLOP/s (algorithmic estimate, SURVEY.md 8d)", "frac": gflops/FP64_VECTOR_PEAK_GFLOPS,
+                          "valu_issue_frac_pmc": prof.get("valu_issue_frac") if prof else None,
+                          "valu_issue_frac_pmc_note": prof.get("valu_issue_note") if prof else None},
+            "kernel_ms": {"distance": dist_ms, "error_correction": ec_ms},
         }
-        # outside the timed region: the reference-defined quality of what was just rendered (estimateSDFError, core/sdf-error-estimation.h)
-        err = gb.estimate_sdf_error(out, xfs)
-        res["quality"] = {"metric": "estimateSDFError of the rendered tiles (1 scanline per row, non-zero fill), evaluated on the device",
-                          "mean": float(err.mean()), "max": float(err.max())}
+        if not args.no_extras:
+            # outside the timed region: the reference-defined quality of what was just rendered (estimateSDFError, core/sdf-error-estimation.h)
+            err = gb.estimate_sdf_error(out, xfs)
+            res["quality"] = {"metric": "estimateSDFError of the rendered tiles (1 scanline per row, non-zero fill), evaluated on the device",
+                              "mean": float(err.mean()), "max": float(err.max())}
+    gb.close()
+    del out
+    if rank == 0 and world == 1 and not args.no_extras:
+        res["end_to_end"] = end_to_end(M, batch, xfs, w, h)
+        latin, lxf = load_latin()
+        if w != 64:
+            from msdfgen_amd.shape import autoframe
+            lxf = np.stack([autoframe(b, w, h, 4) for b in np.load(os.path.join(ROOT, "tests", "golden", "latin.npz"))["bounds"]])
+        lb, lx = tile_batch(latin, lxf, args.glyphs)
+        g2 = M.GlyphBatch(lb, dev)
+        o2 = torch.empty((lb.n_glyphs, h, w, 3), dtype=torch.float32, device=dev)
+        e2, d2, c2, _ = timed_steps(M, torch, dist, lib, g2, g2.descriptors(lx, w, h, 3), o2, cfg, w, h, max(5, args.steps//3), 2, 1, dev, stream)
+        res["secondary"] = {"workload": "round 1's bench workload: DejaVuSans Basic-Latin (94 prepared shapes, 15.6 edges / 1.41 contours per glyph) tiled to %d glyphs" % args.glyphs,
+                            "glyphs_per_s": args.glyphs*max(5, args.steps//3)/e2, "kernel_ms": {"distance": d2, "error_correction": c2}}
+        g2.close()
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(batch, xfs, w, h)
         print(json.dumps(res))

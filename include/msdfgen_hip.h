@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MSDFHIP_ABI_VERSION 3
+#define MSDFHIP_ABI_VERSION 4
 
 /* mode: which generator (msdfgen.h:46-56) */
 #define MSDFHIP_MODE_SDF   1 /* generateSDF   msdfgen.h:47  (TrueDistanceSelector)          1 channel  */
@@ -76,7 +76,11 @@ typedef struct MsdfHipConfig {
     int32_t sign_correction;     /* 0 / 1 */
     int32_t fill_rule;           /* FillRule, core/Scanline.h:10-15: 0 NONZERO (default), 1 ODD, 2 POSITIVE, 3 NEGATIVE */
     float sdf_zero_value;        /* default 0.5 */
-    int32_t reserved;
+    int32_t stencil_y_down;      /* 1: the output bitmap's yOrientation is Y_DOWNWARD. Only the row order of the optional stencil
+                                    (ErrorCorrectionConfig::buffer) depends on it: the reference creates the stencil section with the
+                                    default orientation (core/msdf-error-correction.cpp:19) and re-orients it against the bitmap
+                                    (core/MSDFErrorCorrection.cpp:122,192,415), so its memory row r is always the r-th row counted
+                                    upwards -- the bitmap's memory row height-1-r when the bitmap is Y_DOWNWARD. Default 0. */
 } MsdfHipConfig;
 
 /* Per-glyph descriptor of a batch (one output tile per glyph). Lives in device memory for the *_device entry points. */
@@ -91,8 +95,11 @@ typedef struct MsdfHipGlyph {
 void msdfhip_default_config(MsdfHipConfig *cfg);
 
 int msdfhip_abi_version(void);
-/* Binds the calling thread (and by default the process) to HIP device `device`; checks that it is gfx950. */
+/* Makes HIP device `device` the process default (checks that it is gfx950): the device of the single-shape calls and of batches
+ * created without an explicit device. Batches remember their device; every call on a batch binds the calling thread to it, so one
+ * process can drive all GPUs of a node (msdfhip_batch_create_on, msdfhip_generate_sharded below). */
 int msdfhip_init(int device);
+int msdfhip_device_count(int *count);
 /* Text of the last error on the calling thread ("" if none). */
 const char *msdfhip_last_error(void);
 /* name buffer receives e.g. "gfx950:sramecc+:xnack-"; cus/lds_bytes may be NULL. */
@@ -172,6 +179,10 @@ typedef struct MsdfHipBatch MsdfHipBatch; /* opaque */
  *   glyph_contour_offsets int32[n_glyphs+1], contour_offsets int32[n_contours+1], points double[n_edges*8], types/colors uint8[n_edges]. */
 int msdfhip_batch_create(MsdfHipBatch **batch, int n_glyphs, const int32_t *glyph_contour_offsets, const int32_t *contour_offsets,
                          const double *points, const uint8_t *types, const uint8_t *colors);
+/* Same, on an explicit device (-1 = the process default). One host thread per device may create and run its own batch concurrently. */
+int msdfhip_batch_create_on(MsdfHipBatch **batch, int device, int n_glyphs, const int32_t *glyph_contour_offsets, const int32_t *contour_offsets,
+                            const double *points, const uint8_t *types, const uint8_t *colors);
+int msdfhip_batch_device(const MsdfHipBatch *batch, int *device);
 /* Same, from DEVICE arrays that already live in HBM (e.g. torch tensors); they must stay valid until the batch is destroyed.
  * max_contours_per_glyph / max_edges_per_glyph are host-known upper bounds used to size LDS. `stream` is a hipStream_t (or NULL). */
 int msdfhip_batch_create_device(MsdfHipBatch **batch, int n_glyphs, int n_contours, int n_edges, int max_contours_per_glyph, int max_edges_per_glyph,
@@ -193,9 +204,36 @@ int msdfhip_batch_windings(const MsdfHipBatch *batch, int32_t *windings);
  * stream at a time. Different batches, and the single-shape entry points above, are independent of each other. */
 int msdfhip_batch_generate(const MsdfHipBatch *batch, int mode, int width, int height, const MsdfHipGlyph *d_glyphs,
                            float *d_out, uint8_t *d_stencil, float *d_scratch, const MsdfHipConfig *cfg, void *stream);
-/* Convenience: same but with HOST descriptors and HOST output (tiles copied back; synchronous). */
+/* End to end into HOST memory (what replaces an atlas generator's loop of generate*() calls into caller-owned bitmaps,
+ * core/msdfgen.cpp:52-76, README.md:133): HOST descriptors, HOST output. The glyph list is processed in chunks on two streams, so the
+ * kernels of one chunk overlap the device-to-host copy of the previous one; synchronous for the caller.
+ *   glyphs[g].out_offset / row_stride place tile g in `out` (floats). When the tiles are packed in glyph order (out_offset = g*w*h*N,
+ *   row_stride = w*N) every chunk is one contiguous copy; any other placement (rectangles of a larger atlas, negative strides) goes
+ *   through a device mirror of the whole buffer (uploaded first so that texels outside the rectangles survive, copied back once).
+ *   stencil: NULL or n_glyphs*width*height bytes; written only when an error-correction pass runs (like the reference's buffer).
+ * For full copy speed `out` should be pinned (msdfhip_host_alloc); pageable memory works, the runtime then stages the copies. */
 int msdfhip_batch_generate_host(const MsdfHipBatch *batch, int mode, int width, int height, const MsdfHipGlyph *glyphs,
                                 float *out, size_t out_floats, uint8_t *stencil, const MsdfHipConfig *cfg);
+/* Same pipeline with 8-bit output: every chunk's float tiles stay on the device, are converted with pixelFloatToByte
+ * (core/pixel-conversion.hpp:8-10) and blitted into the caller's uint8 atlas; glyphs[g].out_offset / row_stride are in BYTES of
+ * `atlas`. The copy back is a quarter of the float tiles'. */
+int msdfhip_batch_generate_bytes_host(const MsdfHipBatch *batch, int mode, int width, int height, const MsdfHipGlyph *glyphs,
+                                      uint8_t *atlas, size_t atlas_bytes, const MsdfHipConfig *cfg);
+/* Glyphs per pipeline chunk (0 = automatic: about 48 MB of float tiles). */
+int msdfhip_set_pipeline_chunk(int glyphs_per_chunk);
+/* Pinned (page-locked, portable across devices) host memory for outputs of the two functions above. */
+int msdfhip_host_alloc(void **p, size_t bytes);
+int msdfhip_host_free(void *p);
+
+/* Glyph-sharded generation on several devices of one node: the glyph list (HOST CSR arrays as for
+ * msdfhip_batch_create) is cut into n_devices contiguous ranges balanced by edge count; one host thread per entry of `devices`
+ * uploads its range, runs the pipeline above on that device and copies its tiles straight into the caller's buffer. No exchange
+ * between devices; the bytes do not depend on the split (a device may be listed more than once). Exactly one of `out` (float tiles,
+ * offsets in floats) and `atlas` (8-bit, offsets in bytes) is non-NULL. */
+int msdfhip_generate_sharded(const int *devices, int n_devices, int mode, int width, int height, int n_glyphs,
+                             const int32_t *glyph_contour_offsets, const int32_t *contour_offsets, const double *points, const uint8_t *types,
+                             const uint8_t *colors, const MsdfHipGlyph *glyphs, float *out, size_t out_floats, uint8_t *atlas, size_t atlas_bytes,
+                             const MsdfHipConfig *cfg);
 
 /* Shape preparation on the device: what callers run on every glyph before the generators.
  *   normalize  Shape::normalize (core/Shape.cpp:65-92): single-edge contours split in thirds, convergent edges pushed apart

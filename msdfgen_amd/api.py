@@ -147,6 +147,7 @@ def _generate(mode, output, shape, transformation, config, y_orientation):
     xf = transformation.xf6()
     cfg = _c_config(config)
     flip = int(bool(shape.inverse_y) != (y_orientation == Y_DOWNWARD))  # shape.getYAxisOrientation() != output.yOrientation
+    cfg.stencil_y_down = int(y_orientation == Y_DOWNWARD)
     stencil = None
     ec = getattr(config, "error_correction", None)
     if ec is not None and ec.buffer is not None:
@@ -189,7 +190,10 @@ def msdf_error_correction(sdf, shape, transformation, config: Optional[MSDFGener
     xf = transformation.xf6()
     cfg = _c_config(config)
     flip = int(bool(shape.inverse_y) != (y_orientation == Y_DOWNWARD))
+    cfg.stencil_y_down = int(y_orientation == Y_DOWNWARD)
     stencil = config.error_correction.buffer
+    if stencil is not None and (stencil.dtype != np.uint8 or stencil.size < w*h or not stencil.flags.c_contiguous):
+        raise ValueError("error_correction.buffer must be C-contiguous uint8 with at least width*height bytes")
     _lib.check(lib.msdfhip_error_correction(n, px, w, h, stride, flip, *sargs, _lib.ptr(xf, _lib._dp), C.byref(cfg),
                                             _lib.ptr(stencil, _lib._bp) if stencil is not None else None))
     del keep
@@ -453,3 +457,123 @@ class GlyphBatch:
         _lib.check(_lib.load().msdfhip_batch_generate(self._handle, mode, width, height, descriptors.data_ptr(), out.data_ptr(),
                                                       stencil.data_ptr() if stencil is not None else None, scratch_ptr, C.byref(cfg), s))
         return out
+
+
+# ------------------------------------------------------------------------------------------------- end to end, host memory
+
+
+def host_alloc(shape, dtype=np.float32):
+    """Pinned (page-locked) host array for the outputs of generate_host / generate_bytes_host / generate_sharded
+    (msdfhip_host_alloc): device-to-host copies into it run at full PCIe speed and truly asynchronously."""
+    n = int(np.prod(shape))*np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    _lib.check(_lib.load().msdfhip_host_alloc(C.byref(p), n))
+    buf = (C.c_char*max(n, 1)).from_address(p.value)
+    a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    _PINNED[a.__array_interface__["data"][0]] = p.value
+    return a
+
+
+_PINNED = {}
+
+
+def host_free(a):
+    p = _PINNED.pop(a.__array_interface__["data"][0], None)
+    if p is not None:
+        _lib.check(_lib.load().msdfhip_host_free(p))
+
+
+def _descriptors_host(shapes: ShapeBatch, xfs, out_offsets, row_stride, y_orientation=Y_UPWARD):
+    xfs = np.ascontiguousarray(xfs, np.float64).reshape(shapes.n_glyphs, 6)
+    d = np.zeros(shapes.n_glyphs, _lib.GLYPH_DTYPE)
+    d["xf"][:, :4] = xfs[:, :4]
+    d["xf"][:, 4] = np.float64(1)/(xfs[:, 5]-xfs[:, 4])  # DistanceMapping.cpp:13
+    d["xf"][:, 5] = -xfs[:, 4]
+    d["out_offset"] = np.asarray(out_offsets, np.int64)
+    d["row_stride"] = row_stride
+    d["flip"] = (np.asarray(shapes.inverse_y).astype(bool) != (y_orientation == Y_DOWNWARD)).astype(np.int32)
+    return d
+
+
+class HostBatch:
+    """The batch API without torch: shapes uploaded from host arrays (msdfhip_batch_create_on), tiles delivered into host memory
+    by the chunked two-stream pipeline (msdfhip_batch_generate_host / _bytes_host). This is the end-to-end path of SURVEY.md 8(d):
+    host flatten -> H2D -> kernels incl. error correction -> D2H into caller-owned bitmaps."""
+
+    def __init__(self, shapes: ShapeBatch, device=-1):
+        self.shapes = shapes
+        self.n_glyphs = shapes.n_glyphs
+        gco = np.ascontiguousarray(shapes.glyph_contour_offsets, np.int32)
+        co = np.ascontiguousarray(shapes.contour_offsets, np.int32)
+        pts = np.ascontiguousarray(shapes.points, np.float64).reshape(-1, 8)
+        types = np.ascontiguousarray(shapes.types, np.uint8)
+        colors = np.ascontiguousarray(shapes.colors, np.uint8)
+        self._handle = C.c_void_p()
+        _lib.check(_lib.load().msdfhip_batch_create_on(C.byref(self._handle), int(device), shapes.n_glyphs, _lib.ptr(gco, _lib._ip), _lib.ptr(co, _lib._ip),
+                                                       _lib.ptr(pts, _lib._dp), _lib.ptr(types, _lib._bp), _lib.ptr(colors, _lib._bp)))
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            _lib.load().msdfhip_batch_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device(self):
+        d = C.c_int()
+        _lib.check(_lib.load().msdfhip_batch_device(self._handle, C.byref(d)))
+        return d.value
+
+    def generate_host(self, mode, width, height, xfs, out=None, config=None, stencil=None, out_offsets=None, row_stride=None, y_orientation=Y_UPWARD):
+        """Float tiles into `out` (host float32; default: a fresh packed (G, height, width, N) array). out_offsets / row_stride (floats)
+        place the tiles elsewhere, e.g. as rectangles of one atlas bitmap (BitmapSection semantics)."""
+        n = CHANNELS[mode]
+        tile = width*height*n
+        if out is None:
+            out = np.zeros((self.n_glyphs, height, width, n), np.float32)
+        assert out.dtype == np.float32 and out.flags.c_contiguous
+        d = _descriptors_host(self.shapes, xfs, np.arange(self.n_glyphs, dtype=np.int64)*tile if out_offsets is None else out_offsets,
+                              width*n if row_stride is None else row_stride, y_orientation)
+        cfg = _c_config(config if config is not None else (MSDFGeneratorConfig() if mode >= 3 else GeneratorConfig()))
+        if stencil is not None:
+            assert stencil.dtype == np.uint8 and stencil.flags.c_contiguous and stencil.size >= self.n_glyphs*width*height
+        _lib.check(_lib.load().msdfhip_batch_generate_host(self._handle, mode, width, height, d.ctypes.data, out.ctypes.data, out.size,
+                                                           stencil.ctypes.data if stencil is not None else None, C.byref(cfg)))
+        return out
+
+    def generate_bytes_host(self, mode, width, height, xfs, atlas, out_offsets, row_stride, config=None, y_orientation=Y_UPWARD):
+        """8-bit output (pixelFloatToByte, core/pixel-conversion.hpp:8-10) blitted into the host uint8 `atlas`; offsets / stride in bytes."""
+        assert atlas.dtype == np.uint8 and atlas.flags.c_contiguous
+        d = _descriptors_host(self.shapes, xfs, out_offsets, row_stride, y_orientation)
+        cfg = _c_config(config if config is not None else (MSDFGeneratorConfig() if mode >= 3 else GeneratorConfig()))
+        _lib.check(_lib.load().msdfhip_batch_generate_bytes_host(self._handle, mode, width, height, d.ctypes.data, atlas.ctypes.data, atlas.size, C.byref(cfg)))
+        return atlas
+
+
+def generate_sharded(devices, shapes: ShapeBatch, mode, width, height, xfs, out=None, atlas=None, out_offsets=None, row_stride=None, config=None,
+                     y_orientation=Y_UPWARD):
+    """msdfhip_generate_sharded: the glyph list split over `devices` (one host thread + streams per entry, no exchange between devices),
+    every device writing its tiles into the caller's `out` (float32) or `atlas` (uint8)."""
+    n = CHANNELS[mode]
+    tile = width*height*n
+    if out is None and atlas is None:
+        out = np.zeros((shapes.n_glyphs, height, width, n), np.float32)
+    d = _descriptors_host(shapes, xfs, np.arange(shapes.n_glyphs, dtype=np.int64)*tile if out_offsets is None else out_offsets,
+                          width*n if row_stride is None else row_stride, y_orientation)
+    cfg = _c_config(config if config is not None else (MSDFGeneratorConfig() if mode >= 3 else GeneratorConfig()))
+    gco = np.ascontiguousarray(shapes.glyph_contour_offsets, np.int32)
+    co = np.ascontiguousarray(shapes.contour_offsets, np.int32)
+    pts = np.ascontiguousarray(shapes.points, np.float64).reshape(-1, 8)
+    types = np.ascontiguousarray(shapes.types, np.uint8)
+    colors = np.ascontiguousarray(shapes.colors, np.uint8)
+    devs = (C.c_int*len(devices))(*[int(v) for v in devices])
+    _lib.check(_lib.load().msdfhip_generate_sharded(devs, len(devices), mode, width, height, shapes.n_glyphs, _lib.ptr(gco, _lib._ip), _lib.ptr(co, _lib._ip),
+                                                    _lib.ptr(pts, _lib._dp), _lib.ptr(types, _lib._bp), _lib.ptr(colors, _lib._bp), d.ctypes.data,
+                                                    out.ctypes.data if out is not None else None, out.size if out is not None else 0,
+                                                    atlas.ctypes.data if atlas is not None else None, atlas.size if atlas is not None else 0, C.byref(cfg)))
+    return out if out is not None else atlas

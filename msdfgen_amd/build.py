@@ -17,7 +17,12 @@ LIB = os.path.join(LIBDIR, "libmsdfgen_hip.so")
 SHIM = os.path.join(LIBDIR, "libmsdfgen_hip_shim.so")
 
 # -ffp-contract=off: the reference is compiled without FMA contraction (x86-64 baseline); parity needs the same on gfx950.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-value"]
+# -disable-machine-licm: gfx950 has no 64-bit literal operands, so every fp64 constant (the polynomial coefficients of acos / cos /
+#   cbrt in the quadratic solver: ~45 of them) is materialised with two moves; MachineLICM hoists all of those out of the per-edge
+#   loop and pins ~90 VGPRs for the whole kernel (k_distance<msdf>: 177 -> 95 VGPRs without it, i.e. 2 -> 5 wavefronts per SIMD
+#   and no scratch spills in the overlapping-combiner instantiation). Re-materialising them next to their use is mostly SALU work.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-fPIC", "-shared", "-Wall",
+               "-Wno-unused-value"]
 
 
 def hipcc():

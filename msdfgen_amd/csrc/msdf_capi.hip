@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "msdf_kernels.hpp"
@@ -40,17 +41,32 @@ int fail(int code, const char *fmt, ...) {
 
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(MSDFHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
-int ensureDevice() {
-    int dev = gDevice.load();
-    if (dev < 0) {
+// Binds the calling thread to `dev` (>= 0: the device a batch lives on) or to the process default (msdfhip_init; device 0 if never called).
+int ensureDevice(int dev = -1) {
+    if (gDevice.load() < 0) {
         int rc = msdfhip_init(0);
         if (rc != MSDFHIP_OK)
             return rc;
-        dev = gDevice.load();
     }
+    if (dev < 0)
+        dev = gDevice.load();
     if (hipSetDevice(dev) != hipSuccess)
         return fail(MSDFHIP_ERR_NO_DEVICE, "hipSetDevice(%d) failed", dev);
     return MSDFHIP_OK;
+}
+
+// For the entry points that only receive device pointers: bind to the device that owns `p`.
+int ensureDeviceOf(const void *p) {
+    hipPointerAttribute_t attr;
+    if (p && hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeDevice)
+        return ensureDevice(attr.device);
+    (void) hipGetLastError();
+    return ensureDevice();
+}
+
+int currentDevice() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess ? dev : 0;
 }
 
 int channelsOf(int mode) { return mode <= 2 ? 1 : mode; }
@@ -81,7 +97,10 @@ struct ScopedTimer {
 
 } // namespace
 
+struct PipeSlot;
+
 struct MsdfHipBatch {
+    int device;                       // the HIP device the batch lives on; every call on the batch binds the calling thread to it
     int nGlyphs, nContours, nEdges, maxContours, maxEdges;
     bool ownsInputs;
     int32_t *dGlyphContourOffsets, *dContourOffsets;
@@ -98,10 +117,20 @@ struct MsdfHipBatch {
     mutable size_t deferredCap;
     mutable std::mutex scratchMutex;
     mutable std::vector<int> hContours; // contours per glyph (host copy, fetched on first need)
+    mutable std::vector<int> hEdges;    // edges per glyph (host copy, fetched with hContours)
     mutable int bucketLimit;          // the contour limit dBucket was built for (-1 = none)
-    mutable int *dBucket;             // [nSmall glyph indices with <= bucketLimit contours][the others]
-    mutable int nSmall, smallMaxC;
+    mutable int *dBucket;             // glyph indices: [nOne with <= 1 contour][nSmall with 2..bucketLimit contours][the others]
+    mutable int nOne, nSmall, smallMaxC, smallMaxE, oneMaxE;
+    int glyphCap;                     // per-glyph work buffers are sized for max(nGlyphs, glyphCap) glyphs (views of the host-output pipeline)
+    mutable PipeSlot *pipe;           // the two slots of the host-output pipeline (msdfhip_batch_generate_host / _bytes_host), lazily created
+    mutable std::mutex pipeMutex;     // one host-output call at a time per batch
+    MsdfHipBatch() : device(0), nGlyphs(0), nContours(0), nEdges(0), maxContours(0), maxEdges(0), ownsInputs(false), dGlyphContourOffsets(NULL),
+                     dContourOffsets(NULL), dPoints(NULL), dTypes(NULL), dColors(NULL), dRecs(NULL), dWindings(NULL), dScratch(NULL), scratchFloats(0),
+                     dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), deferredCap(0), bucketLimit(-1), dBucket(NULL), nOne(0), nSmall(0),
+                     smallMaxC(0), smallMaxE(0), oneMaxE(0), glyphCap(0), pipe(NULL) { }
 };
+
+static void destroyPipe(const MsdfHipBatch *b);
 
 namespace {
 
@@ -128,31 +157,40 @@ int digest(MsdfHipBatch *b, hipStream_t stream) {
     return MSDFHIP_OK;
 }
 
-// LDS plan for a launch: bytes of dynamic LDS and whether the records are staged in LDS or read from global memory.
-struct LdsPlan { size_t bytes; bool globalRes; size_t resBytes, ldsBudget, idxBytes; };
+// LDS plan for a launch: bytes of dynamic LDS, the stride of the per-tile survivor lists, and where the combiner scratch lives.
+struct LdsPlan { size_t bytes; bool globalRes; size_t resBytes, ldsBudget, idxBytes; int listStride; };
 const size_t GRES_WORKSPACE_CAP = (size_t) 1<<30;   // bound of the global combiner scratch; larger launches are chunked
+const int SMALL_MAX_EDGES = 128;                    // glyphs of the LDS-scratch class have at most this many edges (bounds their survivor lists)
 
-int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan, int maxContours = -1) {
-    if (maxContours < 0)
-        maxContours = b->maxContours;
-    const size_t resBytes = overlap ? (size_t) maxContours*nch*WAVE*sizeof(double) : 0;
-    const size_t idxOne = ((size_t) b->maxEdges+(size_t) b->maxContours+2)*sizeof(int);   // survivor list + per-contour offsets of one tile
-    const size_t idxBytes = (size_t) QUAD*idxOne;                // the LDS-scratch variant culls a quad of tiles per wavefront
-    plan.ldsBudget = 13*1024;
-    const size_t limit = (size_t) gLdsLimit.load();
-    plan.resBytes = resBytes;
+size_t ldsBudget() {
     // The combiner scratch lives in LDS only while 12 wavefronts (3 per SIMD, the register-limited occupancy) fit a CU's 160 KB:
     // beyond ~13 KB per wavefront LDS would cap the occupancy (a 20-contour glyph set ran at 1.25 wavefronts/SIMD), so it moves to a
     // global workspace instead -- written and read once per contour with lane-consecutive addresses.
     if (const char *env = getenv("MSDFHIP_RES_LDS_BUDGET"))      // experiment knob (bytes)
-        plan.ldsBudget = (size_t) atol(env);
+        return (size_t) atol(env);
+    return 13*1024;
+}
+
+// maxContours / maxEdges: of the glyphs this launch covers (default: of the whole batch).
+int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan, int maxContours = -1, int maxEdges = -1) {
+    if (maxContours < 0)
+        maxContours = b->maxContours;
+    if (maxEdges < 0)
+        maxEdges = b->maxEdges;
+    const size_t resBytes = overlap ? (size_t) maxContours*nch*WAVE*sizeof(double) : 0;
+    const size_t idxOne = ((size_t) maxEdges+(size_t) maxContours+2)*sizeof(int);   // survivor list + per-contour offsets of one tile
+    const size_t idxBytes = (size_t) QUAD*idxOne;                // the LDS-scratch variant culls a quad of tiles per wavefront
+    plan.ldsBudget = ldsBudget();
+    const size_t limit = (size_t) gLdsLimit.load();
+    plan.resBytes = resBytes;
     plan.globalRes = overlap && resBytes+idxBytes > plan.ldsBudget;
     plan.idxBytes = idxBytes;
-    if (idxOne > limit)
-        return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours / %d edges: the survivor list needs %zu B of LDS per wavefront, device limit is %zu B",
-                    b->maxContours, b->maxEdges, idxOne, limit);
-    // (Staging the surviving records in LDS instead of reading them with scalar loads was measured slower and is gone.)
+    plan.listStride = maxEdges;
     plan.bytes = plan.globalRes ? idxOne : resBytes+idxBytes;     // the global-scratch variant takes one tile per wavefront
+    if (plan.bytes > limit)
+        return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours / %d edges: the survivor lists need %zu B of LDS per wavefront, device limit is %zu B",
+                    maxContours, maxEdges, plan.bytes, limit);
+    // (Staging the surviving records in LDS instead of reading them with scalar loads was measured slower and is gone.)
     return MSDFHIP_OK;
 }
 
@@ -169,7 +207,6 @@ int ensureGres(const MsdfHipBatch *b, size_t bytes, double **out) {
         if (b->dGres)
             hipFree(b->dGres);
         b->dGres = NULL, b->gresBytes = 0;
-    b->bucketLimit = -1, b->dBucket = NULL, b->nSmall = 0, b->smallMaxC = 0;
         HIPCHK(hipMalloc((void **) &b->dGres, bytes));
         b->gresBytes = bytes;
     }
@@ -207,39 +244,54 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
     for (size_t base = 0; base < blocks; base += chunk) {
         const size_t n = blocks-base < chunk ? blocks-base : chunk;
         hipLaunchKernelGGL((k_distance<SEL, OVERLAP, GRES>), dim3((unsigned) n), dim3(WAVE), plan.bytes, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles,
-                           b->maxEdges, dst, toScratch, (unsigned) base, gres, stride, dGlyphMap, nMapped);
+                           plan.listStride, dst, toScratch, (unsigned) base, gres, stride, dGlyphMap, nMapped);
     }
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
 }
 
-// Glyph indices sorted into "combiner scratch fits the LDS budget" (<= limit contours) and the rest; cached per limit.
+// Glyph indices sorted into three classes of the overlapping combiner; cached per limit:
+//   one    <= 1 contour: the combiner reduces to the simple one (contour-combiners.cpp:104-133 with a single selector) -- these run the
+//          simple-combiner kernel, which needs 95 VGPRs instead of ~150 and therefore runs 5 instead of 3 wavefronts per SIMD;
+//   small  2..limit contours: per-contour distances in LDS;
+//   rest   more: per-contour distances in the global workspace.
 int ensureBuckets(const MsdfHipBatch *b, int limit) {
     std::lock_guard<std::mutex> lock(b->scratchMutex);
     if (b->bucketLimit == limit && b->dBucket)
         return MSDFHIP_OK;
-    if (b->hContours.empty() && b->nGlyphs > 0) {                // batch created from device arrays: read the glyph offsets back once
-        std::vector<int32_t> gco((size_t) b->nGlyphs+1);
+    if ((b->hContours.empty() || b->hEdges.empty()) && b->nGlyphs > 0) {   // batch created from device arrays: read the offsets back once
+        std::vector<int32_t> gco((size_t) b->nGlyphs+1), co((size_t) b->nContours+1);
         HIPCHK(hipMemcpy(gco.data(), b->dGlyphContourOffsets, sizeof(int32_t)*gco.size(), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(co.data(), b->dContourOffsets, sizeof(int32_t)*co.size(), hipMemcpyDeviceToHost));
         b->hContours.resize((size_t) b->nGlyphs);
-        for (int g = 0; g < b->nGlyphs; ++g)
+        b->hEdges.resize((size_t) b->nGlyphs);
+        for (int g = 0; g < b->nGlyphs; ++g) {
             b->hContours[g] = gco[g+1]-gco[g];
+            b->hEdges[g] = co[gco[g+1]]-co[gco[g]];
+        }
     }
     std::vector<int> order((size_t) b->nGlyphs);
-    int nSmall = 0, smallMaxC = 0;
+    int at = 0, nOne = 0, nSmall = 0, smallMaxC = 0, smallMaxE = 0, oneMaxE = 0;
     for (int g = 0; g < b->nGlyphs; ++g)
-        if (b->hContours[g] <= limit) {
-            order[nSmall++] = g;
-            smallMaxC = b->hContours[g] > smallMaxC ? b->hContours[g] : smallMaxC;
+        if (b->hContours[g] <= 1) {
+            order[at++] = g;
+            oneMaxE = b->hEdges[g] > oneMaxE ? b->hEdges[g] : oneMaxE;
         }
-    int at = nSmall;
+    nOne = at;
     for (int g = 0; g < b->nGlyphs; ++g)
-        if (b->hContours[g] > limit)
+        if (b->hContours[g] > 1 && b->hContours[g] <= limit && b->hEdges[g] <= SMALL_MAX_EDGES) {
+            order[at++] = g;
+            smallMaxC = b->hContours[g] > smallMaxC ? b->hContours[g] : smallMaxC;
+            smallMaxE = b->hEdges[g] > smallMaxE ? b->hEdges[g] : smallMaxE;
+        }
+    nSmall = at-nOne;
+    for (int g = 0; g < b->nGlyphs; ++g)
+        if (b->hContours[g] > 1 && !(b->hContours[g] <= limit && b->hEdges[g] <= SMALL_MAX_EDGES))
             order[at++] = g;
     if (!b->dBucket)
-        HIPCHK(hipMalloc((void **) &b->dBucket, sizeof(int)*(size_t) (b->nGlyphs > 0 ? b->nGlyphs : 1)));
+        HIPCHK(hipMalloc((void **) &b->dBucket, sizeof(int)*(size_t) (b->nGlyphs > b->glyphCap ? b->nGlyphs : b->glyphCap > 0 ? b->glyphCap : 1)));
     HIPCHK(hipMemcpy(b->dBucket, order.data(), sizeof(int)*(size_t) b->nGlyphs, hipMemcpyHostToDevice));
-    b->bucketLimit = limit, b->nSmall = nSmall, b->smallMaxC = smallMaxC;
+    b->bucketLimit = limit, b->nOne = nOne, b->nSmall = nSmall, b->smallMaxC = smallMaxC, b->smallMaxE = smallMaxE, b->oneMaxE = oneMaxE;
     return MSDFHIP_OK;
 }
 
@@ -250,31 +302,53 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     if (rc != MSDFHIP_OK)
         return rc;
     ScopedTimer timer(stream, 0);                                // the distance pass of one generate call (one or more launches)
-    if (plan.globalRes) {
-        // Only the glyphs whose combiner scratch does not fit the LDS budget take the global-workspace kernel; the others (usually
-        // nearly all of a font: a handful of many-contour symbols must not slow the rest down) run the LDS variant.
-        const size_t perContour = (size_t) SelTraits<SEL>::NCH*WAVE*sizeof(double);
-        const int limit = plan.ldsBudget > plan.idxBytes ? (int) ((plan.ldsBudget-plan.idxBytes)/perContour) : 0;
-        if (limit >= 1 && b->nGlyphs > 1) {
-            rc = ensureBuckets(b, limit);
+    if (!overlap || b->maxContours <= 1) {
+        if (overlap) {
+            rc = planLds(b, SelTraits<SEL>::NCH, false, plan);
             if (rc != MSDFHIP_OK)
                 return rc;
-            if (b->nSmall > 0) {
-                LdsPlan small;
-                rc = planLds(b, SelTraits<SEL>::NCH, overlap, small, b->smallMaxC);
-                if (rc != MSDFHIP_OK)
-                    return rc;
-                rc = launchDistance<SEL, true, false>(b, dGlyphs, w, h, dst, toScratch, small, stream, b->dBucket, b->nSmall);
-                if (rc != MSDFHIP_OK)
-                    return rc;
-                return launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, plan, stream, b->dBucket+b->nSmall, b->nGlyphs-b->nSmall);
-            }
         }
+        return launchDistance<SEL, false, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
+    }
+    // how many contours' worth of combiner scratch fit the per-wavefront LDS budget next to the survivor lists of a SMALL_MAX_EDGES glyph
+    const size_t perContour = (size_t) SelTraits<SEL>::NCH*WAVE*sizeof(double);
+    int limit = 0;
+    while ((size_t) (limit+1)*perContour+(size_t) QUAD*((size_t) SMALL_MAX_EDGES+(limit+1)+2)*sizeof(int) <= plan.ldsBudget)
+        ++limit;
+    if (b->nGlyphs == 1) {                                       // the single-shape calls: the class is known, no index map
+        if (b->maxContours <= limit && b->maxEdges <= SMALL_MAX_EDGES && !plan.globalRes)
+            return launchDistance<SEL, true, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
+        plan.globalRes = true;
+        plan.bytes = ((size_t) b->maxEdges+(size_t) b->maxContours+2)*sizeof(int);
         return launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
     }
-    if (overlap)
-        return launchDistance<SEL, true, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
-    return launchDistance<SEL, false, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
+    rc = ensureBuckets(b, limit < 1 ? 1 : limit);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    const int nRest = b->nGlyphs-b->nOne-b->nSmall;
+    if (b->nOne > 0) {
+        LdsPlan simple;
+        rc = planLds(b, SelTraits<SEL>::NCH, false, simple, 1, b->oneMaxE);
+        if (rc == MSDFHIP_OK)
+            rc = launchDistance<SEL, false, false>(b, dGlyphs, w, h, dst, toScratch, simple, stream, b->dBucket, b->nOne);
+        if (rc != MSDFHIP_OK)
+            return rc;
+    }
+    if (b->nSmall > 0) {
+        LdsPlan small;
+        rc = planLds(b, SelTraits<SEL>::NCH, true, small, b->smallMaxC, b->smallMaxE);
+        if (rc == MSDFHIP_OK)
+            rc = launchDistance<SEL, true, false>(b, dGlyphs, w, h, dst, toScratch, small, stream, b->dBucket+b->nOne, b->nSmall);
+        if (rc != MSDFHIP_OK)
+            return rc;
+    }
+    if (nRest > 0) {
+        LdsPlan rest = plan;                                     // sized for the batch's largest glyph
+        rest.globalRes = true;
+        rest.bytes = ((size_t) b->maxEdges+(size_t) b->maxContours+2)*sizeof(int);
+        return launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, rest, stream, b->dBucket+b->nOne+b->nSmall, nRest);
+    }
+    return MSDFHIP_OK;
 }
 
 // Records of the per-glyph candidate segments incl. the header (msdf_kernels.hpp, EcCandidate).
@@ -291,7 +365,7 @@ int ensureDeferred(const MsdfHipBatch *b, size_t cap, EcCandidate **out) {
         b->deferredCap = cap;
     }
     if (!b->dEcParams)
-        HIPCHK(hipMalloc((void **) &b->dEcParams, sizeof(EcGlyphParams)*(size_t) (b->nGlyphs > 0 ? b->nGlyphs : 1)));
+        HIPCHK(hipMalloc((void **) &b->dEcParams, sizeof(EcGlyphParams)*(size_t) (b->nGlyphs > b->glyphCap ? b->nGlyphs : b->glyphCap > 0 ? b->glyphCap : 1)));
     *out = b->dDeferred;
     return MSDFHIP_OK;
 }
@@ -340,6 +414,9 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     if (rc != MSDFHIP_OK)
         return rc;
     const size_t fastLds = ecFastLdsBytes(b->maxEdges, N);
+    if (fastLds > (size_t) gLdsLimit.load() || queryLds > (size_t) gLdsLimit.load())
+        return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours / %d edges: the error-correction pass needs %zu B of LDS per wavefront, device limit is %d B",
+                    b->maxContours, b->maxEdges, fastLds > queryLds ? fastLds : queryLds, gLdsLimit.load());
     rc = setLds(k_ec_fast<N>, fastLds);
     if (rc != MSDFHIP_OK)
         return rc;
@@ -457,7 +534,7 @@ void msdfhip_default_config(MsdfHipConfig *cfg) {
     cfg->sign_correction = 0;
     cfg->fill_rule = 0;                                          // FILL_NONZERO (core/rasterization.h:17)
     cfg->sdf_zero_value = .5f;
-    cfg->reserved = 0;
+    cfg->stencil_y_down = 0;
 }
 
 int msdfhip_abi_version(void) { return MSDFHIP_ABI_VERSION; }
@@ -510,6 +587,7 @@ int msdfhip_batch_create_device(MsdfHipBatch **batch, int n_glyphs, int n_contou
     if (rc != MSDFHIP_OK)
         return rc;
     MsdfHipBatch *b = new MsdfHipBatch();
+    b->device = currentDevice();                                 // where the caller's arrays live: the device bound by msdfhip_init
     b->nGlyphs = n_glyphs, b->nContours = n_contours, b->nEdges = n_edges;
     b->maxContours = max_contours_per_glyph, b->maxEdges = max_edges_per_glyph;
     b->ownsInputs = false;
@@ -518,8 +596,6 @@ int msdfhip_batch_create_device(MsdfHipBatch **batch, int n_glyphs, int n_contou
     b->dPoints = const_cast<double *>(d_points);
     b->dTypes = const_cast<uint8_t *>(d_types);
     b->dColors = const_cast<uint8_t *>(d_colors);
-    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0, b->dEcParams = NULL, b->dGres = NULL, b->gresBytes = 0;
-    b->bucketLimit = -1, b->dBucket = NULL, b->nSmall = 0, b->smallMaxC = 0;
     rc = digest(b, (hipStream_t) stream);
     if (rc != MSDFHIP_OK) {
         msdfhip_batch_destroy(b);
@@ -529,35 +605,57 @@ int msdfhip_batch_create_device(MsdfHipBatch **batch, int n_glyphs, int n_contou
     return MSDFHIP_OK;
 }
 
-int msdfhip_batch_create(MsdfHipBatch **batch, int n_glyphs, const int32_t *gco, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors) {
-    if (!batch || n_glyphs < 0 || !gco || !co)
+// Validates a CSR shape list given as HOST arrays before anything is dereferenced beyond its stated size; fills the per-glyph counts.
+static int checkShapeArrays(int n_glyphs, const int32_t *gco, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors,
+                            bool colorsRequired, std::vector<int> &hContours, std::vector<int> &hEdges, int &maxC, int &maxE) {
+    if (n_glyphs < 0 || !gco || !co)
         return fail(MSDFHIP_ERR_INVALID, "bad batch arguments");
-    int rc = ensureDevice();
-    if (rc != MSDFHIP_OK)
-        return rc;
-    const int nC = gco[n_glyphs], nE = co[nC];
-    if (gco[0] != 0 || co[0] != 0 || nC < 0 || nE < 0)
+    if (gco[0] != 0 || co[0] != 0)
         return fail(MSDFHIP_ERR_INVALID, "offset arrays must start at 0");
-    int maxC = 0, maxE = 0;
-    for (int g = 0; g < n_glyphs; ++g) {
+    for (int g = 0; g < n_glyphs; ++g)
         if (gco[g+1] < gco[g])
             return fail(MSDFHIP_ERR_INVALID, "glyph_contour_offsets not monotonic at %d", g);
-        const int c = gco[g+1]-gco[g], e = co[gco[g+1]]-co[gco[g]];
-        maxC = c > maxC ? c : maxC;
-        maxE = e > maxE ? e : maxE;
-    }
+    const int nC = gco[n_glyphs];
     for (int c = 0; c < nC; ++c)
         if (co[c+1] < co[c])
             return fail(MSDFHIP_ERR_INVALID, "contour_offsets not monotonic at %d", c);
+    const int nE = co[nC];
+    if (nE > 0 && (!points || !types || (colorsRequired && !colors)))
+        return fail(MSDFHIP_ERR_INVALID, "NULL edge arrays");
     for (int e = 0; e < nE; ++e)
         if (types[e] < 1 || types[e] > 3)
             return fail(MSDFHIP_ERR_INVALID, "edge %d has type %d (must be 1, 2 or 3)", e, (int) types[e]);
+    hContours.resize((size_t) n_glyphs);
+    hEdges.resize((size_t) n_glyphs);
+    maxC = maxE = 0;
+    for (int g = 0; g < n_glyphs; ++g) {
+        const int c = gco[g+1]-gco[g], e = co[gco[g+1]]-co[gco[g]];
+        hContours[g] = c, hEdges[g] = e;
+        maxC = c > maxC ? c : maxC;
+        maxE = e > maxE ? e : maxE;
+    }
+    return MSDFHIP_OK;
+}
+
+int msdfhip_batch_create_on(MsdfHipBatch **batch, int device, int n_glyphs, const int32_t *gco, const int32_t *co, const double *points, const uint8_t *types,
+                            const uint8_t *colors) {
+    if (!batch)
+        return fail(MSDFHIP_ERR_INVALID, "bad batch arguments");
+    std::vector<int> hContours, hEdges;
+    int maxC = 0, maxE = 0;
+    int rc = checkShapeArrays(n_glyphs, gco, co, points, types, colors, true, hContours, hEdges, maxC, maxE);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    rc = ensureDevice(device);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    const int nC = gco[n_glyphs], nE = co[nC];
     MsdfHipBatch *b = new MsdfHipBatch();
+    b->device = currentDevice();
     b->nGlyphs = n_glyphs, b->nContours = nC, b->nEdges = nE, b->maxContours = maxC, b->maxEdges = maxE;
     b->ownsInputs = true;
-    b->dGlyphContourOffsets = NULL, b->dContourOffsets = NULL, b->dPoints = NULL, b->dTypes = NULL, b->dColors = NULL;
-    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0, b->dEcParams = NULL, b->dGres = NULL, b->gresBytes = 0;
-    b->bucketLimit = -1, b->dBucket = NULL, b->nSmall = 0, b->smallMaxC = 0;
+    b->hContours.swap(hContours);
+    b->hEdges.swap(hEdges);
     const size_t eAlloc = nE > 0 ? nE : 1;
     #define ALLOC_COPY(dst, src, bytes, used) do { \
         hipError_t e_ = hipMalloc((void **) &(dst), (bytes) ? (bytes) : 16); \
@@ -580,27 +678,44 @@ int msdfhip_batch_create(MsdfHipBatch **batch, int n_glyphs, const int32_t *gco,
     return MSDFHIP_OK;
 }
 
+int msdfhip_batch_create(MsdfHipBatch **batch, int n_glyphs, const int32_t *gco, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors) {
+    return msdfhip_batch_create_on(batch, -1, n_glyphs, gco, co, points, types, colors);
+}
+
+int msdfhip_batch_device(const MsdfHipBatch *b, int *device) {
+    if (!b || !device)
+        return fail(MSDFHIP_ERR_INVALID, "NULL argument");
+    *device = b->device;
+    return MSDFHIP_OK;
+}
+
+int msdfhip_device_count(int *count) {
+    if (!count)
+        return fail(MSDFHIP_ERR_INVALID, "NULL argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(MSDFHIP_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    *count = n;
+    return MSDFHIP_OK;
+}
+
 int msdfhip_batch_create_prepared(MsdfHipBatch **batch, int n_glyphs, const int32_t *gco, const int32_t *co, const double *points, const uint8_t *types,
                                   const uint8_t *colors, const uint64_t *seeds, const MsdfHipPrepConfig *cfg) {
     if (!batch || n_glyphs < 0 || !gco || !co || !cfg)
         return fail(MSDFHIP_ERR_INVALID, "bad arguments to msdfhip_batch_create_prepared");
     if (cfg->coloring < 0 || cfg->coloring > 2)
         return fail(MSDFHIP_ERR_INVALID, "coloring %d (0 keep, 1 edgeColoringSimple, 2 edgeColoringInkTrap)", cfg->coloring);
+    {
+        std::vector<int> hc, he;
+        int mc = 0, me = 0;
+        int rcv = checkShapeArrays(n_glyphs, gco, co, points, types, colors, false, hc, he, mc, me);
+        if (rcv != MSDFHIP_OK)
+            return rcv;
+    }
     int rc = ensureDevice();
     if (rc != MSDFHIP_OK)
         return rc;
     const int nC = gco[n_glyphs], nE = co[nC];
-    if (gco[0] != 0 || co[0] != 0 || nC < 0 || nE < 0)
-        return fail(MSDFHIP_ERR_INVALID, "offset arrays must start at 0");
-    for (int g = 0; g < n_glyphs; ++g)
-        if (gco[g+1] < gco[g])
-            return fail(MSDFHIP_ERR_INVALID, "glyph_contour_offsets not monotonic at %d", g);
-    for (int c = 0; c < nC; ++c)
-        if (co[c+1] < co[c])
-            return fail(MSDFHIP_ERR_INVALID, "contour_offsets not monotonic at %d", c);
-    for (int e = 0; e < nE; ++e)
-        if (types[e] < 1 || types[e] > 3)
-            return fail(MSDFHIP_ERR_INVALID, "edge %d has type %d (must be 1, 2 or 3)", e, (int) types[e]);
 
     // offsets after normalize are a host-side prefix over the raw contour sizes; the upper bound of the coloured size as well
     std::vector<int32_t> co1(nC+1, 0), co2(nC+1, 0);
@@ -691,12 +806,11 @@ int msdfhip_batch_create_prepared(MsdfHipBatch **batch, int n_glyphs, const int3
         maxE = e > maxE ? e : maxE;
     }
     MsdfHipBatch *b = new MsdfHipBatch();
+    b->device = currentDevice();
     b->nGlyphs = n_glyphs, b->nContours = nC, b->nEdges = finalCo[nC], b->maxContours = maxC, b->maxEdges = maxE;
     b->ownsInputs = true;                                        // the batch takes over the final arrays
     b->dGlyphContourOffsets = dGco, b->dContourOffsets = dFinalCo, b->dPoints = fin.points, b->dTypes = fin.types, b->dColors = fin.colors;
     dev.release(dGco), dev.release(dFinalCo), dev.release(fin.points), dev.release(fin.types), dev.release(fin.colors);
-    b->dRecs = NULL, b->dWindings = NULL, b->dScratch = NULL, b->scratchFloats = 0, b->dDeferred = NULL, b->deferredCap = 0, b->dEcParams = NULL, b->dGres = NULL, b->gresBytes = 0;
-    b->bucketLimit = -1, b->dBucket = NULL, b->nSmall = 0, b->smallMaxC = 0;
     rc = digest(b, NULL);
     if (rc == MSDFHIP_OK && hipStreamSynchronize(NULL) != hipSuccess)
         rc = fail(MSDFHIP_ERR_HIP, "edge digestion failed: %s", hipGetErrorString(hipGetLastError()));
@@ -713,7 +827,7 @@ int msdfhip_batch_candidate_counts(const MsdfHipBatch *b, uint32_t *counts) {
         return fail(MSDFHIP_ERR_INVALID, "NULL argument");
     if (!b->dDeferred)
         return fail(MSDFHIP_ERR_INVALID, "no error-correction pass has run on this batch");
-    int rc = ensureDevice();
+    int rc = ensureDevice(b->device);
     if (rc != MSDFHIP_OK)
         return rc;
     HIPCHK(hipDeviceSynchronize());
@@ -735,7 +849,7 @@ int msdfhip_batch_info(const MsdfHipBatch *b, int *nGlyphs, int *nContours, int 
 int msdfhip_batch_download(const MsdfHipBatch *b, int32_t *co, double *points, uint8_t *types, uint8_t *colors) {
     if (!b)
         return fail(MSDFHIP_ERR_INVALID, "NULL batch");
-    int rc = ensureDevice();
+    int rc = ensureDevice(b->device);
     if (rc != MSDFHIP_OK)
         return rc;
     HIPCHK(hipDeviceSynchronize());
@@ -753,7 +867,7 @@ int msdfhip_batch_download(const MsdfHipBatch *b, int32_t *co, double *points, u
 int msdfhip_batch_digest(MsdfHipBatch *b, void *stream) {
     if (!b)
         return fail(MSDFHIP_ERR_INVALID, "NULL batch");
-    int rc = ensureDevice();
+    int rc = ensureDevice(b->device);
     if (rc != MSDFHIP_OK)
         return rc;
     return digest(b, (hipStream_t) stream);
@@ -762,6 +876,8 @@ int msdfhip_batch_digest(MsdfHipBatch *b, void *stream) {
 void msdfhip_batch_destroy(MsdfHipBatch *b) {
     if (!b)
         return;
+    (void) hipSetDevice(b->device);
+    destroyPipe(b);
     if (b->ownsInputs) {
         hipFree(b->dGlyphContourOffsets);
         hipFree(b->dContourOffsets);
@@ -782,7 +898,7 @@ void msdfhip_batch_destroy(MsdfHipBatch *b) {
 int msdfhip_batch_windings(const MsdfHipBatch *b, int32_t *windings) {
     if (!b || !windings)
         return fail(MSDFHIP_ERR_INVALID, "NULL argument");
-    int rc = ensureDevice();
+    int rc = ensureDevice(b->device);
     if (rc != MSDFHIP_OK)
         return rc;
     std::vector<int8_t> tmp((size_t) b->nContours+1);
@@ -801,7 +917,7 @@ int msdfhip_batch_generate(const MsdfHipBatch *b, int mode, int w, int h, const 
     int rc = checkConfig(cfg);
     if (rc != MSDFHIP_OK)
         return rc;
-    rc = ensureDevice();
+    rc = ensureDevice(b->device);
     if (rc != MSDFHIP_OK)
         return rc;
     if (b->nGlyphs == 0 || w == 0 || h == 0)
@@ -846,7 +962,7 @@ int msdfhip_tiles_to_bytes(const float *dTiles, int nGlyphs, int w, int h, int c
         return MSDFHIP_OK;
     if (!dTiles || !dGlyphs || !dAtlas)
         return fail(MSDFHIP_ERR_INVALID, "NULL argument");
-    int rc = ensureDevice();
+    int rc = ensureDeviceOf(dTiles);
     if (rc != MSDFHIP_OK)
         return rc;
     hipStream_t stream = (hipStream_t) streamPtr;
@@ -866,7 +982,7 @@ int msdfhip_batch_estimate_sdf_error(const MsdfHipBatch *b, int channels, int w,
         return fail(MSDFHIP_ERR_INVALID, "bad arguments to msdfhip_batch_estimate_sdf_error");
     if (fillRule < 0 || fillRule > 3)
         return fail(MSDFHIP_ERR_INVALID, "fill rule %d (must be 0..3)", fillRule);
-    int rc = ensureDevice();
+    int rc = ensureDevice(b->device);
     if (rc != MSDFHIP_OK)
         return rc;
     hipStream_t stream = (hipStream_t) streamPtr;
@@ -915,7 +1031,7 @@ int msdfhip_render_sdf(const float *dSdf, int nGlyphs, int sw, int sh, int ns, f
         return MSDFHIP_OK;
     if (!dSdf || !dOut || sw == 0 || sh == 0)
         return fail(MSDFHIP_ERR_INVALID, "NULL or empty distance field");
-    int rc = ensureDevice();
+    int rc = ensureDeviceOf(dSdf);
     if (rc != MSDFHIP_OK)
         return rc;
     const double scaleX = (double) sw/ow, scaleY = (double) sh/oh;       // render-sdf.cpp:15
@@ -949,7 +1065,7 @@ int msdfhip_simulate_8bit(float *dPixels, size_t n, void *streamPtr) {
         return MSDFHIP_OK;
     if (!dPixels)
         return fail(MSDFHIP_ERR_INVALID, "NULL argument");
-    int rc = ensureDevice();
+    int rc = ensureDeviceOf(dPixels);
     if (rc != MSDFHIP_OK)
         return rc;
     const unsigned blocks = (unsigned) ((n+255)/256 < 65536 ? (n+255)/256 : 65536);
@@ -958,58 +1074,396 @@ int msdfhip_simulate_8bit(float *dPixels, size_t n, void *streamPtr) {
     return MSDFHIP_OK;
 }
 
+// ------------------------------------------------------------------------------------------- host-output pipeline
+//
+// msdfhip_batch_generate_host / _bytes_host: the end-to-end form an atlas generator wants -- the batch's glyphs rendered into HOST
+// memory. The glyph list is cut into chunks; two slots (stream + device tile buffer + work buffers each) alternate, so the kernels
+// of chunk k+1 overlap the device-to-host copy of chunk k. A chunk is a non-owning view of the batch (the CSR arrays are global:
+// a glyph range is the same arrays with shifted glyph offsets).
+
+struct PipeSlot {
+    hipStream_t stream;
+    hipEvent_t done;                  // the slot's last device-to-host copy has finished
+    bool busy;
+    char *dev;                        // [descriptors | tiles | stencil | byte staging]
+    size_t devCap;
+    MsdfHipGlyph *pinnedGlyphs;       // pinned staging of the chunk's descriptors: [cap] for the generators, [cap] for the byte blit
+    size_t pinnedGlyphCap;
+    int viewCap;                      // glyphs the view's per-glyph work buffers (class lists, correction constants) were sized for
+    MsdfHipBatch view;                // glyph range of the parent batch + this slot's own work buffers
+};
+
+static void destroyPipe(const MsdfHipBatch *b) {
+    if (!b->pipe)
+        return;
+    for (int k = 0; k < 2; ++k) {
+        PipeSlot &p = b->pipe[k];
+        if (p.stream) {
+            hipStreamSynchronize(p.stream);
+            hipStreamDestroy(p.stream);
+        }
+        if (p.done)
+            hipEventDestroy(p.done);
+        hipFree(p.dev);
+        if (p.pinnedGlyphs)
+            hipHostFree(p.pinnedGlyphs);
+        hipFree(p.view.dScratch), hipFree(p.view.dDeferred), hipFree(p.view.dEcParams), hipFree(p.view.dGres), hipFree(p.view.dBucket);
+    }
+    delete[] b->pipe;
+    b->pipe = NULL;
+}
+
+static int ensurePipe(const MsdfHipBatch *b) {
+    if (b->pipe)
+        return MSDFHIP_OK;
+    b->pipe = new PipeSlot[2];
+    for (int k = 0; k < 2; ++k) {
+        PipeSlot &p = b->pipe[k];
+        p.stream = NULL, p.done = NULL, p.busy = false, p.dev = NULL, p.devCap = 0, p.pinnedGlyphs = NULL, p.pinnedGlyphCap = 0, p.viewCap = 0;
+    }
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(hipStreamCreateWithFlags(&b->pipe[k].stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&b->pipe[k].done, hipEventDisableTiming));
+    }
+    return MSDFHIP_OK;
+}
+
+// Points slot.view at glyphs [g0, g0+n) of b (shared, read-only inputs; the slot keeps its own work buffers across chunks and calls).
+static void sliceBatch(const MsdfHipBatch *b, MsdfHipBatch &v, int g0, int n) {
+    v.device = b->device;
+    v.nGlyphs = n, v.nContours = b->nContours, v.nEdges = b->nEdges;
+    v.ownsInputs = false;
+    v.dGlyphContourOffsets = b->dGlyphContourOffsets+g0;        // entries are absolute contour indices: valid from any starting glyph
+    v.dContourOffsets = b->dContourOffsets, v.dPoints = b->dPoints, v.dTypes = b->dTypes, v.dColors = b->dColors;
+    v.dRecs = b->dRecs, v.dWindings = b->dWindings;
+    v.hContours.assign(b->hContours.begin()+g0, b->hContours.begin()+g0+n);
+    v.hEdges.assign(b->hEdges.begin()+g0, b->hEdges.begin()+g0+n);
+    int maxC = 0, maxE = 0;
+    for (int g = 0; g < n; ++g) {
+        maxC = v.hContours[g] > maxC ? v.hContours[g] : maxC;
+        maxE = v.hEdges[g] > maxE ? v.hEdges[g] : maxE;
+    }
+    v.maxContours = maxC, v.maxEdges = maxE;
+    v.bucketLimit = -1;                                          // the class lists are per glyph range
+}
+
+static int fetchGlyphCounts(const MsdfHipBatch *b) {             // device-array batches: the per-glyph counts are read back once
+    if (!b->hContours.empty() || b->nGlyphs == 0)
+        return MSDFHIP_OK;
+    std::vector<int32_t> gco((size_t) b->nGlyphs+1), co((size_t) b->nContours+1);
+    HIPCHK(hipMemcpy(gco.data(), b->dGlyphContourOffsets, sizeof(int32_t)*gco.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(co.data(), b->dContourOffsets, sizeof(int32_t)*co.size(), hipMemcpyDeviceToHost));
+    b->hContours.resize((size_t) b->nGlyphs);
+    b->hEdges.resize((size_t) b->nGlyphs);
+    for (int g = 0; g < b->nGlyphs; ++g) {
+        b->hContours[g] = gco[g+1]-gco[g];
+        b->hEdges[g] = co[gco[g+1]]-co[gco[g]];
+    }
+    return MSDFHIP_OK;
+}
+
+static std::atomic<int> gPipeChunkGlyphs(0);                     // 0 = automatic (about 48 MB of float tiles per chunk)
+
+// out != NULL: float tiles into the caller's bitmaps (glyphs[g].out_offset / row_stride in floats). atlas != NULL: pixelFloatToByte
+// + blit into the caller's 8-bit atlas (out_offset / row_stride in bytes). Exactly one of the two.
+static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const MsdfHipGlyph *glyphs, float *out, size_t outFloats, uint8_t *atlas,
+                       size_t atlasBytes, uint8_t *stencil, const MsdfHipConfig *cfg) {
+    if (!b || !glyphs || (!out && !atlas) || mode < 1 || mode > 4 || w < 0 || h < 0)
+        return fail(MSDFHIP_ERR_INVALID, "bad arguments to the host-output generator");
+    int rc = checkConfig(cfg);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    rc = ensureDevice(b->device);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    const int nG = b->nGlyphs, N = channelsOf(mode);
+    if (nG == 0 || w == 0 || h == 0)
+        return MSDFHIP_OK;
+    std::lock_guard<std::mutex> lock(b->pipeMutex);
+    rc = ensurePipe(b);
+    if (rc == MSDFHIP_OK)
+        rc = fetchGlyphCounts(b);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    const size_t texels = (size_t) w*h, tile = texels*N;         // floats per tile; also bytes per 8-bit tile
+    const size_t total = out ? outFloats : atlasBytes;
+    // every rectangle must lie inside the caller's buffer
+    for (int g = 0; g < nG; ++g) {
+        const long long o = glyphs[g].out_offset, rs = glyphs[g].row_stride;
+        const long long lo = rs >= 0 ? o : o+rs*(h-1), hi = (rs >= 0 ? o+rs*(h-1) : o)+(long long) w*N;
+        if (lo < 0 || (unsigned long long) hi > total)
+            return fail(MSDFHIP_ERR_INVALID, "glyph %d's rectangle [%lld, %lld) lies outside the output buffer of %zu elements", g, lo, hi, total);
+    }
+    // packed: glyph g's tile is the g-th tile of the output, rows contiguous -> a chunk is one contiguous host range and the device
+    // renders straight into the chunk's tile buffer. Otherwise (rectangles of a larger atlas) the device keeps a mirror of the whole
+    // buffer: uploaded first (texels outside the rectangles survive), copied back once at the end.
+    bool packed = true;
+    for (int g = 0; g < nG && packed; ++g)
+        packed = glyphs[g].out_offset == (long long) ((size_t) g*tile) && glyphs[g].row_stride == w*N;
+    int chunk = gPipeChunkGlyphs.load();
+    if (chunk <= 0) {
+        chunk = (int) ((48u<<20)/(tile*sizeof(float) ? tile*sizeof(float) : 1));
+        chunk = chunk < 64 ? 64 : chunk/64*64;
+    }
+    if (chunk > nG)
+        chunk = nG;
+    const bool correct = mode >= 3 && cfg->ec_mode != MSDFHIP_EC_DISABLED;
+    const bool wantStencil = stencil != NULL && correct;         // the reference leaves the caller's buffer alone when no correction runs
+    char *mirror = NULL;                                         // whole-buffer device mirror (non-packed layouts; always for 8-bit atlases)
+    const size_t elem = out ? sizeof(float) : 1;
+    struct MirrorGuard { char *&p; ~MirrorGuard() { hipFree(p); } } mirrorGuard = { mirror };
+    if (!packed || atlas) {
+        HIPCHK(hipMalloc((void **) &mirror, total*elem));
+        if (!packed)
+            HIPCHK(hipMemcpy(mirror, out ? (const void *) out : (const void *) atlas, total*elem, hipMemcpyHostToDevice));
+    }
+    const size_t offGlyphs = 0, offTiles = (2*(size_t) chunk*sizeof(MsdfHipGlyph)+255)/256*256, tilesBytes = ((size_t) chunk*tile*sizeof(float)+255)/256*256;
+    const size_t offStencil = offTiles+((packed && out) || atlas ? tilesBytes : 0), devBytes = offStencil+(wantStencil ? (size_t) chunk*texels : 0)+256;
+    for (int k = 0; k < 2; ++k) {
+        PipeSlot &p = b->pipe[k];
+        if (p.devCap < devBytes) {
+            HIPCHK(hipStreamSynchronize(p.stream));
+            if (p.dev)
+                HIPCHK(hipFree(p.dev));
+            p.dev = NULL, p.devCap = 0;
+            HIPCHK(hipMalloc((void **) &p.dev, devBytes));
+            p.devCap = devBytes;
+        }
+        if (p.pinnedGlyphCap < (size_t) chunk) {
+            if (p.pinnedGlyphs)
+                HIPCHK(hipHostFree(p.pinnedGlyphs));
+            p.pinnedGlyphs = NULL, p.pinnedGlyphCap = 0;
+            HIPCHK(hipHostMalloc((void **) &p.pinnedGlyphs, sizeof(MsdfHipGlyph)*2*(size_t) chunk, hipHostMallocDefault));
+            p.pinnedGlyphCap = (size_t) chunk;
+        }
+        if (p.viewCap < chunk) {                                 // per-glyph work buffers of the view: reallocated on demand by the launches
+            HIPCHK(hipStreamSynchronize(p.stream));
+            hipFree(p.view.dBucket), hipFree(p.view.dEcParams);
+            p.view.dBucket = NULL, p.view.dEcParams = NULL, p.view.bucketLimit = -1;
+            p.viewCap = chunk;
+        }
+        p.view.glyphCap = p.viewCap;                             // sized for a full chunk whatever the length of the slot's first chunk
+    }
+    int slot = 0;
+    for (int g0 = 0; g0 < nG && rc == MSDFHIP_OK; g0 += chunk, slot ^= 1) {
+        const int n = nG-g0 < chunk ? nG-g0 : chunk;
+        PipeSlot &p = b->pipe[slot];
+        if (p.busy) {                                            // the slot's previous copy must have left its buffers
+            HIPCHK(hipEventSynchronize(p.done));
+            p.busy = false;
+        }
+        sliceBatch(b, p.view, g0, n);
+        MsdfHipGlyph *dGlyphs = reinterpret_cast<MsdfHipGlyph *>(p.dev+offGlyphs);
+        float *dTiles = reinterpret_cast<float *>(p.dev+offTiles);
+        uint8_t *dStencil = wantStencil ? reinterpret_cast<uint8_t *>(p.dev+offStencil) : NULL;
+        for (int g = 0; g < n; ++g) {
+            p.pinnedGlyphs[g] = glyphs[g0+g];
+            if ((packed && out) || atlas)                        // render into the slot's packed tile buffer
+                p.pinnedGlyphs[g].out_offset = (int64_t) ((size_t) g*tile), p.pinnedGlyphs[g].row_stride = w*N;
+        }
+        HIPCHK(hipMemcpyAsync(dGlyphs, p.pinnedGlyphs, sizeof(MsdfHipGlyph)*(size_t) n, hipMemcpyHostToDevice, p.stream));
+        float *dDst = (packed && out) || atlas ? dTiles : reinterpret_cast<float *>(mirror);
+        rc = msdfhip_batch_generate(&p.view, mode, w, h, dGlyphs, dDst, dStencil, NULL, cfg, p.stream);
+        if (rc != MSDFHIP_OK)
+            break;
+        if (atlas) {
+            // descriptors again, this time with the caller's byte rectangles; the conversion kernel reads tiles packed in chunk order
+            MsdfHipGlyph *dAtlasGlyphs = dGlyphs+chunk, *hAtlasGlyphs = p.pinnedGlyphs+p.pinnedGlyphCap;
+            for (int g = 0; g < n; ++g)
+                hAtlasGlyphs[g] = glyphs[g0+g];
+            HIPCHK(hipMemcpyAsync(dAtlasGlyphs, hAtlasGlyphs, sizeof(MsdfHipGlyph)*(size_t) n, hipMemcpyHostToDevice, p.stream));
+            rc = msdfhip_tiles_to_bytes(dTiles, n, w, h, N, dAtlasGlyphs, reinterpret_cast<uint8_t *>(mirror), p.stream);
+            if (rc != MSDFHIP_OK)
+                break;
+            if (packed)                                          // byte tiles in glyph order: this chunk's bytes are one contiguous range
+                HIPCHK(hipMemcpyAsync(atlas+(size_t) g0*tile, mirror+(size_t) g0*tile, (size_t) n*tile, hipMemcpyDeviceToHost, p.stream));
+        } else if (packed)
+            HIPCHK(hipMemcpyAsync(out+(size_t) g0*tile, dTiles, sizeof(float)*(size_t) n*tile, hipMemcpyDeviceToHost, p.stream));
+        if (wantStencil)
+            HIPCHK(hipMemcpyAsync(stencil+(size_t) g0*texels, dStencil, (size_t) n*texels, hipMemcpyDeviceToHost, p.stream));
+        HIPCHK(hipEventRecord(p.done, p.stream));
+        p.busy = true;
+        // pinnedGlyphs is rewritten by this slot's next chunk only after p.done (above), i.e. after both descriptor uploads ran
+    }
+    for (int k = 0; k < 2; ++k) {
+        hipError_t e = hipStreamSynchronize(b->pipe[k].stream);
+        b->pipe[k].busy = false;
+        if (e != hipSuccess && rc == MSDFHIP_OK)
+            rc = fail(MSDFHIP_ERR_HIP, "host-output pipeline: %s", hipGetErrorString(e));
+    }
+    if (rc == MSDFHIP_OK && !packed)
+        HIPCHK(hipMemcpy(out ? (void *) out : (void *) atlas, mirror, total*elem, hipMemcpyDeviceToHost));
+    return rc;
+}
+
 int msdfhip_batch_generate_host(const MsdfHipBatch *b, int mode, int w, int h, const MsdfHipGlyph *glyphs, float *out, size_t outFloats,
                                 uint8_t *stencil, const MsdfHipConfig *cfg) {
-    if (!b || !glyphs || !out)
+    if (!out)
+        return fail(MSDFHIP_ERR_INVALID, "NULL argument");
+    return runPipeline(b, mode, w, h, glyphs, out, outFloats, NULL, 0, stencil, cfg);
+}
+
+int msdfhip_batch_generate_bytes_host(const MsdfHipBatch *b, int mode, int w, int h, const MsdfHipGlyph *glyphs, uint8_t *atlas, size_t atlasBytes,
+                                      const MsdfHipConfig *cfg) {
+    if (!atlas)
+        return fail(MSDFHIP_ERR_INVALID, "NULL argument");
+    return runPipeline(b, mode, w, h, glyphs, NULL, 0, atlas, atlasBytes, NULL, cfg);
+}
+
+int msdfhip_set_pipeline_chunk(int glyphs_per_chunk) {
+    if (glyphs_per_chunk < 0)
+        return fail(MSDFHIP_ERR_INVALID, "msdfhip_set_pipeline_chunk(%d)", glyphs_per_chunk);
+    gPipeChunkGlyphs.store(glyphs_per_chunk);
+    return MSDFHIP_OK;
+}
+
+int msdfhip_host_alloc(void **p, size_t bytes) {
+    if (!p)
         return fail(MSDFHIP_ERR_INVALID, "NULL argument");
     int rc = ensureDevice();
     if (rc != MSDFHIP_OK)
         return rc;
-    MsdfHipGlyph *dGlyphs = NULL;
-    float *dOut = NULL;
-    uint8_t *dStencil = NULL;
-    const size_t nG = (size_t) b->nGlyphs;
-    hipError_t e = hipMalloc((void **) &dGlyphs, sizeof(MsdfHipGlyph)*(nG ? nG : 1));
-    if (e == hipSuccess) e = hipMalloc((void **) &dOut, sizeof(float)*(outFloats ? outFloats : 1));
-    if (e == hipSuccess && stencil) e = hipMalloc((void **) &dStencil, nG*w*h ? nG*w*h : 1);
-    if (e == hipSuccess && nG) e = hipMemcpy(dGlyphs, glyphs, sizeof(MsdfHipGlyph)*nG, hipMemcpyHostToDevice);
-    if (e == hipSuccess && outFloats) e = hipMemcpy(dOut, out, sizeof(float)*outFloats, hipMemcpyHostToDevice); // keep texels outside the tiles
-    if (e == hipSuccess) {
-        rc = msdfhip_batch_generate(b, mode, w, h, dGlyphs, dOut, dStencil, NULL, cfg, NULL);
-        if (rc == MSDFHIP_OK) {
-            e = hipStreamSynchronize(NULL);
-            if (e == hipSuccess && outFloats) e = hipMemcpy(out, dOut, sizeof(float)*outFloats, hipMemcpyDeviceToHost);
-            if (e == hipSuccess && stencil && nG*w*h) e = hipMemcpy(stencil, dStencil, nG*w*h, hipMemcpyDeviceToHost);
-        }
+    // portable: usable by every device of the process (the sharded generator writes one buffer from several GPUs)
+    if (hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess)
+        return fail(MSDFHIP_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+    return MSDFHIP_OK;
+}
+
+int msdfhip_host_free(void *p) {
+    if (p && hipHostFree(p) != hipSuccess)
+        return fail(MSDFHIP_ERR_HIP, "hipHostFree failed");
+    return MSDFHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------- glyph-sharded, multi-device
+//
+// glyphs are independent, so a glyph list is cut into contiguous ranges balanced by W*H*E, one range per device, one
+// host thread + its own streams per device, no exchange between devices; every device copies its tiles straight into the caller's
+// buffer. The bytes do not depend on the split.
+
+static void shardRanges(const int32_t *gco, const int32_t *co, int nGlyphs, int parts, std::vector<int> &bounds) {
+    bounds.assign((size_t) parts+1, nGlyphs);
+    bounds[0] = 0;
+    double total = 0;
+    for (int g = 0; g < nGlyphs; ++g)
+        total += 1.+(co[gco[g+1]]-co[gco[g]]);
+    double acc = 0;
+    int part = 1;
+    for (int g = 0; g < nGlyphs && part < parts; ++g) {
+        acc += 1.+(co[gco[g+1]]-co[gco[g]]);
+        while (part < parts && acc >= total*part/parts)
+            bounds[part++] = g+1;
     }
-    hipFree(dGlyphs);
-    hipFree(dOut);
-    hipFree(dStencil);
-    if (e != hipSuccess)
-        return fail(MSDFHIP_ERR_HIP, "msdfhip_batch_generate_host: %s", hipGetErrorString(e));
-    return rc;
+}
+
+int msdfhip_generate_sharded(const int *devices, int n_devices, int mode, int w, int h, int n_glyphs, const int32_t *gco, const int32_t *co,
+                             const double *points, const uint8_t *types, const uint8_t *colors, const MsdfHipGlyph *glyphs,
+                             float *out, size_t outFloats, uint8_t *atlas, size_t atlasBytes, const MsdfHipConfig *cfg) {
+    if (!devices || n_devices < 1 || !glyphs || (!out) == (!atlas))
+        return fail(MSDFHIP_ERR_INVALID, "bad arguments to msdfhip_generate_sharded (exactly one of out / atlas)");
+    std::vector<int> hc, he;
+    int maxC = 0, maxE = 0;
+    int rc = checkShapeArrays(n_glyphs, gco, co, points, types, colors, true, hc, he, maxC, maxE);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    int count = 0;
+    rc = msdfhip_device_count(&count);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    for (int k = 0; k < n_devices; ++k)
+        if (devices[k] < 0 || devices[k] >= count)
+            return fail(MSDFHIP_ERR_INVALID, "device %d out of range (0..%d)", devices[k], count-1);
+    if (gDevice.load() < 0) {
+        rc = msdfhip_init(devices[0]);
+        if (rc != MSDFHIP_OK)
+            return rc;
+    }
+    std::vector<int> bounds;
+    shardRanges(gco, co, n_glyphs, n_devices, bounds);
+    std::vector<int> rcs((size_t) n_devices, MSDFHIP_OK);
+    std::vector<std::string> errors((size_t) n_devices);
+    std::vector<std::thread> workers;
+    for (int k = 0; k < n_devices; ++k)
+        workers.push_back(std::thread([&, k]() {
+            const int g0 = bounds[k], g1 = bounds[k+1];
+            if (g1 <= g0)
+                return;
+            // the range's own CSR arrays: offsets rebased, edge arrays are slices of the caller's
+            const int c0 = gco[g0], c1 = gco[g1], e0 = co[c0];
+            std::vector<int32_t> lgco((size_t) (g1-g0)+1), lco((size_t) (c1-c0)+1);
+            for (int g = g0; g <= g1; ++g)
+                lgco[g-g0] = gco[g]-c0;
+            for (int c = c0; c <= c1; ++c)
+                lco[c-c0] = co[c]-e0;
+            MsdfHipBatch *b = NULL;
+            int r = msdfhip_batch_create_on(&b, devices[k], g1-g0, lgco.data(), lco.data(), points+(size_t) e0*8, types+e0, colors+e0);
+            if (r == MSDFHIP_OK) {
+                r = out ? runPipeline(b, mode, w, h, glyphs+g0, out, outFloats, NULL, 0, NULL, cfg)
+                        : runPipeline(b, mode, w, h, glyphs+g0, NULL, 0, atlas, atlasBytes, NULL, cfg);
+                msdfhip_batch_destroy(b);
+            }
+            rcs[k] = r;
+            if (r != MSDFHIP_OK)
+                errors[k] = tlsError;
+        }));
+    for (size_t k = 0; k < workers.size(); ++k)
+        workers[k].join();
+    for (int k = 0; k < n_devices; ++k)
+        if (rcs[k] != MSDFHIP_OK) {
+            tlsError = errors[k];
+            return rcs[k];
+        }
+    return MSDFHIP_OK;
 }
 
 // ------------------------------------------------------------------------------------------- single-shape host calls
 
-// Per-thread resources of the single-shape host-pointer calls: one stream, one device arena, one pinned staging buffer. They grow
-// on demand and are reused, so a steady stream of generate*() calls from a host thread (the way msdf-atlas-gen's workers call the
-// reference) performs no allocation: stage -> async H2D -> kernels -> async D2H -> one stream sync. Never freed (thread exit /
-// process teardown order makes that unsafe); bounded by the largest call the thread ever made.
+// Resources of one host-pointer call in flight: a stream, a device arena, a pinned staging buffer. They grow on demand and are
+// reused, so a steady stream of generate*() calls (the way msdf-atlas-gen's workers call the reference) performs no allocation:
+// stage -> async H2D -> kernels -> async D2H -> one stream sync. Arenas live in a process-wide pool per device: a call takes one and
+// returns it, so short-lived worker threads (msdf-atlas-gen spawns a fresh team per Workload::finish()) reuse them instead of
+// leaking one per thread; the pool is bounded by the peak number of concurrent calls.
 struct ThreadArena {
     int device;
     hipStream_t stream;
     char *dev, *pinned;
     size_t devCap, pinnedCap;
 };
-static thread_local ThreadArena tlsArena = { -1, NULL, NULL, NULL, 0, 0 };
+
+static std::mutex gArenaMutex;
+static std::vector<ThreadArena *> gArenaPool;
+
+struct ArenaLease {
+    ThreadArena *a;
+    ArenaLease() : a(NULL) { }
+    ~ArenaLease() {
+        if (a) {
+            std::lock_guard<std::mutex> lock(gArenaMutex);
+            gArenaPool.push_back(a);
+        }
+    }
+    int take(int device) {
+        {
+            std::lock_guard<std::mutex> lock(gArenaMutex);
+            for (size_t i = gArenaPool.size(); i-- > 0; )
+                if (gArenaPool[i]->device == device) {
+                    a = gArenaPool[i];
+                    gArenaPool.erase(gArenaPool.begin()+i);
+                    return MSDFHIP_OK;
+                }
+        }
+        ThreadArena *fresh = new ThreadArena();
+        fresh->device = device, fresh->stream = NULL, fresh->dev = fresh->pinned = NULL, fresh->devCap = fresh->pinnedCap = 0;
+        if (hipStreamCreateWithFlags(&fresh->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete fresh;
+            return fail(MSDFHIP_ERR_HIP, "hipStreamCreate failed");
+        }
+        a = fresh;
+        return MSDFHIP_OK;
+    }
+};
 
 static int arenaReserve(ThreadArena &a, size_t devBytes, size_t pinnedBytes) {
-    const int device = gDevice.load();
-    if (a.device != device) {                                    // first use on this thread, or the process switched device
-        a.device = device, a.stream = NULL, a.dev = a.pinned = NULL, a.devCap = a.pinnedCap = 0;
-        HIPCHK(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
-    }
     if (a.devCap < devBytes) {
         if (a.dev)
             HIPCHK(hipFree(a.dev));
@@ -1082,7 +1536,7 @@ static int runGroup(ShapeCall *const *calls, int n) {
         const int nE = c.co[c.nC];
         sumC += c.nC, sumE += nE;
         maxC = c.nC > maxC ? c.nC : maxC, maxE = nE > maxE ? nE : maxE;
-        anyStencil = anyStencil || c.stencil != NULL;
+        anyStencil = anyStencil || (c.stencil != NULL && correct);   // no correction pass: the reference leaves the caller's buffer untouched
     }
     const size_t texels = (size_t) w*h, tileBytes = texels*channels*sizeof(float);
     const size_t eAlloc = sumE > 0 ? sumE : 1, cAlloc = sumC > 0 ? sumC : 1;
@@ -1101,7 +1555,11 @@ static int runGroup(ShapeCall *const *calls, int n) {
     dc.off = hc.off;
     const size_t dRecs = dc.take(eAlloc*sizeof(EdgeRec)), dWind = dc.take(cAlloc), dScratch = dc.take(n*tileBytes*stages);
     const size_t dCands = dc.take(correct ? candCap*sizeof(EcCandidate) : 0), dParams = dc.take(n*sizeof(EcGlyphParams));
-    ThreadArena &a = tlsArena;
+    ArenaLease lease;
+    rc = lease.take(currentDevice());
+    if (rc != MSDFHIP_OK)
+        return rc;
+    ThreadArena &a = *lease.a;
     rc = arenaReserve(a, dc.off, hc.off);
     if (rc != MSDFHIP_OK)
         return rc;
@@ -1136,6 +1594,7 @@ static int runGroup(ShapeCall *const *calls, int n) {
     HIPCHK(hipMemcpyAsync(a.dev, a.pinned, inputBytes, hipMemcpyHostToDevice, a.stream));
 
     MsdfHipBatch b;                                              // non-owning view into the arena
+    b.device = a.device;
     b.nGlyphs = n, b.nContours = (int) sumC, b.nEdges = (int) sumE, b.maxContours = maxC, b.maxEdges = maxE;
     b.ownsInputs = false;
     b.dGlyphContourOffsets = reinterpret_cast<int32_t *>(a.dev+hGco);
@@ -1145,15 +1604,15 @@ static int runGroup(ShapeCall *const *calls, int n) {
     b.dColors = reinterpret_cast<uint8_t *>(a.dev+hColors);
     b.dRecs = reinterpret_cast<EdgeRec *>(a.dev+dRecs);
     b.dWindings = reinterpret_cast<int8_t *>(a.dev+dWind);
-    b.dScratch = NULL, b.scratchFloats = 0;
     b.dDeferred = correct ? reinterpret_cast<EcCandidate *>(a.dev+dCands) : NULL;
     b.deferredCap = correct ? candCap : 0;
     b.dEcParams = reinterpret_cast<EcGlyphParams *>(a.dev+dParams);
-    b.dGres = NULL, b.gresBytes = 0;
-    b.bucketLimit = -1, b.dBucket = NULL, b.nSmall = 0, b.smallMaxC = 0;
     b.hContours.resize((size_t) n);
-    for (int g = 0; g < n; ++g)
+    b.hEdges.resize((size_t) n);
+    for (int g = 0; g < n; ++g) {
         b.hContours[g] = calls[g]->nC;
+        b.hEdges[g] = calls[g]->co[calls[g]->nC];
+    }
     struct Owned {                                               // workspaces the launches may have allocated for this view (many-contour shapes)
         MsdfHipBatch &b;
         ~Owned() { hipFree(b.dGres); hipFree(b.dBucket); }
@@ -1185,7 +1644,7 @@ static int runGroup(ShapeCall *const *calls, int n) {
         const float *tile = reinterpret_cast<const float *>(a.pinned+hOut)+(size_t) g*texels*channels;
         for (int y = 0; y < h; ++y)
             memcpy(c.pixels+(ptrdiff_t) c.rowStride*y, tile+(size_t) y*w*channels, sizeof(float)*(size_t) w*channels);
-        if (c.stencil)
+        if (c.stencil && anyStencil)
             memcpy(c.stencil, a.pinned+hStencil+(size_t) g*texels, texels);
     }
     gNsStage += t1-t0, gNsDevice += t2-t1, gNsScatter += nowNs()-t2;
@@ -1350,7 +1809,11 @@ int msdfhip_render_sdf_host(float *out, int ow, int oh, int outStride, int no, c
     const size_t inBytes = sizeof(float)*(size_t) sw*sh*ns, outBytes = sizeof(float)*(size_t) ow*oh*no;
     Carver c;
     const size_t offIn = c.take(inBytes), offOut = c.take(outBytes);
-    ThreadArena &a = tlsArena;
+    ArenaLease lease;
+    rc = lease.take(currentDevice());
+    if (rc != MSDFHIP_OK)
+        return rc;
+    ThreadArena &a = *lease.a;
     rc = arenaReserve(a, c.off, c.off);
     if (rc != MSDFHIP_OK)
         return rc;
@@ -1379,7 +1842,11 @@ int msdfhip_simulate_8bit_host(float *pixels, int w, int h, int rowStride, int c
     if (rc != MSDFHIP_OK)
         return rc;
     const size_t bytes = sizeof(float)*(size_t) w*h*channels;
-    ThreadArena &a = tlsArena;
+    ArenaLease lease;
+    rc = lease.take(currentDevice());
+    if (rc != MSDFHIP_OK)
+        return rc;
+    ThreadArena &a = *lease.a;
     rc = arenaReserve(a, bytes, bytes);
     if (rc != MSDFHIP_OK)
         return rc;

@@ -15,6 +15,7 @@
 // All bounds are inflated by a relative 1e-6 so that rounding in the bounds themselves can never flip an exact tie.
 #pragma once
 
+#include <string.h>
 #include "msdf_device.hpp"
 
 namespace msdfhip {
@@ -54,6 +55,21 @@ MSDF_HD bool cullEdgeSurvives(const EdgeRec &e, V2 c, double r, double Umax) {
     }
     return false;
 }
+
+// Walk order of a contour's survivors: nearest first (ascending key), so that the per-texel relevance test (selEdgeRelevant) can
+// drop most of the others -- the selector's result does not depend on the order (Selector::idx). The key is the squared distance
+// from the tile centre to the nearest of three on-curve points, as non-negative float bits with the low four mantissa bits replaced
+// by the edge's position within its group of 16 (keys are then unique within a group: a plain rank is a permutation).
+MSDF_HD unsigned cullOrderKey(const EdgeRec &e, V2 c, int slot) {
+    const V2 a = c-ld(e.p), b = c-endPoint(e), m = c-ld(e.mid);
+    const float d2 = (float) dmin(dmin(dot(a, a), dot(b, b)), dot(m, m));
+    unsigned bits;
+    memcpy(&bits, &d2, sizeof(bits));
+    if (!(bits < 0x7f800000u))
+        bits = 0x7f7ffff0u;                                      // inf / nan (degenerate input): still ahead of the non-survivors
+    return (bits&~15u)|(unsigned) (slot&15);
+}
+#define MSDF_CULL_KEY_DROPPED 0x7f800000u                        // non-survivors: behind every survivor
 
 // Channel mask with which an edge takes part in selector SEL (1: all edges one "channel"; 2: ditto; 3/4: its colour bits).
 template <int SEL>

@@ -316,20 +316,62 @@ MSDF_HD SD sdLinear(const EdgeRec &e, V2 o, double &param) {                 // 
     return r;
 }
 
+// The three roots of solveCubicNormed's trigonometric branch (equation-solver.cpp:41-53), produced ONE AT A TIME: q*cos(arg_i)-a3.
+// Evaluating them inside the (rolled) candidate loop of sdQuadratic keeps a single cosine's temporaries live instead of three
+// interleaved evaluations -- the quadratic path was what set the kernel's register demand (134 VGPRs for the plain SDF selector).
+MSDF_HD double cosThirdsOne(double t, int i) {
+    const double arg = i == 0 ? 1/3.*t : i == 1 ? 1/3.*(t+2*M_PI) : 1/3.*(t-2*M_PI);     // the reference's own argument arithmetic
+#if defined(MSDF_USE_LEAN_MATH)
+    return cosZeroToPi(fabs(arg));                   // [0, pi/3], [2pi/3, pi], [-2pi/3, -pi/3] (cos is even)
+#else
+    return cos(arg);
+#endif
+}
+
 MSDF_HD SD sdQuadratic(const EdgeRec &e, V2 o, double &param) {              // edge-segments.cpp:187-226
     V2 p0 = ld(e.p), p1 = ld(e.p+2), p2 = ld(e.p+4), ab = ld(e.ab), br = ld(e.br);
     V2 qa = p0-o;
-    double c = e.k[2]+dot(qa, br);
-    double d = dot(qa, ab);
-    double t[3] = { 0, 0, 0 };
-    int solutions;
     const bool fast = (e.flags&REC_FASTDIV) != 0;
-    if (e.flags&REC_NORMED) {                                                 // solveCubic, equation-solver.cpp:63-70
-        const double cn = fast ? divExact(c, e.k[0], e.rcp[0]) : c/e.k[0];
-        const double dn = fast ? divExact(d, e.k[0], e.rcp[0]) : d/e.k[0];
-        solutions = solveCubicNormedPre(t, e.k[3], e.k[4], e.k[5], cn, dn);
-    } else
-        solutions = solveQuadratic(t, e.k[1], c, d);
+
+    // solveCubic (equation-solver.cpp:63-70) up to the point where the roots are formed; the roots themselves follow lazily below
+    double x0 = 0, x1 = 0, trigT = 0, trigQ = 0;
+    int solutions;
+    bool trig = false;
+    {
+        const double c = e.k[2]+dot(qa, br);
+        const double d = dot(qa, ab);
+        if (e.flags&REC_NORMED) {                                             // solveCubicNormed, equation-solver.cpp:34-61 (a, a*a, a/3 from the record)
+            const double b = fast ? divExact(c, e.k[0], e.rcp[0]) : c/e.k[0];
+            const double cc = fast ? divExact(d, e.k[0], e.rcp[0]) : d/e.k[0];
+            const double a = e.k[3], a2 = e.k[4];
+            double q = 1/9.*(a2-3*b);
+            const double r = 1/54.*(a*(2*a2-9*b)+27*cc);
+            const double r2 = r*r;
+            const double q3 = q*q*q;
+            if (r2 < q3) {
+                double t = r/sqrt(q3);
+                if (t < -1) t = -1;
+                if (t > 1) t = 1;
+                trigT = acos(t);
+                trigQ = -2*sqrt(q);
+                trig = true;
+                solutions = 3;
+            } else {
+                const double u = (r < 0 ? 1. : -1.)*powThird(fabs(r)+sqrt(r2-q3));
+                const double v = u == 0 ? 0 : q/u;
+                x0 = (u+v)-e.k[5];
+                solutions = 1;
+                if (u == v || fabs(u-v) < 1e-12*fabs(u+v)) {
+                    x1 = -.5*(u+v)-e.k[5];
+                    solutions = 2;
+                }
+            }
+        } else {
+            double t[2] = { 0, 0 };
+            solutions = solveQuadratic(t, e.k[1], c, d);
+            x0 = t[0], x1 = t[1];
+        }
+    }
 
     V2 epDir = ld(e.ep0);
     double minDistance = nonZeroSign(cross(epDir, qa))*vlen(qa);
@@ -343,14 +385,17 @@ MSDF_HD SD sdQuadratic(const EdgeRec &e, V2 o, double &param) {              // 
             param = fast ? divExact(dot(o-p1, epDir), e.e1dot, e.rcp[2]) : dot(o-p1, epDir)/e.e1dot;
         }
     }
-    MSDF_UNROLL
-    for (int i = 0; i < 3; ++i) {                                             // fixed trip count keeps t[] in registers
-        if (i < solutions && t[i] > 0 && t[i] < 1) {
-            V2 qe = qa+(2*t[i])*ab+(t[i]*t[i])*br;
-            double distance = vlen(qe);
-            if (distance <= fabs(minDistance)) {
-                minDistance = nonZeroSign(cross(ab+t[i]*br, qe))*distance;
-                param = t[i];
+    MSDF_NOUNROLL
+    for (int i = 0; i < 3; ++i) {
+        if (i < solutions) {
+            const double ti = trig ? trigQ*cosThirdsOne(trigT, i)-e.k[5] : i == 0 ? x0 : x1;
+            if (ti > 0 && ti < 1) {
+                V2 qe = qa+(2*ti)*ab+(ti*ti)*br;
+                double distance = vlen(qe);
+                if (distance <= fabs(minDistance)) {
+                    minDistance = nonZeroSign(cross(ab+ti*br, qe))*distance;
+                    param = ti;
+                }
             }
         }
     }
@@ -418,6 +463,11 @@ MSDF_HD SD sdCubic(const EdgeRec &e, V2 o, double &param) {                  // 
 }
 
 MSDF_HD SD signedDistance(const EdgeRec &e, V2 o, double &param) {
+#if defined(MSDF_ONLY_TYPE)
+    if (MSDF_ONLY_TYPE == 1) return sdLinear(e, o, param);
+    if (MSDF_ONLY_TYPE == 2) return sdQuadratic(e, o, param);
+    if (MSDF_ONLY_TYPE == 3) return sdCubic(e, o, param);
+#endif
     if (e.type == 1)
         return sdLinear(e, o, param);
     if (e.type == 2)
@@ -456,28 +506,29 @@ MSDF_HD void distanceToPerpendicular(const EdgeRec &e, SD &distance, V2 o, doubl
 
 // --------------------------------------------------------------------------------------------------------- selectors
 
-struct PB {                              // PerpendicularDistanceSelectorBase, edge-selectors.h:40-70
+// PerpendicularDistanceSelectorBase (edge-selectors.h:40-70) with the nearest edge replaced by what computeDistance() derives
+// from it. The reference remembers (nearEdge, nearEdgeParam) and, at the end, calls
+//   nearEdge->distanceToPerpendicularDistance(minTrueDistance, p, nearEdgeParam)                        (edge-selectors.cpp:110-113)
+// -- a function of the winning edge, its own signed distance / param and the query point only. All of these are at hand (the
+// record in scalar registers) at the moment an edge BECOMES the nearest one, so the converted distance is evaluated right there and
+// travels with the minimum: through later updates, through merge() (edge-selectors.cpp:96-106, the winner's value is the merged
+// selector's value) and into computeDistance(). One register pair instead of (index, param), and no per-lane gather of a record at
+// the end of every contour. Same operands, same operations, same result.
+struct PB {
     double td, tdot;                     // minTrueDistance
+    double perp;                         // distanceToPerpendicularDistance of it w.r.t. the nearest edge; meaningful iff td != -DBL_MAX
     double neg, pos;                     // min negative / positive perpendicular distance
-    double param;                        // nearEdgeParam
-    int near;                            // record index of nearEdge, -1 = NULL
 };
 
 MSDF_HD void pbInit(PB &b) {             // edge-selectors.cpp:54 followed by reset(delta): -DBL_MAX-delta == -DBL_MAX for any realistic delta
     b.td = -DBL_MAX, b.tdot = 0;
+    b.perp = 0;
     b.neg = -DBL_MAX, b.pos = DBL_MAX;
-    b.param = 0;
-    b.near = -1;
 }
 
-MSDF_HD void pbAddTrue(PB &b, int idx, SD sd, double param) {                // edge-selectors.cpp:81-87
-    SD cur = { b.td, b.tdot };
-    if (sdLess(sd, cur)) {
-        b.td = sd.d, b.tdot = sd.dot;
-        b.near = idx;
-        b.param = param;
-    }
-}
+// nearEdge != NULL: an edge replaces the initial minimum only with |distance| < DBL_MAX (SignedDistance <, SignedDistance.hpp:22-24;
+// the tie-break dot is never negative), so a stored minimum is never -DBL_MAX again.
+MSDF_HD bool pbHasNear(const PB &b) { return b.td != -DBL_MAX; }
 
 MSDF_HD void pbAddPerp(PB &b, double d) {                                    // edge-selectors.cpp:89-94
     if (d <= 0 && d > b.neg)
@@ -488,37 +539,18 @@ MSDF_HD void pbAddPerp(PB &b, double d) {                                    // 
 
 MSDF_HD void pbMerge(PB &b, const PB &o) {                                   // edge-selectors.cpp:96-106
     SD a = { o.td, o.tdot }, c = { b.td, b.tdot };
-    if (sdLess(a, c)) {
-        b.td = o.td, b.tdot = o.tdot;
-        b.near = o.near;
-        b.param = o.param;
-    }
+    if (sdLess(a, c))
+        b.td = o.td, b.tdot = o.tdot, b.perp = o.perp;
     if (o.neg > b.neg)
         b.neg = o.neg;
     if (o.pos < b.pos)
         b.pos = o.pos;
 }
 
-// The nearest edge's true distance converted to a perpendicular distance where the reference does so (edge-selectors.cpp:111-113).
-MSDF_HD double pbNearestPerp(const PB &b, const EdgeRec *rec, V2 o) {
-    SD sd = { b.td, b.tdot };
-    distanceToPerpendicular(rec[b.near], sd, o, b.param);
-    return sd.d;
-}
-
-// Where an Edges policy gets that value from: by default from the nearest edge's record (a per-lane gather).
-struct PerpFromRecords {
-    MSDF_HD double nearestPerp(const PB &b, const EdgeRec *rec, V2 o) const { return pbNearestPerp(b, rec, o); }
-};
-
-template <class Edges>
-MSDF_HD double pbCompute(const PB &b, const EdgeRec *rec, V2 o, const Edges &edges) {   // edge-selectors.cpp:108-117
+MSDF_HD double pbCompute(const PB &b) {                                      // edge-selectors.cpp:108-117
     double m = b.td < 0 ? b.neg : b.pos;
-    if (b.near >= 0) {
-        const double perp = edges.nearestPerp(b, rec, o);
-        if (fabs(perp) < fabs(m))
-            m = perp;
-    }
+    if (pbHasNear(b) && fabs(b.perp) < fabs(m))
+        m = b.perp;
     return m;
 }
 
@@ -541,13 +573,28 @@ template <int SEL>
 struct Selector {
     SD m;                                        // TrueDistanceSelector::minDistance (SEL == 1)
     PB c[(int) SelTraits<SEL>::NPB > 0 ? (int) SelTraits<SEL>::NPB : 1];
+    // Visit index (position in the reference's visit order, ShapeDistanceFinder.hpp:45-57) of the edge that holds each minimum.
+    // The reference feeds a contour's edges in visit order and replaces the minimum only on a strict SignedDistance <, so among
+    // exactly tied edges (shared corner points: common) the FIRST VISITED wins. Keeping the index makes that rule explicit and the
+    // result independent of the order in which a contour's edges are fed -- the kernel walks them nearest-first, which lets the
+    // per-texel relevance test drop most of the others. Only compared within one contour; merges never look at it.
+    int idx[(int) SelTraits<SEL>::NPB > 0 ? (int) SelTraits<SEL>::NPB : 1];
 };
 
 template <int SEL>
 MSDF_HD void selInit(Selector<SEL> &s) {
     s.m.d = -DBL_MAX, s.m.dot = 0;
-    for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
+    s.idx[0] = 0x7fffffff;
+    for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i) {
         pbInit(s.c[i]);
+        s.idx[i] = 0x7fffffff;
+    }
+}
+
+// sd replaces the current minimum cur (held by the edge visited at curIdx): SignedDistance < (SignedDistance.hpp:22-24), or an exact
+// tie with an edge that the reference would have visited earlier.
+MSDF_HD bool sdReplaces(SD sd, int idx, SD cur, int curIdx) {
+    return sdLess(sd, cur) || (fabs(sd.d) == fabs(cur.d) && sd.dot == cur.dot && idx < curIdx);
 }
 
 // addEdge: edge-selectors.cpp:19-29 (true), :129-160 (perpendicular), :174-227 (multi)
@@ -556,8 +603,8 @@ MSDF_HD void selAddEdge(Selector<SEL> &s, const EdgeRec &e, int idx, V2 o) {
     if (SEL == 1) {
         double dummy;
         SD sd = signedDistance(e, o, dummy);
-        if (sdLess(sd, s.m))
-            s.m = sd;
+        if (sdReplaces(sd, idx, s.m, s.idx[0]))
+            s.m = sd, s.idx[0] = idx;
         return;
     }
     const int mask = SEL == 2 ? 1 : (e.color&7);
@@ -565,9 +612,20 @@ MSDF_HD void selAddEdge(Selector<SEL> &s, const EdgeRec &e, int idx, V2 o) {
         return;                                  // MultiDistanceSelector ignores BLACK edges (edge-selectors.cpp:175-179)
     double param;
     SD sd = signedDistance(e, o, param);
-    for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
-        if (mask&(1<<i))
-            pbAddTrue(s.c[i], idx, sd, param);
+    bool nearer[(int) SelTraits<SEL>::NPB > 0 ? (int) SelTraits<SEL>::NPB : 1];
+    bool any = false;
+    for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i) {                     // addEdgeTrueDistance, edge-selectors.cpp:81-87
+        SD cur = { s.c[i].td, s.c[i].tdot };
+        nearer[i] = (mask&(1<<i)) && sdReplaces(sd, idx, cur, s.idx[i]);
+        any = any || nearer[i];
+    }
+    if (any) {
+        SD conv = sd;                            // what computeDistance() would make of this edge, were it still the nearest then
+        distanceToPerpendicular(e, conv, o, param);
+        for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
+            if (nearer[i])
+                s.c[i].td = sd.d, s.c[i].tdot = sd.dot, s.c[i].perp = conv.d, s.idx[i] = idx;
+    }
     V2 ap = o-ld(e.p);
     V2 bp = o-endPoint(e);
     double add = dot(ap, ld(e.na));
@@ -655,14 +713,14 @@ MSDF_HD void selMerge(Selector<SEL> &s, const Selector<SEL> &o) {            // 
 }
 
 // distance(): edge-selectors.cpp:36, :162, :235-260. out has NCH entries.
-template <int SEL, class Edges>
-MSDF_HD void selDistance(const Selector<SEL> &s, const EdgeRec *rec, V2 o, double *out, const Edges &edges) {
+template <int SEL>
+MSDF_HD void selDistance(const Selector<SEL> &s, double *out) {
     if (SEL == 1) {
         out[0] = s.m.d;
         return;
     }
     for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
-        out[i] = pbCompute(s.c[i], rec, o, edges);
+        out[i] = pbCompute(s.c[i]);
     if (SEL == 4) {                                                           // trueDistance(), :243-250
         SD t = { s.c[0].td, s.c[0].tdot };
         SD g = { s.c[SEL == 4 ? 1 : 0].td, s.c[SEL == 4 ? 1 : 0].tdot };
@@ -689,13 +747,13 @@ MSDF_HD double resolve(const double *d) {                                    // 
 // res:      per-lane scratch for the per-contour distances of the overlapping combiner, element (c, ch) at res[(c*NCH+ch)*rstride].
 
 // Edge enumeration of one glyph for the per-texel loops: contour c owns positions [begin(c), end(c)); at(k) is the record index.
-struct EdgesAll : PerpFromRecords {     // every edge, straight from the CSR offsets
+struct EdgesAll {                       // every edge, straight from the CSR offsets
     const int32_t *coff;
     MSDF_HD int begin(int c) const { return coff[c]-coff[0]; }
     MSDF_HD int end(int c) const { return coff[c+1]-coff[0]; }
     MSDF_HD int at(int k) const { return k; }
 };
-struct EdgesCulled : PerpFromRecords {  // survivors of the per-tile cull (msdf_cull.hpp), still grouped by contour and in visit order
+struct EdgesCulled {                    // survivors of the per-tile cull (msdf_cull.hpp), still grouped by contour and in visit order
     const int *cstart;                  // C+1 compacted offsets
     const int *list;                    // record index per position, or NULL if the surviving records were copied in this order
     MSDF_HD int begin(int c) const { return MSDF_UNIFORM(cstart[c]); }
@@ -723,42 +781,90 @@ MSDF_HD void shapeDistanceSimple(const EdgeRec *rec, const Edges &edges, int C, 
     selInit(sel);
     for (int c = 0; c < C; ++c)
         selAddContour(sel, rec, edges, c, o);
-    selDistance(sel, rec, o, out, edges);
+    selDistance(sel, out);
 }
 
+// OverlappingContourCombiner::distance (contour-combiners.cpp:77-134), restructured around what a lane has to REMEMBER.
+// The reference keeps three merged selectors (shape / inner / outer) next to the contour being walked. Here only the shape one is
+// kept; for the other two a lane counts the member contours it has seen and remembers the first:
+//   no member   -> the merged selector is still in its initial state: every channel -DBL_MAX;
+//   one member  -> merge(initial, contour) is that contour's own selector, its distance is the res[] entry of the contour (bitwise);
+//   2+ members  -> (nested / overlapping contours around this texel) the member contours are walked a second time and merged in
+//                  contour order, exactly the sequence of merges the reference performs. Membership is re-derived from res[].
+// The second walk is wave-uniform (any lane needing it) and rare for font outlines; it buys 60 fewer live registers per lane than
+// three merged selectors, which is what lets the kernel run without scratch spills. All walks share ONE instance of the edge loop
+// (pass 0: every contour; pass 1 / 2: the members of the inner / outer selector) to keep the kernel's code and register demand down.
 template <int SEL, class Edges>
 MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const int8_t *windings, int C, V2 o, double *res, int rstride, double *out) {
-    enum { NCH = SelTraits<SEL>::NCH };                                      // OverlappingContourCombiner::distance, contour-combiners.cpp:77-134
-    if (C == 1) {
-        // One contour: the shape/inner/outer selectors can only ever hold that contour's own state, and every branch of
-        // contour-combiners.cpp:104-133 then returns that contour's distance -- identical to the simple combiner.
-        shapeDistanceSimple<SEL>(rec, edges, C, o, out);
-        return;
-    }
-    Selector<SEL> shapeSel, innerSel, outerSel;
-    selInit(shapeSel);
-    selInit(innerSel);
-    selInit(outerSel);
-    for (int c = 0; c < C; ++c) {
-        Selector<SEL> sel;
-        selInit(sel);
-        selAddContour(sel, rec, edges, c, o);
-        double d[NCH];
-        selDistance(sel, rec, o, d, edges);
-        for (int ch = 0; ch < NCH; ++ch)
-            res[(c*NCH+ch)*rstride] = d[ch];
-        const double m = resolve<SEL>(d);
-        const int w = windings[c];
-        selMerge(shapeSel, sel);
-        if (w > 0 && m >= 0)
-            selMerge(innerSel, sel);
-        if (w < 0 && m <= 0)
-            selMerge(outerSel, sel);
-    }
+    enum { NCH = SelTraits<SEL>::NCH };
+    Selector<SEL> acc;                               // pass 0: the shape selector; pass 1 / 2: the inner / outer selector of the lanes that need one
+    int nInner = 0, nOuter = 0, firstInner = 0, firstOuter = 0;
     double shapeD[NCH], innerD[NCH], outerD[NCH];
-    selDistance(shapeSel, rec, o, shapeD, edges);
-    selDistance(innerSel, rec, o, innerD, edges);
-    selDistance(outerSel, rec, o, outerD, edges);
+    for (int ch = 0; ch < NCH; ++ch)
+        shapeD[ch] = innerD[ch] = outerD[ch] = -DBL_MAX;
+    MSDF_NOUNROLL
+    for (int pass = 0; pass < 3; ++pass) {
+        const bool mine = pass == 1 ? nInner >= 2 : nOuter >= 2;
+        if (pass > 0 && !MSDF_WAVE_ANY(mine))
+            continue;
+        selInit(acc);
+        MSDF_NOUNROLL
+        for (int c = 0; c < C; ++c) {
+            bool member = false;
+            if (pass > 0) {
+                const int w = windings[c];
+                if (pass == 1 ? !(w > 0) : !(w < 0))
+                    continue;
+                double cd[NCH];
+                for (int ch = 0; ch < NCH; ++ch)
+                    cd[ch] = res[(c*NCH+ch)*rstride];
+                const double m = resolve<SEL>(cd);
+                member = mine && (pass == 1 ? m >= 0 : m <= 0);
+                if (!MSDF_WAVE_ANY(member))
+                    continue;
+            }
+            Selector<SEL> sel;
+            selInit(sel);
+            selAddContour(sel, rec, edges, c, o);
+            if (pass == 0 && C == 1) {
+                // One contour: the shape/inner/outer selectors can only ever hold that contour's own state, and every branch of
+                // contour-combiners.cpp:104-133 then returns that contour's distance -- identical to the simple combiner.
+                selDistance(sel, out);
+                return;
+            }
+            if (pass == 0) {
+                double d[NCH];
+                selDistance(sel, d);
+                for (int ch = 0; ch < NCH; ++ch)
+                    res[(c*NCH+ch)*rstride] = d[ch];
+                const double m = resolve<SEL>(d);
+                const int w = windings[c];
+                selMerge(acc, sel);
+                if (w > 0 && m >= 0) {
+                    if (!nInner)
+                        firstInner = c;
+                    ++nInner;
+                }
+                if (w < 0 && m <= 0) {
+                    if (!nOuter)
+                        firstOuter = c;
+                    ++nOuter;
+                }
+            } else if (member)
+                selMerge(acc, sel);
+        }
+        if (pass == 0)
+            selDistance(acc, shapeD);
+        else if (mine)
+            selDistance(acc, pass == 1 ? innerD : outerD);
+    }
+    // merged selector with exactly one member == that member's own selector; with none, the initial state (every channel -DBL_MAX)
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (nInner == 1)
+            innerD[ch] = res[(firstInner*NCH+ch)*rstride];
+        if (nOuter == 1)
+            outerD[ch] = res[(firstOuter*NCH+ch)*rstride];
+    }
     const double innerScalar = resolve<SEL>(innerD);
     const double outerScalar = resolve<SEL>(outerD);
     double dist[NCH];

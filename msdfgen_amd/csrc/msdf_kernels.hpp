@@ -160,6 +160,16 @@ __device__ inline float rowMinNonNegative(float v, int lane) {
     return __int_as_float(__shfl(x, lane|15));
 }
 
+// Rank of this lane's key among the 16 keys of its DPP row (keys unique within a row): number of smaller keys. VALU only.
+__device__ inline int rowRank(unsigned key) {
+    int rank = 0;
+#define MSDF_DPP_ROR(n) rank += (unsigned) __builtin_amdgcn_update_dpp((int) key, (int) key, 0x120+n, 0xf, 0xf, false) < key ? 1 : 0;
+    MSDF_DPP_ROR(1) MSDF_DPP_ROR(2) MSDF_DPP_ROR(3) MSDF_DPP_ROR(4) MSDF_DPP_ROR(5) MSDF_DPP_ROR(6) MSDF_DPP_ROR(7) MSDF_DPP_ROR(8)
+    MSDF_DPP_ROR(9) MSDF_DPP_ROR(10) MSDF_DPP_ROR(11) MSDF_DPP_ROR(12) MSDF_DPP_ROR(13) MSDF_DPP_ROR(14) MSDF_DPP_ROR(15)
+#undef MSDF_DPP_ROR
+    return rank;
+}
+
 enum { QUAD = 4 };   // tiles per wavefront of the LDS-scratch variant (the global-scratch variant, GRES, takes one: measured faster there)
 
 template <int SEL, bool OVERLAP, bool GRES = false>
@@ -244,10 +254,14 @@ k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, i
 #endif
                         }
                     }
+                    // survivors of each group of 16 edges (one DPP row) go to the list nearest-first; groups stay in visit order
+                    const unsigned key = keep ? cullOrderKey(rec[i], tc, col) : (MSDF_CULL_KEY_DROPPED|(unsigned) (col&15));
+                    const int rank = rowRank(key);
                     const unsigned long long ballot = __ballot(keep);
                     const unsigned long long rowBallot = TPW == 1 ? ballot : (ballot>>(ROW*q))&0xffffull;
+                    const int before = TPW == 1 ? __popcll(ballot&((1ull<<(col&~15))-1ull)) : 0;     // survivors in the earlier rows of a 64-lane chunk
                     if (keep)
-                        list[nSurv+__popcll(rowBallot&((1ull<<col)-1ull))] = i;
+                        list[nSurv+before+rank] = i;
                     nSurv += __popcll(rowBallot);
                 }
             }
@@ -312,10 +326,10 @@ struct PsdfQuery {                                                  // ShapeDist
 };
 
 // Edge policy for a WAVE-UNIFORM query point: the 64 lanes evaluate 64 edges of the contour at once, then the single-edge selector
-// states are merged across lanes in visit order. pbMerge keeps the earlier state on ties exactly like the sequential pbAddTrue
+// states are merged across lanes in visit order. pbMerge keeps the earlier state on ties exactly like the sequential addEdge
 // (strict SignedDistance <, edge-selectors.cpp:81-87, :96-106) and max/min of the perpendicular distances do not depend on the
 // order, so the merged state -- identical in every lane afterwards -- equals the sequential one bit for bit.
-struct PBSlot { double td, tdot, neg, pos, param, perp; int near, pad; };   // a single-edge selector state parked in LDS (56 B); perp: pbNearestPerp of it
+typedef PB PBSlot;                                                  // a single-edge selector state parked in LDS (40 B)
 
 struct EdgesCooperative {
     const int32_t *coff;
@@ -324,15 +338,13 @@ struct EdgesCooperative {
     int nE;
     MSDF_HD int begin(int c) const { return coff[c]-coff[0]; }
     MSDF_HD int end(int c) const { return coff[c+1]-coff[0]; }
-    // The winner of any merge is one of the single-edge states, whose converted distance was evaluated alongside it (same operands:
-    // the edge's own true distance, dot, param and the query point) -- no second visit to the record.
-    __device__ double nearestPerp(const PB &b, const EdgeRec *rec, V2 o) const { return slots ? slots[b.near].perp : pbNearestPerp(b, rec, o); }
 };
 
 __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const EdgesCooperative &edges, int c, V2 o) {
     if (edges.slots) {
         // All edges of the glyph at once (lanes = edges, whatever their contour), states parked in LDS; every contour then merges its
         // own slots in visit order -- a handful of uniform LDS reads per edge instead of a cross-lane reduction per contour.
+        // (Slots are filled when contour 0 is walked: the first walk of every query starts there, later walks reuse them.)
         if (c == 0) {
             for (int base = 0; base < edges.nE; base += WAVE) {
                 const int i = base+edges.lane;
@@ -340,20 +352,14 @@ __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const
                     Selector<2> mine;
                     selInit(mine);
                     selAddEdge(mine, rec[i], i, o);
-                    const PB &m = mine.c[0];
-                    PBSlot slot;
-                    slot.td = m.td, slot.tdot = m.tdot, slot.neg = m.neg, slot.pos = m.pos, slot.param = m.param, slot.near = m.near, slot.pad = 0;
-                    slot.perp = m.near >= 0 ? pbNearestPerp(m, rec, o) : 0.;
-                    edges.slots[i] = slot;
+                    edges.slots[i] = mine.c[0];
                 }
             }
             waveSync();
         }
         const int e = edges.end(c);
         for (int i = edges.begin(c); i < e; ++i) {
-            const PBSlot slot = edges.slots[i];
-            PB one;
-            one.td = slot.td, one.tdot = slot.tdot, one.neg = slot.neg, one.pos = slot.pos, one.param = slot.param, one.near = slot.near;
+            const PBSlot one = edges.slots[i];
             pbMerge(sel.c[0], one);
         }
         return;
@@ -369,15 +375,13 @@ __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const
         MSDF_UNROLL
         for (int off = 1; off < WAVE; off <<= 1) {                  // lane l <- merge(l, l+off): the lower lane is the earlier edge
             PB other;
-            other.td = __shfl_down(m.td, off), other.tdot = __shfl_down(m.tdot, off);
+            other.td = __shfl_down(m.td, off), other.tdot = __shfl_down(m.tdot, off), other.perp = __shfl_down(m.perp, off);
             other.neg = __shfl_down(m.neg, off), other.pos = __shfl_down(m.pos, off);
-            other.param = __shfl_down(m.param, off), other.near = __shfl_down(m.near, off);
             if (edges.lane+off < WAVE)
                 pbMerge(m, other);
         }
         PB all;                                                     // lane 0 holds the chunk's state: broadcast
-        all.td = __shfl(m.td, 0), all.tdot = __shfl(m.tdot, 0), all.neg = __shfl(m.neg, 0), all.pos = __shfl(m.pos, 0);
-        all.param = __shfl(m.param, 0), all.near = __shfl(m.near, 0);
+        all.td = __shfl(m.td, 0), all.tdot = __shfl(m.tdot, 0), all.perp = __shfl(m.perp, 0), all.neg = __shfl(m.neg, 0), all.pos = __shfl(m.pos, 0);
         pbMerge(sel.c[0], all);                                     // chunks in order; the running state is the earlier one
     }
 }
@@ -434,6 +438,13 @@ struct CandidateSink {
             header[0] = 1u;
     }
 };
+
+// Where the stencil byte of the texel in the bitmap's memory row yn goes: the reference's stencil keeps its rows in upward order
+// whatever the bitmap's orientation (core/msdf-error-correction.cpp:19, core/MSDFErrorCorrection.cpp:122,192,415); texel = index of
+// the texel in the packed field [g][h][w] (memory rows).
+MSDF_HD size_t stencilIndex(size_t texel, int yn, int width, int height, int stencilYDown) {
+    return stencilYDown ? texel+(size_t) (height-1-2*yn)*width : texel;
+}
 
 // Per-glyph constants of the error-correction pass (protectEdges radii, findErrors spans, texel size: MSDFErrorCorrection.cpp:90,
 // 194-226, 387-389): 3 sqrt + 8 divisions that every texel of a glyph shares, computed once per glyph instead of once per wavefront.
@@ -647,7 +658,7 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
     for (int i = 0; i < N; ++i)
         px[i] = v[i];
     if (stencilOut)
-        stencilOut[texel] = (uint8_t) st;
+        stencilOut[stencilIndex(texel, yn, width, height, cfg.stencil_y_down)] = (uint8_t) st;
 }
 
 // The deferred distance checks: a wavefront takes candidates of ONE glyph, one candidate at a time, and its 64 lanes evaluate the
@@ -712,7 +723,7 @@ k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, c
                     float *px = out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
                     px[0] = m, px[1] = m, px[2] = m;
                     if (stencilOut)
-                        stencilOut[texel] |= (uint8_t) EC_ERROR;
+                        stencilOut[stencilIndex(texel, yn, width, height, cfg.stencil_y_down)] |= (uint8_t) EC_ERROR;
                 }
             }
             continue;
@@ -733,7 +744,7 @@ k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, c
                 float *px = out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
                 px[0] = m, px[1] = m, px[2] = m;
                 if (stencilOut)
-                    stencilOut[texel] |= (uint8_t) EC_ERROR;
+                    stencilOut[stencilIndex(texel, yn, width, height, cfg.stencil_y_down)] |= (uint8_t) EC_ERROR;
             }
         }
     }
@@ -788,7 +799,7 @@ k_ec_slow(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, co
         for (int k = 0; k < N; ++k)
             px[k] = v[k];
         if (stencilOut)
-            stencilOut[texel] = (uint8_t) st;
+            stencilOut[stencilIndex(texel, yn, width, height, cfg.stencil_y_down)] = (uint8_t) st;
     }
 }
 

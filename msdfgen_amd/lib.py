@@ -32,7 +32,7 @@ class Config(C.Structure):
     """MsdfHipConfig == MSDFGeneratorConfig + ErrorCorrectionConfig (core/generator-config.h:13-64)."""
     _fields_ = [("overlap_support", C.c_int32), ("ec_mode", C.c_int32), ("ec_distance_check", C.c_int32), ("ec_stage_limit", C.c_int32),
                 ("min_deviation_ratio", C.c_double), ("min_improve_ratio", C.c_double),
-                ("sign_correction", C.c_int32), ("fill_rule", C.c_int32), ("sdf_zero_value", C.c_float), ("reserved", C.c_int32)]
+                ("sign_correction", C.c_int32), ("fill_rule", C.c_int32), ("sdf_zero_value", C.c_float), ("stencil_y_down", C.c_int32)]
 
 
 class PrepConfig(C.Structure):
@@ -78,7 +78,16 @@ _PROTOS = {
     "msdfhip_batch_destroy": (None, [_vp]),
     "msdfhip_batch_windings": (C.c_int, [_vp, _ip]),
     "msdfhip_batch_generate": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(Config), _vp]),
-    "msdfhip_batch_generate_host": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(Glyph), _fp, C.c_size_t, _bp, C.POINTER(Config)]),
+    "msdfhip_batch_generate_host": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp, C.POINTER(Config)]),
+    "msdfhip_batch_generate_bytes_host": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, C.POINTER(Config)]),
+    "msdfhip_set_pipeline_chunk": (C.c_int, [C.c_int]),
+    "msdfhip_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
+    "msdfhip_host_free": (C.c_int, [_vp]),
+    "msdfhip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "msdfhip_batch_create_on": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _ip, _ip, _dp, _bp, _bp]),
+    "msdfhip_batch_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "msdfhip_generate_sharded": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, _bp, _bp, _vp, _vp, C.c_size_t, _vp, C.c_size_t,
+                                           C.POINTER(Config)]),
     "msdfhip_tiles_to_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "msdfhip_batch_estimate_sdf_error": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "msdfhip_render_sdf": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_float, _vp]),
@@ -121,7 +130,7 @@ def load(build_if_missing=True):
             fn = getattr(lib, name)  # AttributeError here == a symbol of include/msdfgen_hip.h is missing from the library
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.msdfhip_abi_version() != 3:
+        if lib.msdfhip_abi_version() != 4:
             raise MsdfHipError(ERR_INVALID, "ABI version mismatch")
         _lib = lib
         return lib

@@ -66,9 +66,12 @@ void transformationToXf(const SDFTransformation &t, double xf[6]) {
     double raw[2];
     std::memcpy(raw, &t.distanceMapping, sizeof(raw));
     const double probes[3] = { 0., 1., -.375 };
-    for (int i = 0; i < 3; ++i)
-        if (!(raw[0]*(probes[i]+raw[1]) == t.distanceMapping(probes[i])))
+    for (int i = 0; i < 3; ++i) {
+        // bit patterns, not ==: a degenerate Range(0) maps to inf*(x-0) = nan on both sides, which the reference simply writes out
+        const double mine = raw[0]*(probes[i]+raw[1]), theirs = t.distanceMapping(probes[i]);
+        if (std::memcmp(&mine, &theirs, sizeof(double)) != 0 && !(mine != mine && theirs != theirs))
             throw std::runtime_error("msdfgen_hip shim: DistanceMapping layout does not match {scale, translate}");
+    }
     xf[4] = raw[0], xf[5] = raw[1];
 }
 
@@ -96,7 +99,8 @@ void generate(int mode, const BitmapSection<float, N> &output, const Shape &shap
     flatten(shape, flat);
     double xf[6];
     transformationToXf(transformation, xf);
-    const MsdfHipConfig cfg = makeConfig(overlapSupport, ec);
+    MsdfHipConfig cfg = makeConfig(overlapSupport, ec);
+    cfg.stencil_y_down = output.yOrientation == Y_DOWNWARD;                // row order of ErrorCorrectionConfig::buffer, see msdfgen_hip.h
     const int flip = shape.getYAxisOrientation() != output.yOrientation;   // output.reorient(shape.getYAxisOrientation()), core/msdfgen.cpp:55
     check(msdfhip_generate(mode, output.pixels, output.width, output.height, output.rowStride, flip, flat.contourOffsets.data(),
                            (int) shape.contours.size(), flat.points.data(), flat.types.data(), flat.colors.data(), xf, &cfg, ec ? ec->buffer : NULL),
@@ -109,7 +113,8 @@ void correct(const BitmapSection<float, N> &sdf, const Shape &shape, const SDFTr
     flatten(shape, flat);
     double xf[6];
     transformationToXf(transformation, xf);
-    const MsdfHipConfig cfg = makeConfig(config.overlapSupport, &config.errorCorrection);
+    MsdfHipConfig cfg = makeConfig(config.overlapSupport, &config.errorCorrection);
+    cfg.stencil_y_down = sdf.yOrientation == Y_DOWNWARD;
     const int flip = shape.getYAxisOrientation() != sdf.yOrientation;
     check(msdfhip_error_correction(N, sdf.pixels, sdf.width, sdf.height, sdf.rowStride, flip, flat.contourOffsets.data(), (int) shape.contours.size(),
                                    flat.points.data(), flat.types.data(), flat.colors.data(), xf, &cfg, config.errorCorrection.buffer),

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 
 #include "../../msdfgen_amd/csrc/msdf_device.hpp"
 #include "../../msdfgen_amd/csrc/msdf_prep.hpp"
@@ -81,16 +82,23 @@ TileCull cullTile(const Digest &d, const int32_t *co, int nC, bool overlap, cons
         }
         for (int c = cBegin; c < cEnd; ++c) {
             tcull.cstart.push_back((int) tcull.list.size());
-            for (int i = co[c]-co[0]; i < co[c+1]-co[0]; ++i) {
-                const int mask = cullMask<SEL>(d.recs[i]);
-                if (!mask)
-                    continue;
-                double umax = 0;
-                for (int ch = 0; ch < 3; ++ch)
-                    if ((mask>>ch)&1)
-                        umax = dmax(umax, U[ch]);
-                if (cullEdgeSurvives<(SEL >= 2)>(d.recs[i], tc, tr, umax))
-                    tcull.list.push_back(i);
+            const int cb = co[c]-co[0], ce = co[c+1]-co[0];
+            for (int group = cb; group < ce; group += 16) {                  // one DPP row of phase 1: its survivors are listed nearest-first
+                std::vector<std::pair<unsigned, int> > keyed;
+                for (int i = group; i < ce && i < group+16; ++i) {
+                    const int mask = cullMask<SEL>(d.recs[i]);
+                    if (!mask)
+                        continue;
+                    double umax = 0;
+                    for (int ch = 0; ch < 3; ++ch)
+                        if ((mask>>ch)&1)
+                            umax = dmax(umax, U[ch]);
+                    if (cullEdgeSurvives<(SEL >= 2)>(d.recs[i], tc, tr, umax))
+                        keyed.push_back(std::make_pair(cullOrderKey(d.recs[i], tc, i-group), i));
+                }
+                std::sort(keyed.begin(), keyed.end());
+                for (size_t k = 0; k < keyed.size(); ++k)
+                    tcull.list.push_back(keyed[k].second);
             }
         }
     }
@@ -433,8 +441,6 @@ extern "C" void emu_rasterize(float *pixels, int w, int h, int rowStride, int fl
 namespace msdfhip {
 struct EdgesCoopEmu {
     bool slotted;                       // true: the kernel's LDS-slot path (all edges first, then a serial merge per contour)
-    std::vector<double> *perps;         // slotted: pbNearestPerp of every single-edge state (PBSlot::perp)
-    double nearestPerp(const PB &b, const EdgeRec *rec, V2 o) const { return slotted ? (*perps)[b.near] : pbNearestPerp(b, rec, o); }
     const int32_t *coff;
     int begin(int c) const { return coff[c]-coff[0]; }
     int end(int c) const { return coff[c+1]-coff[0]; }
@@ -445,7 +451,6 @@ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const EdgesCoopE
             Selector<2> mine;
             selInit(mine);
             selAddEdge(mine, rec[i], i, o);
-            (*edges.perps)[i] = mine.c[0].near >= 0 ? pbNearestPerp(mine.c[0], rec, o) : 0.;
             pbMerge(sel.c[0], mine.c[0]);
         }
         return;
@@ -483,8 +488,6 @@ extern "C" void emu_psdf_cooperative(int overlap, int nC, const int32_t *co, con
     edges.coff = co;
     edges.slotted = overlap >= 2;
     overlap &= 1;
-    std::vector<double> perps((size_t) co[nC]+1);
-    edges.perps = &perps;
     for (int i = 0; i < n; ++i) {
         double o[1] = { 0 };
         const V2 q = mk(pts[2*i], pts[2*i+1]);
@@ -568,6 +571,65 @@ extern "C" double emu_estimate_sdf_error(int N, const float *px, int w, int h, i
             error += v;
         }
     return error/((h-1)*scanlinesPerRow);
+}
+
+// Diagnostics (tools only): wave-level cost model of phase 2. For one glyph: number of (tile, edge) evaluations a wavefront performs
+// with the current tile cull and the per-texel wave vote, for the simple (overlap = 0) or overlapping combiner, optionally walking
+// each contour's survivors nearest-first (order = 1: ascending cullUpperDistance at the tile centre) instead of in visit order.
+// out[0] = evaluations, out[1] = survivors of the tile cull, out[2] = tiles, out[3] = contour walks (tile x contour with >= 1 survivor).
+extern "C" void emu_wave_cost(int w, int h, int nC, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors,
+                              const double *xf, int overlap, int order, long *out) {
+    Digest d = digest(nC, co, points, types, colors);
+    Xform t = { xf[0], xf[1], xf[2], xf[3], xf[4], xf[5] };
+    for (int ty = 0; ty < (h+7)/8; ++ty)
+        for (int tx = 0; tx < (w+7)/8; ++tx) {
+            TileCull tc = cullTile<3>(d, co, nC, overlap != 0, t, tx, ty, 8);
+            const V2 centre = unproject(t, mk(tx*8+4., ty*8+4.));
+            ++out[2];
+            out[1] += (long) tc.list.size();
+            Selector<3> sel[64];
+            for (int l = 0; l < 64; ++l)
+                selInit(sel[l]);
+            for (int c = 0; c < nC; ++c) {
+                if (overlap)
+                    for (int l = 0; l < 64; ++l)
+                        selInit(sel[l]);
+                std::vector<int> walk(tc.list.begin()+tc.cstart[c], tc.list.begin()+tc.cstart[c+1]);
+                if (!walk.empty())
+                    ++out[3];
+                auto nearer = [&](int a, int b) { return cullUpperDistance(d.recs[a], centre) < cullUpperDistance(d.recs[b], centre); };
+                if (order == 1)
+                    std::stable_sort(walk.begin(), walk.end(), nearer);
+                else if (order == 2 && !walk.empty())                        // only the nearest moves to the front
+                    std::rotate(walk.begin(), std::min_element(walk.begin(), walk.end(), nearer), walk.end());
+                else if (order >= 16) {                                      // sorted within chunks of `order` consecutive EDGES of the contour (phase-1 lanes)
+                    const int b0 = co[c]-co[0];
+                    size_t from = 0;
+                    while (from < walk.size()) {
+                        size_t to = from;
+                        while (to < walk.size() && (walk[to]-b0)/order == (walk[from]-b0)/order)
+                            ++to;
+                        std::stable_sort(walk.begin()+from, walk.begin()+to, nearer);
+                        from = to;
+                    }
+                }
+                for (size_t k = 0; k < walk.size(); ++k) {
+                    const int i = walk[k];
+                    int relevant = 0;
+                    for (int l = 0; l < 64; ++l) {
+                        const V2 p = unproject(t, mk(tx*8+(l&7)+.5, ty*8+(l>>3)+.5));
+                        relevant += selEdgeRelevant(sel[l], d.recs[i], p);
+                    }
+                    if (!relevant)
+                        continue;
+                    ++out[0];
+                    for (int l = 0; l < 64; ++l) {
+                        const V2 p = unproject(t, mk(tx*8+(l&7)+.5, ty*8+(l>>3)+.5));
+                        selAddEdge(sel[l], d.recs[i], i, p);
+                    }
+                }
+            }
+        }
 }
 
 // Diagnostics (tools only): lockstep walk of phase 2 of k_distance over one glyph, per-contour selectors as in the overlapping

@@ -83,6 +83,11 @@ def test_config4_single_shape_calls_match_the_batch(dejavu):
 
 
 def test_config5_logo_1024_every_texel_and_stencil(oracle):
+    """Pin (tools/make_golden_full.py:logo): the reference's exact per-texel evaluation (ShapeDistanceFinder::oneShotDistance, mapped as
+    DistanceMapping does) at all 1 048 576 texel centres, then the reference's msdfErrorCorrection on that field. The reference's
+    generateMSDF itself walks the texels with a per-edge cache (edge-selectors.cpp:64-79) whose pruning is not exact on this shape: the
+    fixture lists the texel(s) where it departs from its own exact evaluation (1 texel, by 3e-5); there the device must equal the exact
+    value, everywhere else all three agree."""
     z = load_npz("logo1024.npz")
     s = FlatShape(z["contour_offsets"], z["points"], z["types"].astype(np.int32), z["colors"].astype(np.int32))
     xf = z["xf"]
@@ -91,20 +96,28 @@ def test_config5_logo_1024_every_texel_and_stencil(oracle):
     stencil = np.zeros((1024, 1024), np.uint8)
     out = M.generate_msdf(np.zeros((1024, 1024, 3), np.float32), s, t, M.MSDFGeneratorConfig(True, M.ErrorCorrectionConfig(buffer=stencil)))
     y0, x0 = (int(v) for v in z["crop_origin"])
-    ok = (sha(pre) == z["sha_pre"]).all() and (sha(out) == z["sha_out"]).all() and (sha(stencil) == z["sha_stencil"]).all()
+    pre_ok = (sha(pre) == z["sha_pre"]).all()
+    if not pre_ok:                                                            # hold the differing rows to the 1e-5 contract against the oracle
+        rows = [y for y in range(1024) if not (sha(pre[y]) == z["sha_pre_rows"][y]).all()]
+        assert len(rows) <= 8, "pre-correction field: %d rows differ from the reference" % len(rows)
+        for y in rows:
+            pts = np.stack([(np.arange(1024)+.5)/xf[0]-xf[2], np.full(1024, (y+.5)/xf[1]-xf[3])], 1)
+            want = (np.float64(1)/(xf[5]-xf[4])*(oracle.shape_distance(s, 3, True, pts)[:, :3]+(-xf[4]))).astype(np.float32)
+            assert (sha(want) == z["sha_pre_rows"][y]).all(), "the oracle disagrees with the reference fixture in row %d" % y
+            assert float(np.abs(pre[y].astype(np.float64)-want).max()) <= TOL, "row %d" % y
+    for (yy, xx), exact, cached in zip(z["cached_diff_yx"], z["exact_values_there"], z["cached_diff_values"]):
+        assert (bits(pre[yy, xx]) == bits(exact)).all() or not pre_ok
+        assert float(np.abs(exact.astype(np.float64)-cached).max()) < 1e-4     # what the reference's cached walk writes there instead
+    ok = pre_ok and (sha(out) == z["sha_out"]).all() and (sha(stencil) == z["sha_stencil"]).all()
     if not ok:
-        # localise, then hold the whole bitmap to the 1e-5 contract against the oracle (minutes of CPU: only on a mismatch)
-        rows = [y for y in range(1024) if not (sha(out[y]) == z["sha_rows"][y]).all()]
-        srows = [y for y in range(1024) if not (sha(stencil[y]) == z["sha_stencil_rows"][y]).all()]
         want_st = np.zeros((1024, 1024), np.uint8)
-        want = oracle.generate(s, 3, 1024, 1024, xf, stencil=want_st)
-        assert (sha(want) == z["sha_out"]).all() and (sha(want_st) == z["sha_stencil"]).all(), "the oracle disagrees with the reference fixture"
-        d = np.abs(out.astype(np.float64)-want)
+        want = oracle.error_correction(s, pre, xf, stencil=want_st)           # the oracle's correction pass == the reference's (bit-exact, CPU tests)
         nbits = int((bits(out) != bits(want)).sum())
-        assert float(d.max()) <= TOL, "logo 1024x1024: max |delta| %.3g, %d values differ bitwise, rows %s" % (float(d.max()), nbits, rows[:8])
-        assert nbits <= 16 and int((stencil != want_st).sum()) <= 16, (nbits, rows[:8], srows[:8])
-    assert (bits(out[y0:y0+64, x0:x0+64]) == bits(z["crop_out"])).all() or not ok
-    assert (stencil[y0:y0+64, x0:x0+64] == z["crop_stencil"]).all() or not ok
-    assert int((stencil & 1).sum()) == int(z["n_error"]) or not ok
-    print("config 5: 1024x1024 msdf + error correction %s the compiled reference (%d ERROR texels)" % (
-        "bit-identical to" if ok else "within 1e-5 of", int((stencil & 1).sum())))
+        assert nbits == 0 and (stencil == want_st).all(), "error correction of the 1024x1024 field: %d values / %d stencil bytes differ" % (
+            nbits, int((stencil != want_st).sum()))
+    else:
+        assert (bits(out[y0:y0+64, x0:x0+64]) == bits(z["crop_out"])).all()
+        assert (stencil[y0:y0+64, x0:x0+64] == z["crop_stencil"]).all()
+        assert int((stencil & 1).sum()) == int(z["n_error"])
+    print("config 5: 1024x1024 msdf + error correction %s the compiled reference's exact evaluation (%d ERROR texels; the reference's cached walk "
+          "differs from it at %d texel(s))" % ("bit-identical to" if ok else "within 1e-5 of", int((stencil & 1).sum()), len(z["cached_diff_yx"])))

@@ -687,3 +687,26 @@ def test_candidate_segment_overflow_is_handled_per_glyph(latin, oracle):
         want = oracle.error_correction(s, noisy, xf, ec_mode=2, ec_dist=dist)
         got = M.msdf_error_correction(noisy.copy(), s, M.SDFTransformation.from_xf(xf), cfg(ec_dist=dist))
         close(got, want, "standalone correction of a noisy field, distance check %d" % dist)
+
+
+def test_stencil_rows_follow_the_reference_for_y_downward_bitmaps(ref):
+    """ErrorCorrectionConfig::buffer keeps its rows in upward order whatever the bitmap's orientation (core/msdf-error-correction.cpp:19,
+    core/MSDFErrorCorrection.cpp:122,192,415): compared with the compiled reference for all four shape / bitmap orientations,
+    and left untouched when no correction pass runs."""
+    z = load_npz("latin.npz")
+    batch = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
+                       z["colors"].astype(np.int32), z["inverse_y"], [str(n) for n in z["names"]])
+    g = batch.names.index("U+0040")
+    for inv in (False, True):
+        s = batch.shape(g)
+        s.inverse_y = inv
+        for y_down in (False, True):
+            want_st = np.zeros((64, 64), np.uint8)
+            want = ref.generate(s, 3, 64, 64, z["xf64"][g], y_down=y_down, stencil=want_st)
+            got_st = np.full((64, 64), 77, np.uint8)
+            got = gen(3, s, 64, 64, z["xf64"][g], cfg(buffer=got_st), y_down=y_down)
+            close(got, want, "tile, shape inverse_y=%s bitmap y_down=%s" % (inv, y_down))
+            assert (got_st == want_st).all(), (inv, y_down, int((got_st != want_st).sum()))
+    untouched = np.full((64, 64), 77, np.uint8)
+    gen(3, batch.shape(g), 64, 64, z["xf64"][g], cfg(ec_mode=M.EC_DISABLED, buffer=untouched))
+    assert (untouched == 77).all()

@@ -1,0 +1,168 @@
+"""The end-to-end host-memory path (msdfhip_batch_generate_host / _bytes_host: chunked two-stream pipeline), per-batch device binding
+and the glyph-sharded multi-device generator (msdfhip_generate_sharded), through the C ABI on a real MI355X.  Everything here is
+byte-exact by construction (same kernels, different plumbing), so the assertions are on bits."""
+import threading
+
+import numpy as np
+import pytest
+
+import msdfgen_amd as M
+from conftest import load_npz, bits
+from msdfgen_amd import lib as L
+from msdfgen_amd.shape import ShapeBatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    M.init(0)
+
+
+@pytest.fixture(scope="module")
+def glyphs():
+    """1 500 distinct DejaVu glyphs (every fifth of the config-4 fixture: mixes 1..43 contours) + their 48x48 frames and reference hashes."""
+    z = load_npz("dejavu8192.npz")
+    full = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
+                      z["colors"].astype(np.int32), np.zeros(len(z["names"]), bool), [str(n) for n in z["names"]])
+    idx = list(range(0, 7500, 5))
+    sub = full.select(idx)
+    want = M.GlyphBatch(sub).generate(M.MODE_MSDF, 48, 48, z["xf48"][idx]).cpu().numpy()
+    return sub, z["xf48"][idx], want
+
+
+def test_host_pipeline_packed_matches_device_batch(glyphs):
+    sub, xfs, want = glyphs
+    hb = M.HostBatch(sub)
+    try:
+        for chunk in (0, 256, 1000, 4096):                                    # automatic; several chunks + a ragged last one; one chunk
+            L.load().msdfhip_set_pipeline_chunk(chunk)
+            out = M.host_alloc((sub.n_glyphs, 48, 48, 3))
+            out[:] = 7
+            st = np.zeros((sub.n_glyphs, 48, 48), np.uint8)
+            hb.generate_host(M.MODE_MSDF, 48, 48, xfs, out=out, stencil=st)
+            assert (bits(out) == bits(want)).all(), "chunk %d" % chunk
+            assert st.any() and ((st & ~3) == 0).all()
+            M.host_free(out)
+        out = hb.generate_host(M.MODE_MSDF, 48, 48, xfs)                      # pageable output
+        assert (bits(out) == bits(want)).all()
+        sdf = hb.generate_host(M.MODE_SDF, 48, 48, xfs)
+        assert (bits(sdf) == bits(M.GlyphBatch(sub).generate(M.MODE_SDF, 48, 48, xfs).cpu().numpy())).all()
+    finally:
+        L.load().msdfhip_set_pipeline_chunk(0)
+        hb.close()
+
+
+def test_host_pipeline_atlas_rectangles_preserve_the_rest(glyphs):
+    """Tiles as rectangles of one larger float atlas (BitmapSection of a bigger bitmap, core/BitmapRef.hpp:74-111), every second glyph
+    with a negative row stride (bottom-up rows); texels outside the rectangles keep the caller's values."""
+    sub, xfs, want = glyphs
+    n = 600
+    part = sub.select(list(range(n)))
+    cols = 25
+    rows = (n+cols-1)//cols
+    pad = 3
+    aw, ah = cols*(48+pad), rows*(48+pad)
+    atlas = np.full((ah, aw, 3), -5., np.float32)
+    offs, strides = np.zeros(n, np.int64), np.zeros(n, np.int32)
+    for g in range(n):
+        x0, y0 = (g % cols)*(48+pad)+1, (g//cols)*(48+pad)+2
+        if g % 2:
+            offs[g], strides[g] = ((y0+47)*aw+x0)*3, -aw*3
+        else:
+            offs[g], strides[g] = (y0*aw+x0)*3, aw*3
+    hb = M.HostBatch(part)
+    try:
+        L.load().msdfhip_set_pipeline_chunk(128)
+        hb.generate_host(M.MODE_MSDF, 48, 48, xfs[:n], out=atlas, out_offsets=offs, row_stride=strides)
+    finally:
+        L.load().msdfhip_set_pipeline_chunk(0)
+        hb.close()
+    covered = np.zeros((ah, aw), bool)
+    for g in range(n):
+        x0, y0 = (g % cols)*(48+pad)+1, (g//cols)*(48+pad)+2
+        rect = atlas[y0:y0+48, x0:x0+48]
+        tile = want[g][::-1] if g % 2 else want[g]
+        assert (bits(rect) == bits(tile)).all(), g
+        covered[y0:y0+48, x0:x0+48] = True
+    assert (atlas[~covered] == -5.).all()
+
+
+def test_bytes_pipeline_matches_pixel_float_to_byte(glyphs, oracle):
+    sub, xfs, want = glyphs
+    n = 1024
+    part = sub.select(list(range(n)))
+    cols = 32
+    aw = cols*48
+    atlas = np.full((n//cols*48, aw, 3), 9, np.uint8)
+    offs = np.array([((g//cols)*48*aw+(g % cols)*48)*3 for g in range(n)], np.int64)
+    hb = M.HostBatch(part)
+    try:
+        L.load().msdfhip_set_pipeline_chunk(160)
+        hb.generate_bytes_host(M.MODE_MSDF, 48, 48, xfs[:n], atlas, offs, aw*3)
+        packed = np.zeros((n, 48, 48, 3), np.uint8)                           # byte tiles in glyph order: the per-chunk contiguous copy path
+        hb.generate_bytes_host(M.MODE_MSDF, 48, 48, xfs[:n], packed, np.arange(n, dtype=np.int64)*48*48*3, 48*3)
+    finally:
+        L.load().msdfhip_set_pipeline_chunk(0)
+        hb.close()
+    ref = oracle.pixel_float_to_byte(want[:n])
+    assert (packed == ref).all()
+    for g in range(0, n, 7):
+        y0, x0 = (g//cols)*48, (g % cols)*48
+        assert (atlas[y0:y0+48, x0:x0+48] == ref[g]).all(), g
+
+
+def test_sharded_over_the_same_device_is_byte_identical(glyphs):
+    """msdfhip_generate_sharded with the one GPU of the box listed 1, 2 and 5 times: each entry is its own host thread + batch + streams
+    (what runs on 8 GPUs with devices = 0..7); the bytes must not depend on the split."""
+    sub, xfs, want = glyphs
+    assert L.load().msdfhip_device_count is not None
+    for devices in ([0], [0, 0], [0, 0, 0, 0, 0]):
+        out = M.generate_sharded(devices, sub, M.MODE_MSDF, 48, 48, xfs)
+        assert (bits(out) == bits(want)).all(), devices
+    atlas = np.zeros((sub.n_glyphs, 48, 48, 3), np.uint8)
+    M.generate_sharded([0, 0, 0], sub, M.MODE_MSDF, 48, 48, xfs, atlas=atlas, out_offsets=np.arange(sub.n_glyphs, dtype=np.int64)*48*48*3, row_stride=48*3)
+    assert atlas.any()
+    with pytest.raises(M.MsdfHipError):
+        M.generate_sharded([0, 99], sub, M.MODE_MSDF, 48, 48, xfs)
+
+
+def test_batch_remembers_its_device(glyphs):
+    sub, xfs, want = glyphs
+    hb = M.HostBatch(sub.select([0, 1, 2]), device=0)
+    assert hb.device == 0
+    hb.close()
+    with pytest.raises(M.MsdfHipError):
+        M.HostBatch(sub.select([0]), device=64)
+
+
+def test_device_memory_stays_flat_over_many_calls(glyphs):
+    """Long-running callers: single-shape calls mixing few- and many-contour shapes, and fresh worker threads for every
+    round (msdf-atlas-gen spawns a new team per Workload::finish()), must not grow device or pinned memory."""
+    import torch
+    sub, xfs, want = glyphs
+    n_c = np.diff(sub.glyph_contour_offsets)
+    many = int(np.argmax(n_c))
+    assert n_c[many] >= 10
+    picks = [many, 0, int(np.argsort(n_c)[-2]), 1]
+
+    def work():
+        for g in picks:
+            out = np.zeros((48, 48, 3), np.float32)
+            M.generate_msdf(out, sub.shape(g), M.SDFTransformation.from_xf(xfs[g]))
+            assert (bits(out) == bits(want[g])).all()
+
+    def round_of_threads():
+        ts = [threading.Thread(target=work) for _ in range(6)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+
+    for _ in range(3):
+        round_of_threads()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(25):
+        round_of_threads()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0-free1 < 8 << 20, "device memory grew by %.1f MB over 25 rounds of fresh threads" % ((free0-free1)/2**20)

@@ -61,3 +61,26 @@ def test_two_rank_glyph_sharding_and_gather():
     assert ids0 == ids1 == list(range(94)) and e0 == e1 == edges  # both ranks hold the same, correctly ordered atlas
     work = [sum(edges[lo0:hi0]), sum(edges[lo1:hi1])]
     assert abs(work[0]-work[1]) <= max(edges)+1
+
+
+def test_bench_gpus_2_spawns_two_ranks():
+    """`python bench.py --gpus 2` outside torchrun must launch two ranks itself (--gpus was parsed and ignored). --mock runs the
+    N > 1 control path on CPU: gloo ranks, the real shard computation on the bench workload, barrier + gather, rank 0 prints one line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mock", "--glyphs", "2048"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                                          # rank 0 only
+    r = lines[0]
+    assert r["n_gpus"] == 2 and r["bounds"][0] == 0 and r["bounds"][-1] == 4096
+    assert sum(r["glyphs_per_rank"]) == 4096 and all(g > 0 for g in r["glyphs_per_rank"])
+    e = r["edges_per_rank"]
+    assert abs(e[0]-e[1]) < 0.02*sum(e), e                                    # balanced by cost, not by count
+    # a launch with a mismatching torchrun world is refused rather than silently benchmarking one rank
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mock"], capture_output=True, text=True, timeout=120, env=env2)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr+p.stdout)

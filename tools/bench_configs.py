@@ -58,7 +58,7 @@ def main():
     latin, xf64 = load_latin()
 
     def report(name, batch, mode, w, h, xfs, config=None, reps=args.reps, **kw):
-        if args.only and args.only not in name:
+        if args.only and not any(k in name for k in args.only.split(",")):
             return
         gb = M.GlyphBatch(batch)
         out = torch.empty((batch.n_glyphs, h, w, M.CHANNELS[mode]), dtype=torch.float32, device="cuda")
@@ -91,7 +91,7 @@ def main():
     report("cfg4: 8192 CJK-like synthetic glyphs msdf 48x48 default EC", cj, 3, 48, 48, cx, reps=max(2, args.reps//3))
     report("cfg4 shapes, simple combiner (overlapSupport=false)", cj, 3, 48, 48, cx, config=M.MSDFGeneratorConfig(False), reps=max(2, args.reps//3))
     report("cfg4 shapes, sdf 48x48", cj, 1, 48, 48, cx, reps=max(2, args.reps//3))
-    if not args.only or "quality" in args.only:                       # row f4: the reference's own quality metric, on the device
+    if not args.only or "quality" in args.only.split(","):                       # row f4: the reference's own quality metric, on the device
         gb = M.GlyphBatch(b)
         tiles = gb.generate(3, 64, 64, x)
         ms = timed(lambda: gb.estimate_sdf_error(tiles, x), max(2, args.reps//3))
@@ -102,7 +102,7 @@ def main():
                           "mean_error": float(err.mean()), "max_error": float(err.max()),
                           "renderSDF_8192_tiles_to_256x256_ms": round(ms_render, 3)}), flush=True)
         gb.close()
-    if not args.only or "prep" in args.only:                          # row f3: raw outlines -> prepared, digested batch (host call, incl. copies)
+    if not args.only or "prep" in args.only.split(","):                          # row f3: raw outlines -> prepared, digested batch (host call, incl. copies)
         import time
         z = np.load(os.path.join(ROOT, "tests", "golden", "prep.npz"))
         raw = ShapeBatch(z["raw_gco"].astype(np.int32), z["raw_co"].astype(np.int32), z["raw_points"], z["raw_types"].astype(np.int32),
@@ -115,6 +115,14 @@ def main():
         dt = (time.perf_counter()-t0)/5
         print(json.dumps({"config": "prep: Shape::normalize + edgeColoringSimple + digest of 8192 raw glyphs (%d edges) via msdfhip_batch_create_prepared, host arrays in, "
                                     "prepared shapes read back" % big.n_edges, "ms_per_call": round(1e3*dt, 3), "glyphs_per_s": round(8192/dt)}), flush=True)
+    zd = np.load(os.path.join(ROOT, "tests", "golden", "dejavu8192.npz"))
+    dj = ShapeBatch(zd["glyph_contour_offsets"].astype(np.int32), zd["contour_offsets"].astype(np.int32), zd["points"], zd["types"].astype(np.int32),
+                    zd["colors"].astype(np.int32), np.zeros(len(zd["names"]), bool), [str(n) for n in zd["names"]])
+    report("cfg4 real fonts: 8192 distinct DejaVuSans+Bold glyphs msdf 48x48 default EC", dj, 3, 48, 48, zd["xf48"], reps=max(2, args.reps//2))
+    report("8192 distinct DejaVuSans+Bold glyphs msdf 64x64 default EC (bench workload)", dj, 3, 64, 64, zd["xf64"], reps=max(2, args.reps//2))
+    report("8192 distinct DejaVu glyphs msdf 64x64, simple combiner", dj, 3, 64, 64, zd["xf64"], config=M.MSDFGeneratorConfig(False), reps=max(2, args.reps//2))
+    report("8192 distinct DejaVu glyphs msdf 64x64, error correction disabled", dj, 3, 64, 64, zd["xf64"],
+           config=M.MSDFGeneratorConfig(True, M.ErrorCorrectionConfig(M.EC_DISABLED)), reps=max(2, args.reps//2))
     logo = synth.logo_shape(5)
     lb = ShapeBatch.from_shapes([logo])
     lx = np.stack([autoframe(logo.bounds(), 1024, 1024, 8)])
