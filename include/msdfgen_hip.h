@@ -207,9 +207,10 @@ int msdfhip_batch_generate(const MsdfHipBatch *batch, int mode, int width, int h
 /* End to end into HOST memory (what replaces an atlas generator's loop of generate*() calls into caller-owned bitmaps,
  * core/msdfgen.cpp:52-76, README.md:133): HOST descriptors, HOST output. The glyph list is processed in chunks on two streams, so the
  * kernels of one chunk overlap the device-to-host copy of the previous one; synchronous for the caller.
- *   glyphs[g].out_offset / row_stride place tile g in `out` (floats). When the tiles are packed in glyph order (out_offset = g*w*h*N,
- *   row_stride = w*N) every chunk is one contiguous copy; any other placement (rectangles of a larger atlas, negative strides) goes
- *   through a device mirror of the whole buffer (uploaded first so that texels outside the rectangles survive, copied back once).
+ *   glyphs[g].out_offset / row_stride place tile g in `out` (floats). When the tiles are packed in glyph order (out_offset =
+ *   base + g*w*h*N, row_stride = w*N) every chunk is ONE contiguous copy straight into `out`; any other placement (rectangles of a
+ *   larger atlas, negative strides) is copied into pinned staging and scattered row by row on the host while the next chunk runs --
+ *   texels outside the rectangles are never touched.
  *   stencil: NULL or n_glyphs*width*height bytes; written only when an error-correction pass runs (like the reference's buffer).
  * For full copy speed `out` should be pinned (msdfhip_host_alloc); pageable memory works, the runtime then stages the copies. */
 int msdfhip_batch_generate_host(const MsdfHipBatch *batch, int mode, int width, int height, const MsdfHipGlyph *glyphs,
@@ -228,8 +229,9 @@ int msdfhip_host_free(void *p);
 /* Glyph-sharded generation on several devices of one node: the glyph list (HOST CSR arrays as for
  * msdfhip_batch_create) is cut into n_devices contiguous ranges balanced by edge count; one host thread per entry of `devices`
  * uploads its range, runs the pipeline above on that device and copies its tiles straight into the caller's buffer. No exchange
- * between devices; the bytes do not depend on the split (a device may be listed more than once). Exactly one of `out` (float tiles,
- * offsets in floats) and `atlas` (8-bit, offsets in bytes) is non-NULL. */
+ * between devices; the bytes do not depend on the split (a device may be listed more than once), and any tile placement is fine: a
+ * device only ever writes its own glyphs' rectangles. Exactly one of `out` (float tiles, offsets in floats) and `atlas` (8-bit,
+ * offsets in bytes) is non-NULL. */
 int msdfhip_generate_sharded(const int *devices, int n_devices, int mode, int width, int height, int n_glyphs,
                              const int32_t *glyph_contour_offsets, const int32_t *contour_offsets, const double *points, const uint8_t *types,
                              const uint8_t *colors, const MsdfHipGlyph *glyphs, float *out, size_t out_floats, uint8_t *atlas, size_t atlas_bytes,

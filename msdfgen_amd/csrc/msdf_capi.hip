@@ -120,13 +120,17 @@ struct MsdfHipBatch {
     mutable std::vector<int> hEdges;    // edges per glyph (host copy, fetched with hContours)
     mutable int bucketLimit;          // the contour limit dBucket was built for (-1 = none)
     mutable int *dBucket;             // glyph indices: [nOne with <= 1 contour][nSmall with 2..bucketLimit contours][the others]
+    mutable int *hBucket;             // pinned host copy the device list is uploaded from, ON THE LAUNCH STREAM (a synchronous copy of pageable
+                                      // memory may still be in flight on the null stream when a kernel of a non-blocking stream starts)
+    mutable bool bucketExternal;      // dBucket / hBucket belong to someone else (the single-shape calls carve them from their arena)
+    mutable bool bucketUploaded;
     mutable int nOne, nSmall, smallMaxC, smallMaxE, oneMaxE;
     int glyphCap;                     // per-glyph work buffers are sized for max(nGlyphs, glyphCap) glyphs (views of the host-output pipeline)
     mutable PipeSlot *pipe;           // the two slots of the host-output pipeline (msdfhip_batch_generate_host / _bytes_host), lazily created
     mutable std::mutex pipeMutex;     // one host-output call at a time per batch
     MsdfHipBatch() : device(0), nGlyphs(0), nContours(0), nEdges(0), maxContours(0), maxEdges(0), ownsInputs(false), dGlyphContourOffsets(NULL),
                      dContourOffsets(NULL), dPoints(NULL), dTypes(NULL), dColors(NULL), dRecs(NULL), dWindings(NULL), dScratch(NULL), scratchFloats(0),
-                     dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), deferredCap(0), bucketLimit(-1), dBucket(NULL), nOne(0), nSmall(0),
+                     dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
                      smallMaxC(0), smallMaxE(0), oneMaxE(0), glyphCap(0), pipe(NULL) { }
 };
 
@@ -255,7 +259,7 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
 //          simple-combiner kernel, which needs 95 VGPRs instead of ~150 and therefore runs 5 instead of 3 wavefronts per SIMD;
 //   small  2..limit contours: per-contour distances in LDS;
 //   rest   more: per-contour distances in the global workspace.
-int ensureBuckets(const MsdfHipBatch *b, int limit) {
+int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(b->scratchMutex);
     if (b->bucketLimit == limit && b->dBucket)
         return MSDFHIP_OK;
@@ -270,7 +274,14 @@ int ensureBuckets(const MsdfHipBatch *b, int limit) {
             b->hEdges[g] = co[gco[g+1]]-co[gco[g]];
         }
     }
-    std::vector<int> order((size_t) b->nGlyphs);
+    const size_t cap = (size_t) (b->nGlyphs > b->glyphCap ? b->nGlyphs : b->glyphCap > 0 ? b->glyphCap : 1);
+    if (!b->dBucket)
+        HIPCHK(hipMalloc((void **) &b->dBucket, sizeof(int)*cap));
+    if (!b->hBucket)
+        HIPCHK(hipHostMalloc((void **) &b->hBucket, sizeof(int)*cap, hipHostMallocDefault));
+    if (b->bucketUploaded)                                       // an earlier upload from hBucket (same batch, other limit) must have left it
+        HIPCHK(hipStreamSynchronize(stream));
+    int *order = b->hBucket;
     int at = 0, nOne = 0, nSmall = 0, smallMaxC = 0, smallMaxE = 0, oneMaxE = 0;
     for (int g = 0; g < b->nGlyphs; ++g)
         if (b->hContours[g] <= 1) {
@@ -288,9 +299,8 @@ int ensureBuckets(const MsdfHipBatch *b, int limit) {
     for (int g = 0; g < b->nGlyphs; ++g)
         if (b->hContours[g] > 1 && !(b->hContours[g] <= limit && b->hEdges[g] <= SMALL_MAX_EDGES))
             order[at++] = g;
-    if (!b->dBucket)
-        HIPCHK(hipMalloc((void **) &b->dBucket, sizeof(int)*(size_t) (b->nGlyphs > b->glyphCap ? b->nGlyphs : b->glyphCap > 0 ? b->glyphCap : 1)));
-    HIPCHK(hipMemcpy(b->dBucket, order.data(), sizeof(int)*(size_t) b->nGlyphs, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(b->dBucket, b->hBucket, sizeof(int)*(size_t) b->nGlyphs, hipMemcpyHostToDevice, stream));
+    b->bucketUploaded = true;
     b->bucketLimit = limit, b->nOne = nOne, b->nSmall = nSmall, b->smallMaxC = smallMaxC, b->smallMaxE = smallMaxE, b->oneMaxE = oneMaxE;
     return MSDFHIP_OK;
 }
@@ -322,7 +332,7 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
         plan.bytes = ((size_t) b->maxEdges+(size_t) b->maxContours+2)*sizeof(int);
         return launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
     }
-    rc = ensureBuckets(b, limit < 1 ? 1 : limit);
+    rc = ensureBuckets(b, limit < 1 ? 1 : limit, stream);
     if (rc != MSDFHIP_OK)
         return rc;
     const int nRest = b->nGlyphs-b->nOne-b->nSmall;
@@ -351,8 +361,12 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     return MSDFHIP_OK;
 }
 
-// Records of the per-glyph candidate segments incl. the header (msdf_kernels.hpp, EcCandidate).
-size_t deferredRecords(int nGlyphs, size_t texelsPerGlyph) { return ecHeaderRecords(nGlyphs)+(size_t) nGlyphs*ecSegment(texelsPerGlyph); }
+// Records of the per-glyph candidate segments incl. the header (msdf_kernels.hpp, EcCandidate), followed by the work list of
+// k_ec_query: int offsets[nGlyphs+2] (k_ec_scan).
+size_t candidateRecords(int nGlyphs, size_t texelsPerGlyph) { return ecHeaderRecords(nGlyphs)+(size_t) nGlyphs*ecSegment(texelsPerGlyph); }
+size_t deferredRecords(int nGlyphs, size_t texelsPerGlyph) {
+    return candidateRecords(nGlyphs, texelsPerGlyph)+((size_t) (nGlyphs+2)*sizeof(int)+sizeof(EcCandidate)-1)/sizeof(EcCandidate);
+}
 
 int ensureDeferred(const MsdfHipBatch *b, size_t cap, EcCandidate **out) {
     std::lock_guard<std::mutex> lock(b->scratchMutex);
@@ -380,7 +394,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
         return fail(MSDFHIP_ERR_INVALID, "batch of %zu texels exceeds the 32-bit texel index of the error-correction pass; split the batch", allTexels);
     const size_t resBytes = OVERLAP ? (size_t) b->maxContours*WAVE*sizeof(double) : 0;   // combiner scratch of the PSDF distance checks
     const size_t slowLds = GRES ? 0 : resBytes;
-    const unsigned slowGrid = 2048, queryGrid = 1024;
+    const unsigned slowGrid = 2048;
     double *gres = NULL;
     int rc;
     if (GRES) {
@@ -407,30 +421,43 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     rc = ensureDeferred(b, cap, &deferred);
     if (rc != MSDFHIP_OK)
         return rc;
-    // k_ec_query parks the single-edge selector states of a glyph in LDS (48 B per edge) when the glyph has at most slotCap edges
-    const int slotCap = b->maxEdges < 170 ? (b->maxEdges > 0 ? b->maxEdges : 1) : 170;
-    const size_t slotOffset = slowLds/sizeof(double), queryLds = slowLds+(size_t) slotCap*sizeof(PBSlot);
-    rc = setLds(k_ec_query<N, OVERLAP, GRES>, queryLds);
-    if (rc != MSDFHIP_OK)
-        return rc;
+    // k_ec_query parks the single-edge selector states of a glyph in LDS (40 B per edge) when the glyph has at most slotCap edges; its
+    // combiner scratch is one double per contour (wave-uniform query point)
+    const int slotCap = b->maxEdges < 1024 ? (b->maxEdges > 0 ? b->maxEdges : 1) : 1024;
+    // LDS of a query wavefront: the lane-per-candidate scratch [maxContours][64], or (cooperative) [maxContours] + the slots -- one or the other
+    EcQueryPolicy lpcMaxContours;
+    lpcMaxContours.lpcMaxContours = b->maxContours < 192 ? b->maxContours : 192;     // beyond: cooperative only (one double per contour)
+    // Measured on MI355X (post-distance time in ms: Basic-Latin / CJK-like 48x48 / 8192 DejaVu glyphs / 1024x1024 logo):
+    //   cooperative only 1.98 / 5.35 / 2.83 / 4.60;  lane-per-candidate wherever the instruction count favours it 1.76 / 3.57 / 4.23 / 10.3;
+    //   lane-per-candidate only for glyphs of at most 48 edges 1.75 / 5.40 / 2.67 / 4.62  <- default: a chunk of a large glyph is one long
+    //   serial walk that the launch ends up waiting for.
+    lpcMaxContours.lpcEdgeCost = 340, lpcMaxContours.lpcMaxEdges = 48, lpcMaxContours.lpcMinCount = 0x7fffffff;
+    if (const char *env = getenv("MSDFHIP_QUERY_POLICY"))        // experiment knob: "edgeCost,maxEdges,minCount"
+        sscanf(env, "%d,%d,%d", &lpcMaxContours.lpcEdgeCost, &lpcMaxContours.lpcMaxEdges, &lpcMaxContours.lpcMinCount);
+    const size_t resLanes = OVERLAP ? (size_t) (lpcMaxContours.lpcMaxContours > 0 ? lpcMaxContours.lpcMaxContours : 1)*WAVE*sizeof(double) : 0;
+    const int slotOffset = OVERLAP ? (b->maxContours > 0 ? b->maxContours : 1) : 0;
+    const size_t coopLds = (size_t) slotOffset*sizeof(double)+(size_t) slotCap*sizeof(PBSlot);
+    const size_t queryLds = resLanes > coopLds ? resLanes : coopLds;
     const size_t fastLds = ecFastLdsBytes(b->maxEdges, N);
     if (fastLds > (size_t) gLdsLimit.load() || queryLds > (size_t) gLdsLimit.load())
         return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours / %d edges: the error-correction pass needs %zu B of LDS per wavefront, device limit is %d B",
                     b->maxContours, b->maxEdges, fastLds > queryLds ? fastLds : queryLds, gLdsLimit.load());
+    rc = setLds(k_ec_query<N, OVERLAP>, queryLds);
+    if (rc != MSDFHIP_OK)
+        return rc;
     rc = setLds(k_ec_fast<N>, fastLds);
     if (rc != MSDFHIP_OK)
         return rc;
-    // query work units: K wavefronts per glyph, each taking every K-th candidate of the glyph (a handful per glyph is typical)
-    unsigned K = (unsigned) ((16384+b->nGlyphs-1)/b->nGlyphs);
-    K = K < 4 ? 4 : K > seg ? seg : K;
-    const size_t units = (size_t) b->nGlyphs*K;
-    const unsigned queryBlocks = (unsigned) (GRES ? (units < queryGrid ? units : queryGrid) : (units < 0x7fffffffull ? units : 0x7fffffffull));
+    int *offsets = reinterpret_cast<int *>(deferred+candidateRecords(b->nGlyphs, (size_t) w*h));
+    // the query kernel is a pool of wavefronts draining one work list: enough of them to fill the device, no more
+    const unsigned queryBlocks = 8192;                           // (a wavefront that finds the list empty leaves after one atomic)
     hipLaunchKernelGGL(k_ec_params, dim3((b->nGlyphs+255)/256), dim3(256), 0, stream, b->dEcParams, dGlyphs, b->nGlyphs, cfg,
                        reinterpret_cast<unsigned *>(deferred));   // also zeroes the candidate header
     hipLaunchKernelGGL((k_ec_fast<N>), dim3(blocks), dim3(WAVE), fastLds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, src, out, stencil, cfg,
                        (const EcGlyphParams *) b->dEcParams, deferred, seg, b->maxEdges);
-    hipLaunchKernelGGL((k_ec_query<N, OVERLAP, GRES>), dim3(queryBlocks), dim3(WAVE), queryLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
-                       (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, K, gres, gresStride, slotCap, slotOffset);
+    hipLaunchKernelGGL(k_ec_scan, dim3(1), dim3(1024), 0, stream, viewOf(b), reinterpret_cast<const unsigned *>(deferred), seg, offsets, lpcMaxContours);
+    hipLaunchKernelGGL((k_ec_query<N, OVERLAP>), dim3(queryBlocks), dim3(WAVE), queryLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
+                       (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, offsets, slotCap, slotOffset, lpcMaxContours);
     hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowGrid), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
                        (const EcCandidate *) deferred, seg, 1, gres, gresStride);
     HIPCHK(hipGetLastError());
@@ -891,7 +918,11 @@ void msdfhip_batch_destroy(MsdfHipBatch *b) {
     hipFree(b->dDeferred);
     hipFree(b->dEcParams);
     hipFree(b->dGres);
-    hipFree(b->dBucket);
+    if (!b->bucketExternal) {
+        hipFree(b->dBucket);
+        if (b->hBucket)
+            hipHostFree(b->hBucket);
+    }
     delete b;
 }
 
@@ -1085,10 +1116,13 @@ struct PipeSlot {
     hipStream_t stream;
     hipEvent_t done;                  // the slot's last device-to-host copy has finished
     bool busy;
-    char *dev;                        // [descriptors | tiles | stencil | byte staging]
+    char *dev;                        // [descriptors | float tiles | stencil | byte tiles]
     size_t devCap;
-    MsdfHipGlyph *pinnedGlyphs;       // pinned staging of the chunk's descriptors: [cap] for the generators, [cap] for the byte blit
+    MsdfHipGlyph *pinnedGlyphs;       // pinned staging of the chunk's descriptors
     size_t pinnedGlyphCap;
+    char *pinnedTiles;                // pinned staging of the chunk's output when the caller's layout is not packed (scattered on the host)
+    size_t pinnedTilesCap;
+    int pendingFirst, pendingCount;   // the chunk waiting in pinnedTiles for its scatter
     int viewCap;                      // glyphs the view's per-glyph work buffers (class lists, correction constants) were sized for
     MsdfHipBatch view;                // glyph range of the parent batch + this slot's own work buffers
 };
@@ -1107,7 +1141,11 @@ static void destroyPipe(const MsdfHipBatch *b) {
         hipFree(p.dev);
         if (p.pinnedGlyphs)
             hipHostFree(p.pinnedGlyphs);
+        if (p.pinnedTiles)
+            hipHostFree(p.pinnedTiles);
         hipFree(p.view.dScratch), hipFree(p.view.dDeferred), hipFree(p.view.dEcParams), hipFree(p.view.dGres), hipFree(p.view.dBucket);
+        if (p.view.hBucket)
+            hipHostFree(p.view.hBucket);
     }
     delete[] b->pipe;
     b->pipe = NULL;
@@ -1120,6 +1158,7 @@ static int ensurePipe(const MsdfHipBatch *b) {
     for (int k = 0; k < 2; ++k) {
         PipeSlot &p = b->pipe[k];
         p.stream = NULL, p.done = NULL, p.busy = false, p.dev = NULL, p.devCap = 0, p.pinnedGlyphs = NULL, p.pinnedGlyphCap = 0, p.viewCap = 0;
+        p.pinnedTiles = NULL, p.pinnedTilesCap = 0, p.pendingFirst = 0, p.pendingCount = 0;
     }
     for (int k = 0; k < 2; ++k) {
         HIPCHK(hipStreamCreateWithFlags(&b->pipe[k].stream, hipStreamNonBlocking));
@@ -1164,6 +1203,18 @@ static int fetchGlyphCounts(const MsdfHipBatch *b) {             // device-array
 
 static std::atomic<int> gPipeChunkGlyphs(0);                     // 0 = automatic (about 48 MB of float tiles per chunk)
 
+// Rows of the chunk waiting in the slot's pinned staging -> the caller's rectangles (any offsets / strides; nothing else is touched).
+static void scatterPending(PipeSlot &p, const MsdfHipGlyph *glyphs, char *dst, size_t elem, int w, int h, int N) {
+    const size_t rowBytes = (size_t) w*N*elem, tileBytes = rowBytes*h;
+    for (int g = 0; g < p.pendingCount; ++g) {
+        const MsdfHipGlyph &gd = glyphs[p.pendingFirst+g];
+        const char *src = p.pinnedTiles+(size_t) g*tileBytes;
+        for (int y = 0; y < h; ++y)
+            memcpy(dst+((long long) gd.out_offset+(long long) gd.row_stride*y)*(long long) elem, src+(size_t) y*rowBytes, rowBytes);
+    }
+    p.pendingCount = 0;
+}
+
 // out != NULL: float tiles into the caller's bitmaps (glyphs[g].out_offset / row_stride in floats). atlas != NULL: pixelFloatToByte
 // + blit into the caller's 8-bit atlas (out_offset / row_stride in bytes). Exactly one of the two.
 static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const MsdfHipGlyph *glyphs, float *out, size_t outFloats, uint8_t *atlas,
@@ -1186,20 +1237,20 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
     if (rc != MSDFHIP_OK)
         return rc;
     const size_t texels = (size_t) w*h, tile = texels*N;         // floats per tile; also bytes per 8-bit tile
-    const size_t total = out ? outFloats : atlasBytes;
-    // every rectangle must lie inside the caller's buffer
+    const size_t total = out ? outFloats : atlasBytes, elem = out ? sizeof(float) : 1;
+    // every rectangle must lie inside the caller's buffer. packed: the tiles follow each other in glyph order from `base` on, rows
+    // contiguous -> a chunk is ONE contiguous device-to-host copy straight into the caller's memory. Any other placement (rectangles of
+    // a larger atlas, negative strides): the chunk is copied into pinned staging and its rows are scattered on the host while the next
+    // chunk runs -- texels outside the rectangles are never touched, and devices sharing one atlas cannot disturb each other.
+    const long long base = glyphs[0].out_offset;
+    bool packed = true;
     for (int g = 0; g < nG; ++g) {
         const long long o = glyphs[g].out_offset, rs = glyphs[g].row_stride;
         const long long lo = rs >= 0 ? o : o+rs*(h-1), hi = (rs >= 0 ? o+rs*(h-1) : o)+(long long) w*N;
         if (lo < 0 || (unsigned long long) hi > total)
             return fail(MSDFHIP_ERR_INVALID, "glyph %d's rectangle [%lld, %lld) lies outside the output buffer of %zu elements", g, lo, hi, total);
+        packed = packed && o == base+(long long) ((size_t) g*tile) && rs == w*N;
     }
-    // packed: glyph g's tile is the g-th tile of the output, rows contiguous -> a chunk is one contiguous host range and the device
-    // renders straight into the chunk's tile buffer. Otherwise (rectangles of a larger atlas) the device keeps a mirror of the whole
-    // buffer: uploaded first (texels outside the rectangles survive), copied back once at the end.
-    bool packed = true;
-    for (int g = 0; g < nG && packed; ++g)
-        packed = glyphs[g].out_offset == (long long) ((size_t) g*tile) && glyphs[g].row_stride == w*N;
     int chunk = gPipeChunkGlyphs.load();
     if (chunk <= 0) {
         chunk = (int) ((48u<<20)/(tile*sizeof(float) ? tile*sizeof(float) : 1));
@@ -1209,16 +1260,10 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
         chunk = nG;
     const bool correct = mode >= 3 && cfg->ec_mode != MSDFHIP_EC_DISABLED;
     const bool wantStencil = stencil != NULL && correct;         // the reference leaves the caller's buffer alone when no correction runs
-    char *mirror = NULL;                                         // whole-buffer device mirror (non-packed layouts; always for 8-bit atlases)
-    const size_t elem = out ? sizeof(float) : 1;
-    struct MirrorGuard { char *&p; ~MirrorGuard() { hipFree(p); } } mirrorGuard = { mirror };
-    if (!packed || atlas) {
-        HIPCHK(hipMalloc((void **) &mirror, total*elem));
-        if (!packed)
-            HIPCHK(hipMemcpy(mirror, out ? (const void *) out : (const void *) atlas, total*elem, hipMemcpyHostToDevice));
-    }
-    const size_t offGlyphs = 0, offTiles = (2*(size_t) chunk*sizeof(MsdfHipGlyph)+255)/256*256, tilesBytes = ((size_t) chunk*tile*sizeof(float)+255)/256*256;
-    const size_t offStencil = offTiles+((packed && out) || atlas ? tilesBytes : 0), devBytes = offStencil+(wantStencil ? (size_t) chunk*texels : 0)+256;
+    char *dstBytes = out ? reinterpret_cast<char *>(out) : reinterpret_cast<char *>(atlas);
+    const size_t offGlyphs = 0, offTiles = ((size_t) chunk*sizeof(MsdfHipGlyph)+255)/256*256, tilesBytes = ((size_t) chunk*tile*sizeof(float)+255)/256*256;
+    const size_t offStencil = offTiles+tilesBytes, stencilBytes = wantStencil ? ((size_t) chunk*texels+255)/256*256 : 0;
+    const size_t offBytes = offStencil+stencilBytes, devBytes = offBytes+(atlas ? (size_t) chunk*tile : 0)+256;
     for (int k = 0; k < 2; ++k) {
         PipeSlot &p = b->pipe[k];
         if (p.devCap < devBytes) {
@@ -1233,16 +1278,26 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
             if (p.pinnedGlyphs)
                 HIPCHK(hipHostFree(p.pinnedGlyphs));
             p.pinnedGlyphs = NULL, p.pinnedGlyphCap = 0;
-            HIPCHK(hipHostMalloc((void **) &p.pinnedGlyphs, sizeof(MsdfHipGlyph)*2*(size_t) chunk, hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void **) &p.pinnedGlyphs, sizeof(MsdfHipGlyph)*(size_t) chunk, hipHostMallocDefault));
             p.pinnedGlyphCap = (size_t) chunk;
+        }
+        if (!packed && p.pinnedTilesCap < (size_t) chunk*tile*elem) {
+            if (p.pinnedTiles)
+                HIPCHK(hipHostFree(p.pinnedTiles));
+            p.pinnedTiles = NULL, p.pinnedTilesCap = 0;
+            HIPCHK(hipHostMalloc((void **) &p.pinnedTiles, (size_t) chunk*tile*elem, hipHostMallocDefault));
+            p.pinnedTilesCap = (size_t) chunk*tile*elem;
         }
         if (p.viewCap < chunk) {                                 // per-glyph work buffers of the view: reallocated on demand by the launches
             HIPCHK(hipStreamSynchronize(p.stream));
             hipFree(p.view.dBucket), hipFree(p.view.dEcParams);
-            p.view.dBucket = NULL, p.view.dEcParams = NULL, p.view.bucketLimit = -1;
+            if (p.view.hBucket)
+                hipHostFree(p.view.hBucket);
+            p.view.dBucket = NULL, p.view.hBucket = NULL, p.view.dEcParams = NULL, p.view.bucketLimit = -1, p.view.bucketUploaded = false;
             p.viewCap = chunk;
         }
         p.view.glyphCap = p.viewCap;                             // sized for a full chunk whatever the length of the slot's first chunk
+        p.pendingCount = 0;
     }
     int slot = 0;
     for (int g0 = 0; g0 < nG && rc == MSDFHIP_OK; g0 += chunk, slot ^= 1) {
@@ -1251,48 +1306,50 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
         if (p.busy) {                                            // the slot's previous copy must have left its buffers
             HIPCHK(hipEventSynchronize(p.done));
             p.busy = false;
+            if (p.pendingCount)
+                scatterPending(p, glyphs, dstBytes, elem, w, h, N);
         }
         sliceBatch(b, p.view, g0, n);
         MsdfHipGlyph *dGlyphs = reinterpret_cast<MsdfHipGlyph *>(p.dev+offGlyphs);
         float *dTiles = reinterpret_cast<float *>(p.dev+offTiles);
         uint8_t *dStencil = wantStencil ? reinterpret_cast<uint8_t *>(p.dev+offStencil) : NULL;
-        for (int g = 0; g < n; ++g) {
+        uint8_t *dBytes = reinterpret_cast<uint8_t *>(p.dev+offBytes);
+        for (int g = 0; g < n; ++g) {                            // the device always renders the chunk as packed tiles (same numbers in floats and bytes)
             p.pinnedGlyphs[g] = glyphs[g0+g];
-            if ((packed && out) || atlas)                        // render into the slot's packed tile buffer
-                p.pinnedGlyphs[g].out_offset = (int64_t) ((size_t) g*tile), p.pinnedGlyphs[g].row_stride = w*N;
+            p.pinnedGlyphs[g].out_offset = (int64_t) ((size_t) g*tile), p.pinnedGlyphs[g].row_stride = w*N;
         }
         HIPCHK(hipMemcpyAsync(dGlyphs, p.pinnedGlyphs, sizeof(MsdfHipGlyph)*(size_t) n, hipMemcpyHostToDevice, p.stream));
-        float *dDst = (packed && out) || atlas ? dTiles : reinterpret_cast<float *>(mirror);
-        rc = msdfhip_batch_generate(&p.view, mode, w, h, dGlyphs, dDst, dStencil, NULL, cfg, p.stream);
+        rc = msdfhip_batch_generate(&p.view, mode, w, h, dGlyphs, dTiles, dStencil, NULL, cfg, p.stream);
         if (rc != MSDFHIP_OK)
             break;
+        const char *dResult = reinterpret_cast<const char *>(dTiles);
         if (atlas) {
-            // descriptors again, this time with the caller's byte rectangles; the conversion kernel reads tiles packed in chunk order
-            MsdfHipGlyph *dAtlasGlyphs = dGlyphs+chunk, *hAtlasGlyphs = p.pinnedGlyphs+p.pinnedGlyphCap;
-            for (int g = 0; g < n; ++g)
-                hAtlasGlyphs[g] = glyphs[g0+g];
-            HIPCHK(hipMemcpyAsync(dAtlasGlyphs, hAtlasGlyphs, sizeof(MsdfHipGlyph)*(size_t) n, hipMemcpyHostToDevice, p.stream));
-            rc = msdfhip_tiles_to_bytes(dTiles, n, w, h, N, dAtlasGlyphs, reinterpret_cast<uint8_t *>(mirror), p.stream);
+            rc = msdfhip_tiles_to_bytes(dTiles, n, w, h, N, dGlyphs, dBytes, p.stream);
             if (rc != MSDFHIP_OK)
                 break;
-            if (packed)                                          // byte tiles in glyph order: this chunk's bytes are one contiguous range
-                HIPCHK(hipMemcpyAsync(atlas+(size_t) g0*tile, mirror+(size_t) g0*tile, (size_t) n*tile, hipMemcpyDeviceToHost, p.stream));
-        } else if (packed)
-            HIPCHK(hipMemcpyAsync(out+(size_t) g0*tile, dTiles, sizeof(float)*(size_t) n*tile, hipMemcpyDeviceToHost, p.stream));
+            dResult = reinterpret_cast<const char *>(dBytes);
+        }
+        if (packed)
+            HIPCHK(hipMemcpyAsync(dstBytes+((size_t) base+(size_t) g0*tile)*elem, dResult, (size_t) n*tile*elem, hipMemcpyDeviceToHost, p.stream));
+        else {
+            HIPCHK(hipMemcpyAsync(p.pinnedTiles, dResult, (size_t) n*tile*elem, hipMemcpyDeviceToHost, p.stream));
+            p.pendingFirst = g0, p.pendingCount = n;
+        }
         if (wantStencil)
             HIPCHK(hipMemcpyAsync(stencil+(size_t) g0*texels, dStencil, (size_t) n*texels, hipMemcpyDeviceToHost, p.stream));
         HIPCHK(hipEventRecord(p.done, p.stream));
         p.busy = true;
-        // pinnedGlyphs is rewritten by this slot's next chunk only after p.done (above), i.e. after both descriptor uploads ran
     }
     for (int k = 0; k < 2; ++k) {
-        hipError_t e = hipStreamSynchronize(b->pipe[k].stream);
-        b->pipe[k].busy = false;
+        PipeSlot &p = b->pipe[k];
+        hipError_t e = hipStreamSynchronize(p.stream);
+        p.busy = false;
         if (e != hipSuccess && rc == MSDFHIP_OK)
             rc = fail(MSDFHIP_ERR_HIP, "host-output pipeline: %s", hipGetErrorString(e));
+        if (rc == MSDFHIP_OK && p.pendingCount)
+            scatterPending(p, glyphs, dstBytes, elem, w, h, N);
+        p.pendingCount = 0;
     }
-    if (rc == MSDFHIP_OK && !packed)
-        HIPCHK(hipMemcpy(out ? (void *) out : (void *) atlas, mirror, total*elem, hipMemcpyDeviceToHost));
     return rc;
 }
 
@@ -1548,6 +1605,7 @@ static int runGroup(ShapeCall *const *calls, int n) {
     const size_t hTypes = hc.take(eAlloc), hColors = hc.take(eAlloc), hGlyph = hc.take(n*sizeof(MsdfHipGlyph));
     const size_t hSrc = bitmapIsInput ? hc.take(n*tileBytes) : hc.off;
     const size_t inputBytes = hc.off;
+    const size_t hBucketOff = hc.take(n*sizeof(int));           // class lists of the overlapping combiner (uploaded on the stream by the launch code)
     const size_t hOut = hc.take(n*tileBytes), hStencil = hc.take(n*texels);
     const size_t resultBytes = hc.off-hOut;
     // device layout: mirror of the staging area, then device-only work buffers
@@ -1607,6 +1665,7 @@ static int runGroup(ShapeCall *const *calls, int n) {
     b.dDeferred = correct ? reinterpret_cast<EcCandidate *>(a.dev+dCands) : NULL;
     b.deferredCap = correct ? candCap : 0;
     b.dEcParams = reinterpret_cast<EcGlyphParams *>(a.dev+dParams);
+    b.dBucket = reinterpret_cast<int *>(a.dev+hBucketOff), b.hBucket = reinterpret_cast<int *>(a.pinned+hBucketOff), b.bucketExternal = true;
     b.hContours.resize((size_t) n);
     b.hEdges.resize((size_t) n);
     for (int g = 0; g < n; ++g) {
@@ -1615,7 +1674,7 @@ static int runGroup(ShapeCall *const *calls, int n) {
     }
     struct Owned {                                               // workspaces the launches may have allocated for this view (many-contour shapes)
         MsdfHipBatch &b;
-        ~Owned() { hipFree(b.dGres); hipFree(b.dBucket); }
+        ~Owned() { hipFree(b.dGres); }
     } owned = { b };
     const MsdfHipGlyph *dGlyph = reinterpret_cast<const MsdfHipGlyph *>(a.dev+hGlyph);
     float *dOut = reinterpret_cast<float *>(a.dev+hOut);

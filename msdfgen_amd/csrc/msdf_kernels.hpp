@@ -401,7 +401,7 @@ struct PsdfQueryCooperative {                                       // same quer
         if (slots)
             waveSync();                                             // the previous query's slot reads are done
         if (OVERLAP)
-            shapeDistanceOverlap<2>(rec, edges, windings, C, q, res, WAVE, out);
+            shapeDistanceOverlap<2>(rec, edges, windings, C, q, res, 1, out);   // wave-uniform point: every lane holds the same values, one slot per contour
         else
             shapeDistanceSimple<2>(rec, edges, C, q, out);
         return out[0];
@@ -661,27 +661,95 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
         stencilOut[stencilIndex(texel, yn, width, height, cfg.stencil_y_down)] = (uint8_t) st;
 }
 
-// The deferred distance checks: a wavefront takes candidates of ONE glyph, one candidate at a time, and its 64 lanes evaluate the
-// glyph's edges in parallel (EdgesCooperative) -- a candidate costs one round per contour instead of a serial walk over all edges.
-// Work unit = (glyph, k): the unit handles candidates k, k+K, ... of the glyph's segment. A candidate that turns out to be an artifact flags its texel: rgb := median (apply,
-// MSDFErrorCorrection.cpp:459-479), stencil |= ERROR. Several candidates of one texel write identical values.
-template <int N, bool OVERLAP, bool GRES = false>
+// Two ways to spend a wavefront on deferred distance checks of a glyph with nE edges:
+//   cooperative        one candidate at a time, lanes = edges (one round of edge evaluations per 64 edges, then a serial merge of the
+//                      single-edge states per contour): cost per candidate ~ 340*ceil(nE/64) + 10*nE + 1000 instructions;
+//   lane per candidate 64 candidates at a time, every lane walks all edges (uniform control flow, scalar record loads -- the loop of
+//                      k_distance): cost per chunk ~ 340*nE + 1000, whatever the number of live lanes.
+// The first wins for the usual handful of candidates, the second for many (an icon with 186, a 1024x1024 logo with thousands).
+struct EcQueryPolicy { int lpcMaxContours, lpcEdgeCost, lpcMaxEdges, lpcMinCount; };
+MSDF_HD bool ecQueryLanePerCandidate(unsigned count, int nE, int C, EcQueryPolicy q) {
+    if (C > q.lpcMaxContours)                                        // its [contour][lane] scratch would not fit the LDS the launch reserved
+        return false;
+    if ((nE > q.lpcMaxEdges && (int) count < q.lpcMinCount))         // a chunk is one long serial walk: only worth it when there are many chunks
+        return false;
+    const long long coop = (long long) count*(340ll*((nE+WAVE-1)/WAVE)+10ll*nE+1000ll);
+    const long long lpc = (long long) ((count+WAVE-1)/WAVE)*((long long) q.lpcEdgeCost*nE+1000ll);
+    return lpc < coop;
+}
+MSDF_HD int ecQueryItems(unsigned count, unsigned seg, int nE, int C, EcQueryPolicy lpcMaxContours) {     // work items of one glyph; a glyph whose segment overflowed has none (k_ec_slow redoes it)
+    if (count > seg)
+        return 0;
+    return ecQueryLanePerCandidate(count, nE, C, lpcMaxContours) ? (int) ((count+WAVE-1)/WAVE) : (int) count;
+}
+
+// Prefix sums of the per-glyph work items of k_ec_query (one workgroup): offsets[g] = items of glyphs < g, offsets[G] = total,
+// offsets[G+1] = the work counter of k_ec_query (zeroed here).
+__global__ void __launch_bounds__(1024)
+k_ec_scan(BatchView batch, const unsigned *header, unsigned seg, int *offsets, EcQueryPolicy lpcMaxContours) {
+    __shared__ int partial[1024];
+    const int nGlyphs = batch.nGlyphs;
+    const int t = threadIdx.x, per = (nGlyphs+1023)/1024;
+    const int lo = t*per < nGlyphs ? t*per : nGlyphs, hi = lo+per < nGlyphs ? lo+per : nGlyphs;
+    int sum = 0;
+    for (int g = lo; g < hi; ++g) {
+        const int nE = batch.contourOffsets[batch.glyphContourOffsets[g+1]]-batch.contourOffsets[batch.glyphContourOffsets[g]];
+        sum += ecQueryItems(header[1+g], seg, nE, batch.glyphContourOffsets[g+1]-batch.glyphContourOffsets[g], lpcMaxContours);
+    }
+    partial[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                      // inclusive scan of the 1024 partial sums
+        const int v = t >= off ? partial[t-off] : 0;
+        __syncthreads();
+        partial[t] += v;
+        __syncthreads();
+    }
+    int at = partial[t]-sum;
+    for (int g = lo; g < hi; ++g) {
+        offsets[g] = at;
+        const int nE = batch.contourOffsets[batch.glyphContourOffsets[g+1]]-batch.contourOffsets[batch.glyphContourOffsets[g]];
+        at += ecQueryItems(header[1+g], seg, nE, batch.glyphContourOffsets[g+1]-batch.glyphContourOffsets[g], lpcMaxContours);
+    }
+    if (t == 1023) {
+        offsets[nGlyphs] = partial[1023];
+        offsets[nGlyphs+1] = 0;
+    }
+}
+
+// The deferred distance checks. The work items of the whole batch form one flat list (offsets[], k_ec_scan); a wavefront grabs one
+// item at a time from an atomic counter -- glyphs differ by orders of magnitude in candidates x edges (one symbol of the DejaVu set:
+// 186 candidates x 543 edges), a static split per glyph left the launch waiting for a single wavefront. An item is one candidate
+// (cooperative: the 64 lanes evaluate the glyph's edges in parallel, EdgesCooperative; the query point is wave-uniform, so the
+// combiner scratch is one double per contour) or a chunk of 64 candidates of one glyph (lane per candidate, scratch [contour][lane]).
+// A candidate that turns out to be an artifact flags its texel: rgb := median (apply, MSDFErrorCorrection.cpp:459-479),
+// stencil |= ERROR. Several candidates of one texel write identical values.
+template <int N, bool OVERLAP>
 __global__ void __launch_bounds__(WAVE, 2)
 k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, const float *src, float *out, uint8_t *stencilOut,
-           MsdfHipConfig cfg, const EcGlyphParams *glyphParams, const EcCandidate *cands, unsigned seg, unsigned K, double *gres, size_t gresStride,
-           int slotCap, size_t slotOffset) {
-    extern __shared__ double smemLds[];                             // [maxContours][64] combiner scratch (overlap only), then slotCap PBSlots
-    double *smem = GRES ? gres+(size_t) blockIdx.x*gresStride : smemLds;
+           MsdfHipConfig cfg, const EcGlyphParams *glyphParams, const EcCandidate *cands, unsigned seg, int *offsets, int slotCap, int slotOffset, EcQueryPolicy lpcMaxContours) {
+    extern __shared__ double smemLds[];                             // combiner scratch ([maxContours][64] or [maxContours]) | slotCap PBSlots at slotOffset
     PBSlot *slotBuf = reinterpret_cast<PBSlot *>(smemLds+slotOffset);
     const unsigned *header = reinterpret_cast<const unsigned *>(cands);
     const size_t texelsPerGlyph = (size_t) width*height;
-    const size_t units = (size_t) batch.nGlyphs*K;
-    for (size_t unit = blockIdx.x; unit < units; unit += gridDim.x) {
-        const int g = (int) (unit/K);
-        const unsigned k = (unsigned) (unit-(size_t) g*K);
+    const int total = offsets[batch.nGlyphs];
+    int *counter = offsets+batch.nGlyphs+1;
+    for (;;) {
+        int i = 0;
+        if (threadIdx.x == 0)
+            i = atomicAdd(counter, 1);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= total)
+            break;
+        int lo = 0, hi = batch.nGlyphs-1;                           // the glyph g with offsets[g] <= i < offsets[g+1]
+        while (lo < hi) {
+            const int mid = (lo+hi)>>1;
+            if (offsets[mid+1] > i)
+                hi = mid;
+            else
+                lo = mid+1;
+        }
+        const int g = lo, item = i-offsets[g];
         const unsigned count = header[1+g];
-        if (k >= count || count > seg)                              // nothing to do / segment overflowed: k_ec_slow redoes this glyph
-            continue;
         const EcCandidate *segment = cands+ecHeaderRecords(batch.nGlyphs)+(size_t) g*seg;
         const int c0 = batch.glyphContourOffsets[g], C = batch.glyphContourOffsets[g+1]-c0;
         const int32_t *coff = batch.contourOffsets+c0;
@@ -697,22 +765,13 @@ k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, c
         SdfView sdf;
         sdf.px = src+(size_t) g*texelsPerGlyph*N;
         sdf.w = width, sdf.h = height, sdf.N = N, sdf.flip = gd.flip;
-        // Two ways to spend the wavefront on this glyph's candidates: lanes = edges of one candidate at a time (cooperative: one round
-        // and one cross-lane merge per contour and candidate) or lane = candidate (every lane walks all edges; uniform control flow
-        // and scalar record loads since the whole wavefront is on one glyph). The first wins for the usual handful of candidates on a
-        // glyph of few contours, the second for many candidates / many small contours (CJK-like shapes: 14 contours of 6 edges).
         const int nE = coff[C]-coff[0];
-        const bool slotted = nE <= slotCap;                         // the glyph's single-edge states fit the LDS slots
-        const bool lanePerCandidate = slotted ? (size_t) count*((nE+WAVE-1)/WAVE*4+C) > (size_t) 16*nE*K
-                                              : (size_t) count*C*2 > (size_t) nE*K;
-        if (lanePerCandidate) {
+        if (ecQueryLanePerCandidate(count, nE, C, lpcMaxContours)) {
             PsdfQuery<OVERLAP> query;
-            query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.res = smem+threadIdx.x;
-            for (unsigned base = k*WAVE; base < count; base += K*WAVE) {
-                const unsigned i = base+threadIdx.x;
-                if (i >= count)
-                    continue;
-                const EcCandidate cand = segment[i];
+            query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.res = smemLds+threadIdx.x;
+            const unsigned k = (unsigned) item*WAVE+threadIdx.x;
+            if (k < count) {
+                const EcCandidate cand = segment[k];
                 const size_t texel = cand.texel;
                 const int rem = (int) (texel-(size_t) g*texelsPerGlyph);
                 const int yn = rem/width, x = rem%width;
@@ -726,14 +785,12 @@ k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, c
                         stencilOut[stencilIndex(texel, yn, width, height, cfg.stencil_y_down)] |= (uint8_t) EC_ERROR;
                 }
             }
-            continue;
-        }
-        PsdfQueryCooperative<OVERLAP> query;
-        query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.lane = threadIdx.x;
-        query.res = smem+threadIdx.x;
-        query.slots = slotted ? slotBuf : NULL;
-        for (unsigned i = k; i < count; i += K) {                    // one candidate at a time, the wavefront shares its edges
-            const EcCandidate cand = segment[i];
+        } else {
+            const EcCandidate cand = segment[item];
+            PsdfQueryCooperative<OVERLAP> query;
+            query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.lane = threadIdx.x;
+            query.res = smemLds;
+            query.slots = nE <= slotCap ? slotBuf : NULL;           // larger glyphs: per-contour cross-lane merge instead of the slots
             const size_t texel = cand.texel;
             const int rem = (int) (texel-(size_t) g*texelsPerGlyph);
             const int yn = rem/width, x = rem%width;
@@ -747,6 +804,7 @@ k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, c
                     stencilOut[stencilIndex(texel, yn, width, height, cfg.stencil_y_down)] |= (uint8_t) EC_ERROR;
             }
         }
+        waveSync();                                                 // the next item rewrites the LDS scratch
     }
 }
 

@@ -352,7 +352,7 @@ def test_micro_batched_concurrent_calls_mixed_parameters(latin, oracle):
                     st, want_st = np.zeros((40, 40), np.uint8), np.zeros((40, 40), np.uint8)
                     got = gen(4, s, 40, 40, xf40[g], cfg(buffer=st), y_down=True)
                     close(got, oracle.generate(s, 4, 40, 40, xf40[g], y_down=True, stencil=want_st), "mtsdf %d" % g)
-                    assert (st == want_st[::-1]).all()
+                    assert (st == want_st).all()                                 # rows in the reference's (upward) order, also for a Y-down bitmap
                 elif kind == 2:
                     close(gen(1, s, 32, 32, xf32[g]), oracle.generate(s, 1, 32, 32, xf32[g]), "sdf %d" % g)
                 else:

@@ -26,3 +26,16 @@ gb = M.GlyphBatch(cj)
 gb.generate(3, 48, 48, cx)
 ov, c = gb.candidate_counts()
 print("cjk-like 48x48: overflow %s, candidates/glyph mean %.1f p50 %d p99 %d max %d" % (ov, c.mean(), np.percentile(c, 50), np.percentile(c, 99), c.max()))
+from bench import load_dejavu  # noqa: E402
+dj, djx, _ = load_dejavu()
+gb = M.GlyphBatch(dj)
+gb.generate(3, 64, 64, djx)
+ov, c = gb.candidate_counts()
+gco, co = dj.glyph_contour_offsets, dj.contour_offsets
+ne = co[gco[1:]]-co[gco[:-1]]
+nc = np.diff(gco)
+print("dejavu8192 64x64: overflow %s, candidates/glyph mean %.1f p50 %d p90 %d p99 %d max %d; sum(cand*edges) %.3g, sum(cand) %d; glyphs with 0: %d" % (
+    ov, c.mean(), np.percentile(c, 50), np.percentile(c, 90), np.percentile(c, 99), c.max(), float((c.astype(np.float64)*ne).sum()), int(c.sum()), int((c == 0).sum())))
+for lo, hi in ((1, 1), (2, 3), (4, 7), (8, 99)):
+    m = (nc >= lo) & (nc <= hi)
+    print("  contours %d..%d: glyphs %d, candidates/glyph %.1f, edges %.1f" % (lo, hi, m.sum(), c[m].mean(), ne[m].mean()))
