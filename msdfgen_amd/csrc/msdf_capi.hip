@@ -71,6 +71,32 @@ int currentDevice() {
 
 int channelsOf(int mode) { return mode <= 2 ? 1 : mode; }
 
+// hipHostMalloc for the library's own staging buffers. The HIP runtime recycles pinned address ranges without ThreadSanitizer seeing
+// the free / allocation pair (it is not instrumented), so under TSan the allocator's own synchronisation is stated explicitly (release at
+// the free, acquire at the allocation) -- otherwise writes of two threads to buffers that merely reuse an address are reported as races.
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define MSDFHIP_TSAN 1
+extern "C" void __tsan_acquire(void *addr);
+extern "C" void __tsan_release(void *addr);
+#endif
+#endif
+hipError_t pinnedAlloc(void **p, size_t bytes) {
+    const hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault);
+#if defined(MSDFHIP_TSAN)
+    if (e == hipSuccess)
+        __tsan_acquire(*p);                                      // pairs with pinnedFree of the address range's previous owner
+#endif
+    return e;
+}
+hipError_t pinnedFree(void *p) {
+#if defined(MSDFHIP_TSAN)
+    if (p)
+        __tsan_release(p);
+#endif
+    return hipHostFree(p);
+}
+
 struct TimedLaunch { hipEvent_t a, b; int kind; };
 std::mutex gTimingMutex;
 std::vector<TimedLaunch> gTimed;
@@ -114,6 +140,7 @@ struct MsdfHipBatch {
     mutable EcGlyphParams *dEcParams; // per-glyph constants of the error-correction pass
     mutable double *dGres;            // global combiner scratch for glyphs whose contour count exceeds what LDS can hold
     mutable size_t gresBytes;
+    mutable bool gresExternal;        // dGres belongs to someone else (the single-shape calls carve it from their arena)
     mutable size_t deferredCap;
     mutable std::mutex scratchMutex;
     mutable std::vector<int> hContours; // contours per glyph (host copy, fetched on first need)
@@ -130,7 +157,7 @@ struct MsdfHipBatch {
     mutable std::mutex pipeMutex;     // one host-output call at a time per batch
     MsdfHipBatch() : device(0), nGlyphs(0), nContours(0), nEdges(0), maxContours(0), maxEdges(0), ownsInputs(false), dGlyphContourOffsets(NULL),
                      dContourOffsets(NULL), dPoints(NULL), dTypes(NULL), dColors(NULL), dRecs(NULL), dWindings(NULL), dScratch(NULL), scratchFloats(0),
-                     dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
+                     dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
                      smallMaxC(0), smallMaxE(0), oneMaxE(0), glyphCap(0), pipe(NULL) { }
 };
 
@@ -208,9 +235,9 @@ int setLds(K kernel, size_t bytes) {
 int ensureGres(const MsdfHipBatch *b, size_t bytes, double **out) {
     std::lock_guard<std::mutex> lock(b->scratchMutex);
     if (b->gresBytes < bytes) {
-        if (b->dGres)
+        if (b->dGres && !b->gresExternal)
             hipFree(b->dGres);
-        b->dGres = NULL, b->gresBytes = 0;
+        b->dGres = NULL, b->gresBytes = 0, b->gresExternal = false;
         HIPCHK(hipMalloc((void **) &b->dGres, bytes));
         b->gresBytes = bytes;
     }
@@ -234,7 +261,7 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
         return rc;
     double *gres = NULL;
     size_t chunk = blocks, stride = 0;
-    if (GRES) {
+    if (GRES && OVERLAP && plan.resBytes) {
         stride = plan.resBytes/sizeof(double);
         chunk = GRES_WORKSPACE_CAP/plan.resBytes;
         if (chunk < 256)
@@ -278,7 +305,7 @@ int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
     if (!b->dBucket)
         HIPCHK(hipMalloc((void **) &b->dBucket, sizeof(int)*cap));
     if (!b->hBucket)
-        HIPCHK(hipHostMalloc((void **) &b->hBucket, sizeof(int)*cap, hipHostMallocDefault));
+        HIPCHK(pinnedAlloc((void **) &b->hBucket, sizeof(int)*cap));
     if (b->bucketUploaded)                                       // an earlier upload from hBucket (same batch, other limit) must have left it
         HIPCHK(hipStreamSynchronize(stream));
     int *order = b->hBucket;
@@ -312,7 +339,19 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     if (rc != MSDFHIP_OK)
         return rc;
     ScopedTimer timer(stream, 0);                                // the distance pass of one generate call (one or more launches)
+    // A launch too small to fill the device (a single-shape call, a micro-batched group) is latency bound: it takes one tile per
+    // wavefront instead of four -- four times the wavefronts, a quarter of the serial work each -- with the combiner scratch in the
+    // global workspace (single 64x64 glyph: 19 -> 8 us simple, ~100 -> ~30 us overlapping combiner).
+    const int tilesAll = ((w+TILE-1)/TILE)*((h+TILE-1)/TILE);
+    const size_t gresAll = (size_t) b->nGlyphs*tilesAll*(size_t) b->maxContours*SelTraits<SEL>::NCH*WAVE*sizeof(double);
+    const bool smallLaunch = (size_t) b->nGlyphs*tilesAll <= 8192 && (!overlap || gresAll <= ((size_t) 64<<20));
+    LdsPlan single = plan;                                       // one tile per wavefront: one survivor list, scratch (if any) in global memory
+    single.globalRes = true;
+    single.bytes = ((size_t) b->maxEdges+(size_t) b->maxContours+2)*sizeof(int);
+    single.resBytes = overlap ? (size_t) b->maxContours*SelTraits<SEL>::NCH*WAVE*sizeof(double) : 0;
     if (!overlap || b->maxContours <= 1) {
+        if (smallLaunch)
+            return launchDistance<SEL, false, true>(b, dGlyphs, w, h, dst, toScratch, single, stream);
         if (overlap) {
             rc = planLds(b, SelTraits<SEL>::NCH, false, plan);
             if (rc != MSDFHIP_OK)
@@ -320,22 +359,32 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
         }
         return launchDistance<SEL, false, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
     }
+    if (smallLaunch && b->nGlyphs == 1)
+        return launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, single, stream);
     // how many contours' worth of combiner scratch fit the per-wavefront LDS budget next to the survivor lists of a SMALL_MAX_EDGES glyph
     const size_t perContour = (size_t) SelTraits<SEL>::NCH*WAVE*sizeof(double);
     int limit = 0;
     while ((size_t) (limit+1)*perContour+(size_t) QUAD*((size_t) SMALL_MAX_EDGES+(limit+1)+2)*sizeof(int) <= plan.ldsBudget)
         ++limit;
-    if (b->nGlyphs == 1) {                                       // the single-shape calls: the class is known, no index map
+    if (b->nGlyphs == 1) {                                       // the class is known, no index map
         if (b->maxContours <= limit && b->maxEdges <= SMALL_MAX_EDGES && !plan.globalRes)
             return launchDistance<SEL, true, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
-        plan.globalRes = true;
-        plan.bytes = ((size_t) b->maxEdges+(size_t) b->maxContours+2)*sizeof(int);
-        return launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
+        return launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, single, stream);
     }
     rc = ensureBuckets(b, limit < 1 ? 1 : limit, stream);
     if (rc != MSDFHIP_OK)
         return rc;
     const int nRest = b->nGlyphs-b->nOne-b->nSmall;
+    if (smallLaunch) {
+        if (b->nOne > 0) {
+            rc = launchDistance<SEL, false, true>(b, dGlyphs, w, h, dst, toScratch, single, stream, b->dBucket, b->nOne);
+            if (rc != MSDFHIP_OK)
+                return rc;
+        }
+        if (b->nGlyphs > b->nOne)
+            return launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, single, stream, b->dBucket+b->nOne, b->nGlyphs-b->nOne);
+        return MSDFHIP_OK;
+    }
     if (b->nOne > 0) {
         LdsPlan simple;
         rc = planLds(b, SelTraits<SEL>::NCH, false, simple, 1, b->oneMaxE);
@@ -394,7 +443,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
         return fail(MSDFHIP_ERR_INVALID, "batch of %zu texels exceeds the 32-bit texel index of the error-correction pass; split the batch", allTexels);
     const size_t resBytes = OVERLAP ? (size_t) b->maxContours*WAVE*sizeof(double) : 0;   // combiner scratch of the PSDF distance checks
     const size_t slowLds = GRES ? 0 : resBytes;
-    const unsigned slowGrid = 2048;
+    const unsigned slowGrid = (unsigned) (allTexels/WAVE < 64 ? 64 : allTexels/WAVE > 2048 ? 2048 : allTexels/WAVE);   // grid-stride over the texels
     double *gres = NULL;
     int rc;
     if (GRES) {
@@ -450,7 +499,9 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
         return rc;
     int *offsets = reinterpret_cast<int *>(deferred+candidateRecords(b->nGlyphs, (size_t) w*h));
     // the query kernel is a pool of wavefronts draining one work list: enough of them to fill the device, no more
-    const unsigned queryBlocks = 8192;                           // (a wavefront that finds the list empty leaves after one atomic)
+    // (a wavefront that finds the list empty leaves after one atomic; still, a single 64x64 glyph should not launch thousands of them)
+    const size_t wanted = allTexels/512;
+    const unsigned queryBlocks = (unsigned) (wanted < 64 ? 64 : wanted > 8192 ? 8192 : wanted);
     hipLaunchKernelGGL(k_ec_params, dim3((b->nGlyphs+255)/256), dim3(256), 0, stream, b->dEcParams, dGlyphs, b->nGlyphs, cfg,
                        reinterpret_cast<unsigned *>(deferred));   // also zeroes the candidate header
     hipLaunchKernelGGL((k_ec_fast<N>), dim3(blocks), dim3(WAVE), fastLds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, src, out, stencil, cfg,
@@ -921,7 +972,7 @@ void msdfhip_batch_destroy(MsdfHipBatch *b) {
     if (!b->bucketExternal) {
         hipFree(b->dBucket);
         if (b->hBucket)
-            hipHostFree(b->hBucket);
+            pinnedFree(b->hBucket);
     }
     delete b;
 }
@@ -1140,12 +1191,12 @@ static void destroyPipe(const MsdfHipBatch *b) {
             hipEventDestroy(p.done);
         hipFree(p.dev);
         if (p.pinnedGlyphs)
-            hipHostFree(p.pinnedGlyphs);
+            pinnedFree(p.pinnedGlyphs);
         if (p.pinnedTiles)
-            hipHostFree(p.pinnedTiles);
+            pinnedFree(p.pinnedTiles);
         hipFree(p.view.dScratch), hipFree(p.view.dDeferred), hipFree(p.view.dEcParams), hipFree(p.view.dGres), hipFree(p.view.dBucket);
         if (p.view.hBucket)
-            hipHostFree(p.view.hBucket);
+            pinnedFree(p.view.hBucket);
     }
     delete[] b->pipe;
     b->pipe = NULL;
@@ -1276,23 +1327,23 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
         }
         if (p.pinnedGlyphCap < (size_t) chunk) {
             if (p.pinnedGlyphs)
-                HIPCHK(hipHostFree(p.pinnedGlyphs));
+                HIPCHK(pinnedFree(p.pinnedGlyphs));
             p.pinnedGlyphs = NULL, p.pinnedGlyphCap = 0;
-            HIPCHK(hipHostMalloc((void **) &p.pinnedGlyphs, sizeof(MsdfHipGlyph)*(size_t) chunk, hipHostMallocDefault));
+            HIPCHK(pinnedAlloc((void **) &p.pinnedGlyphs, sizeof(MsdfHipGlyph)*(size_t) chunk));
             p.pinnedGlyphCap = (size_t) chunk;
         }
         if (!packed && p.pinnedTilesCap < (size_t) chunk*tile*elem) {
             if (p.pinnedTiles)
-                HIPCHK(hipHostFree(p.pinnedTiles));
+                HIPCHK(pinnedFree(p.pinnedTiles));
             p.pinnedTiles = NULL, p.pinnedTilesCap = 0;
-            HIPCHK(hipHostMalloc((void **) &p.pinnedTiles, (size_t) chunk*tile*elem, hipHostMallocDefault));
+            HIPCHK(pinnedAlloc((void **) &p.pinnedTiles, (size_t) chunk*tile*elem));
             p.pinnedTilesCap = (size_t) chunk*tile*elem;
         }
         if (p.viewCap < chunk) {                                 // per-glyph work buffers of the view: reallocated on demand by the launches
             HIPCHK(hipStreamSynchronize(p.stream));
             hipFree(p.view.dBucket), hipFree(p.view.dEcParams);
             if (p.view.hBucket)
-                hipHostFree(p.view.hBucket);
+                pinnedFree(p.view.hBucket);
             p.view.dBucket = NULL, p.view.hBucket = NULL, p.view.dEcParams = NULL, p.view.bucketLimit = -1, p.view.bucketUploaded = false;
             p.viewCap = chunk;
         }
@@ -1531,10 +1582,10 @@ static int arenaReserve(ThreadArena &a, size_t devBytes, size_t pinnedBytes) {
     }
     if (a.pinnedCap < pinnedBytes) {
         if (a.pinned)
-            HIPCHK(hipHostFree(a.pinned));
+            HIPCHK(pinnedFree(a.pinned));
         a.pinned = NULL, a.pinnedCap = 0;
         const size_t cap = pinnedBytes+pinnedBytes/2+4096;
-        HIPCHK(hipHostMalloc((void **) &a.pinned, cap, hipHostMallocDefault));
+        HIPCHK(pinnedAlloc((void **) &a.pinned, cap));
         a.pinnedCap = cap;
     }
     return MSDFHIP_OK;
@@ -1613,6 +1664,12 @@ static int runGroup(ShapeCall *const *calls, int n) {
     dc.off = hc.off;
     const size_t dRecs = dc.take(eAlloc*sizeof(EdgeRec)), dWind = dc.take(cAlloc), dScratch = dc.take(n*tileBytes*stages);
     const size_t dCands = dc.take(correct ? candCap*sizeof(EcCandidate) : 0), dParams = dc.take(n*sizeof(EcGlyphParams));
+    // combiner scratch of the small-launch distance kernels (one tile per wavefront), see dispatchDistance
+    const size_t tilesAll = (size_t) ((w+TILE-1)/TILE)*((h+TILE-1)/TILE);
+    size_t gresNeed = op == OP_GENERATE && cfg->overlap_support && maxC > 1 && (size_t) n*tilesAll <= 8192 ? (size_t) n*tilesAll*maxC*channels*WAVE*sizeof(double) : 0;
+    if (gresNeed > ((size_t) 64<<20))
+        gresNeed = 0;
+    const size_t dGresOff = dc.take(gresNeed);
     ArenaLease lease;
     rc = lease.take(currentDevice());
     if (rc != MSDFHIP_OK)
@@ -1666,6 +1723,8 @@ static int runGroup(ShapeCall *const *calls, int n) {
     b.deferredCap = correct ? candCap : 0;
     b.dEcParams = reinterpret_cast<EcGlyphParams *>(a.dev+dParams);
     b.dBucket = reinterpret_cast<int *>(a.dev+hBucketOff), b.hBucket = reinterpret_cast<int *>(a.pinned+hBucketOff), b.bucketExternal = true;
+    if (gresNeed)
+        b.dGres = reinterpret_cast<double *>(a.dev+dGresOff), b.gresBytes = gresNeed, b.gresExternal = true;
     b.hContours.resize((size_t) n);
     b.hEdges.resize((size_t) n);
     for (int g = 0; g < n; ++g) {
@@ -1674,7 +1733,7 @@ static int runGroup(ShapeCall *const *calls, int n) {
     }
     struct Owned {                                               // workspaces the launches may have allocated for this view (many-contour shapes)
         MsdfHipBatch &b;
-        ~Owned() { hipFree(b.dGres); }
+        ~Owned() { if (!b.gresExternal) hipFree(b.dGres); }
     } owned = { b };
     const MsdfHipGlyph *dGlyph = reinterpret_cast<const MsdfHipGlyph *>(a.dev+hGlyph);
     float *dOut = reinterpret_cast<float *>(a.dev+hOut);

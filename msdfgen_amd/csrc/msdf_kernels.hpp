@@ -172,8 +172,11 @@ __device__ inline int rowRank(unsigned key) {
 
 enum { QUAD = 4 };   // tiles per wavefront of the LDS-scratch variant (the global-scratch variant, GRES, takes one: measured faster there)
 
+#ifndef MSDF_SIMPLE_WAVES_PER_SIMD
+#define MSDF_SIMPLE_WAVES_PER_SIMD 5     // the simple-combiner instantiations need ~96 VGPRs: five wavefronts per SIMD
+#endif
 template <int SEL, bool OVERLAP, bool GRES = false>
-__global__ void __launch_bounds__(WAVE, MSDF_DISTANCE_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(WAVE, OVERLAP ? MSDF_DISTANCE_WAVES_PER_SIMD : MSDF_SIMPLE_WAVES_PER_SIMD)
 k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges, float *dst, int toScratch,
            unsigned blockBase, double *gres, size_t gresStride, const int *glyphMap, int nMapped) {
     enum { NCH = SelTraits<SEL>::NCH, TPW = GRES ? 1 : (int) QUAD, ROW = WAVE/TPW };   // tiles per wavefront, lanes per tile in phase 1

@@ -1,0 +1,203 @@
+// san_driver.cpp -- exercises the HOST side of libmsdfgen_hip (arenas, group-commit micro-batcher, host-output pipeline, sharded
+// generator, argument validation) from plain C++ so that it can run under AddressSanitizer + UBSan and under ThreadSanitizer on the
+// GPU box (tests/sanitize/run.sh). Shapes are synthesised here (closed polygons with a few quadratic
+// sides, 1..12 contours); results are cross-checked between the entry points (single call == batch == sharded), not against the oracle
+// -- parity is the business of tests/test_gpu_*.py.
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "msdfgen_hip.h"
+
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+extern "C" void __lsan_do_leak_check(void);
+#endif
+#endif
+
+struct Shapes {
+    std::vector<int32_t> gco, co;
+    std::vector<double> points;
+    std::vector<uint8_t> types, colors;
+    std::vector<double> xf;             // 6 per glyph
+    int n() const { return (int) gco.size()-1; }
+};
+
+static unsigned rngState = 12345;
+static double rnd() { rngState = rngState*1664525u+1013904223u; return (rngState>>8)/16777216.; }
+
+static void addGlyph(Shapes &s, int contours, int size) {
+    for (int c = 0; c < contours; ++c) {
+        const int n = 3+(int) (rnd()*6);
+        const double cx = .2+.6*rnd(), cy = .2+.6*rnd(), r = .05+.25*rnd(), a0 = 6.28*rnd();
+        const bool hole = c > 0 && rnd() < .4;
+        for (int i = 0; i < n; ++i) {
+            const double a = a0+(hole ? -1 : 1)*6.28318530718*i/n, b = a0+(hole ? -1 : 1)*6.28318530718*(i+1)/n;
+            double p[8] = { cx+r*cos(a), cy+r*sin(a), 0, 0, 0, 0, 0, 0 };
+            const bool quad = rnd() < .5;
+            if (quad) {
+                const double m = .5*(a+b), rr = r*(1.05+.2*rnd());
+                p[2] = cx+rr*cos(m), p[3] = cy+rr*sin(m), p[4] = cx+r*cos(b), p[5] = cy+r*sin(b);
+            } else
+                p[2] = cx+r*cos(b), p[3] = cy+r*sin(b);
+            s.points.insert(s.points.end(), p, p+8);
+            s.types.push_back(quad ? 2 : 1);
+            static const uint8_t cyc[3] = { 6, 5, 3 };                // CYAN, MAGENTA, YELLOW
+            s.colors.push_back(cyc[i%3]);
+        }
+        s.co.push_back((int32_t) s.types.size());
+    }
+    s.gco.push_back((int32_t) s.co.size()-1);
+    const double range = 4./size;
+    const double xf[6] = { (double) size, (double) size, 0, 0, 1/(2*range*.5), range*.5 };   // DistanceMapping(Range(-range/2, range/2))
+    s.xf.insert(s.xf.end(), xf, xf+6);
+}
+
+static int failures = 0;
+#define EXPECT(cond) do { if (!(cond)) { ++failures; fprintf(stderr, "FAILED %s:%d: %s (%s)\n", __FILE__, __LINE__, #cond, msdfhip_last_error()); } } while (0)
+
+int main(int argc, char **argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 3;
+    const int W = 32, N = 3;
+    Shapes s;
+    s.gco.push_back(0), s.co.push_back(0);
+    const int G = 200;
+    for (int g = 0; g < G; ++g)
+        addGlyph(s, g%23 == 0 ? 12 : 1+g%4, W);
+    MsdfHipConfig cfg;
+    msdfhip_default_config(&cfg);
+    EXPECT(msdfhip_init(0) == MSDFHIP_OK);
+    if (failures)
+        return 2;
+    const size_t tile = (size_t) W*W*N;
+
+    // 1. batch on the device -> host tiles (packed), with stencil; twice with different chunk sizes
+    std::vector<MsdfHipGlyph> gd(G);
+    for (int g = 0; g < G; ++g) {
+        memcpy(gd[g].xf, &s.xf[6*g], sizeof(gd[g].xf));
+        gd[g].out_offset = (int64_t) (g*tile), gd[g].row_stride = W*N, gd[g].flip = 0;
+    }
+    std::vector<float> want(G*tile), got(G*tile);
+    std::vector<uint8_t> stencil((size_t) G*W*W);
+    MsdfHipBatch *b = NULL;
+    EXPECT(msdfhip_batch_create(&b, G, s.gco.data(), s.co.data(), s.points.data(), s.types.data(), s.colors.data()) == MSDFHIP_OK);
+    EXPECT(msdfhip_batch_generate_host(b, MSDFHIP_MODE_MSDF, W, W, gd.data(), want.data(), want.size(), stencil.data(), &cfg) == MSDFHIP_OK);
+    for (int chunk : { 7, 64, 1000 }) {
+        EXPECT(msdfhip_set_pipeline_chunk(chunk) == MSDFHIP_OK);
+        std::fill(got.begin(), got.end(), -1.f);
+        EXPECT(msdfhip_batch_generate_host(b, MSDFHIP_MODE_MSDF, W, W, gd.data(), got.data(), got.size(), NULL, &cfg) == MSDFHIP_OK);
+        EXPECT(memcmp(got.data(), want.data(), sizeof(float)*got.size()) == 0);
+    }
+    msdfhip_set_pipeline_chunk(0);
+
+    // 2. rectangles of an atlas with gaps and a negative stride; 8-bit atlas; pinned memory
+    {
+        const int cols = 10, pad = 2, aw = cols*(W+pad), ah = (G+cols-1)/cols*(W+pad);
+        void *pinned = NULL;
+        EXPECT(msdfhip_host_alloc(&pinned, sizeof(float)*(size_t) aw*ah*N) == MSDFHIP_OK);
+        float *atlas = (float *) pinned;
+        for (size_t i = 0; i < (size_t) aw*ah*N; ++i)
+            atlas[i] = -7.f;
+        std::vector<MsdfHipGlyph> ad(gd);
+        for (int g = 0; g < G; ++g) {
+            const int x0 = (g%cols)*(W+pad)+1, y0 = (g/cols)*(W+pad)+1;
+            ad[g].out_offset = g%2 ? (int64_t) (((size_t) (y0+W-1)*aw+x0)*N) : (int64_t) (((size_t) y0*aw+x0)*N);
+            ad[g].row_stride = g%2 ? -aw*N : aw*N;
+        }
+        msdfhip_set_pipeline_chunk(33);
+        EXPECT(msdfhip_batch_generate_host(b, MSDFHIP_MODE_MSDF, W, W, ad.data(), atlas, (size_t) aw*ah*N, NULL, &cfg) == MSDFHIP_OK);
+        msdfhip_set_pipeline_chunk(0);
+        size_t untouched = 0, bad = 0;
+        for (int g = 0; g < G; ++g) {
+            const int x0 = (g%cols)*(W+pad)+1, y0 = (g/cols)*(W+pad)+1;
+            for (int y = 0; y < W; ++y) {
+                const int ay = g%2 ? y0+W-1-y : y0+y;
+                bad += memcmp(atlas+((size_t) ay*aw+x0)*N, want.data()+g*tile+(size_t) y*W*N, sizeof(float)*W*N) != 0;
+            }
+        }
+        for (size_t i = 0; i < (size_t) aw*ah*N; ++i)
+            untouched += atlas[i] == -7.f;
+        EXPECT(bad == 0);
+        EXPECT(untouched == (size_t) aw*ah*N-(size_t) G*tile);
+        std::vector<uint8_t> bytes(G*tile, 0);
+        std::vector<MsdfHipGlyph> bd(gd);
+        EXPECT(msdfhip_batch_generate_bytes_host(b, MSDFHIP_MODE_MSDF, W, W, bd.data(), bytes.data(), bytes.size(), &cfg) == MSDFHIP_OK);
+        size_t nonzero = 0;
+        for (size_t i = 0; i < bytes.size(); ++i)
+            nonzero += bytes[i] != 0;
+        EXPECT(nonzero > bytes.size()/8);
+        bd[G-1].out_offset = (int64_t) bytes.size();                                  // a rectangle outside the buffer must be refused
+        EXPECT(msdfhip_batch_generate_bytes_host(b, MSDFHIP_MODE_MSDF, W, W, bd.data(), bytes.data(), bytes.size(), &cfg) == MSDFHIP_ERR_INVALID);
+        EXPECT(msdfhip_host_free(pinned) == MSDFHIP_OK);
+    }
+    msdfhip_batch_destroy(b);
+
+    // 3. the single-shape entry point from many short-lived threads (fresh team per round, like Workload::finish()), micro-batched
+    for (int round = 0; round < rounds; ++round) {
+        std::atomic<int> mismatches(0), errors(0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < 12; ++t)
+            pool.emplace_back([&, t]() {
+                std::vector<float> px(tile);
+                std::vector<uint8_t> st((size_t) W*W);
+                std::vector<int32_t> local;
+                for (int i = 0; i < 25; ++i) {
+                    const int g = (t*17+i*3+round)%G, c0 = s.gco[g], nC = s.gco[g+1]-c0, e0 = s.co[c0];
+                    local.assign(nC+1, 0);
+                    for (int k = 0; k <= nC; ++k)
+                        local[k] = s.co[c0+k]-e0;
+                    const int rc = msdfhip_generate(MSDFHIP_MODE_MSDF, px.data(), W, W, W*N, 0, local.data(), nC, &s.points[8*(size_t) e0], &s.types[e0], &s.colors[e0],
+                                                    &s.xf[6*(size_t) g], &cfg, (i&1) ? st.data() : NULL);
+                    if (rc != MSDFHIP_OK)
+                        ++errors;
+                    else if (memcmp(px.data(), want.data()+g*tile, sizeof(float)*tile) != 0)
+                        ++mismatches;
+                    else if ((i&1) && memcmp(st.data(), stencil.data()+(size_t) g*W*W, (size_t) W*W) != 0)
+                        ++mismatches;
+                }
+            });
+        for (auto &th : pool)
+            th.join();
+        EXPECT(errors.load() == 0);
+        EXPECT(mismatches.load() == 0);
+    }
+
+    // 4. glyph-sharded over the same device listed several times (one host thread + batch + streams per entry)
+    {
+        const int devices[5] = { 0, 0, 0, 0, 0 };
+        for (int n : { 1, 2, 5 }) {
+            std::fill(got.begin(), got.end(), -1.f);
+            EXPECT(msdfhip_generate_sharded(devices, n, MSDFHIP_MODE_MSDF, W, W, G, s.gco.data(), s.co.data(), s.points.data(), s.types.data(), s.colors.data(),
+                                            gd.data(), got.data(), got.size(), NULL, 0, &cfg) == MSDFHIP_OK);
+            EXPECT(memcmp(got.data(), want.data(), sizeof(float)*got.size()) == 0);
+        }
+    }
+
+    // 5. argument validation never reads past what it was given
+    {
+        MsdfHipBatch *bad = NULL;
+        std::vector<int32_t> gco2(s.gco);
+        gco2[1] = -3;
+        EXPECT(msdfhip_batch_create(&bad, G, gco2.data(), s.co.data(), s.points.data(), s.types.data(), s.colors.data()) == MSDFHIP_ERR_INVALID);
+        EXPECT(msdfhip_batch_create(&bad, G, s.gco.data(), s.co.data(), NULL, s.types.data(), s.colors.data()) == MSDFHIP_ERR_INVALID);
+        std::vector<uint8_t> t2(s.types);
+        t2[3] = 9;
+        EXPECT(msdfhip_batch_create(&bad, G, s.gco.data(), s.co.data(), s.points.data(), t2.data(), s.colors.data()) == MSDFHIP_ERR_INVALID);
+        const int devs[2] = { 0, 77 };
+        EXPECT(msdfhip_generate_sharded(devs, 2, MSDFHIP_MODE_MSDF, W, W, G, s.gco.data(), s.co.data(), s.points.data(), s.types.data(), s.colors.data(),
+                                        gd.data(), got.data(), got.size(), NULL, 0, &cfg) == MSDFHIP_ERR_INVALID);
+    }
+    printf("san_driver: %d failure(s)\n", failures);
+    fflush(stdout);
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+    __lsan_do_leak_check();            // now, and not from an exit handler: the ROCm runtime's own teardown trips a CHECK in its ASan device allocator
+#endif
+#endif
+    _Exit(failures ? 1 : 0);
+}
