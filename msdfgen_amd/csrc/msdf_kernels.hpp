@@ -558,7 +558,11 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
     const bool inside = x < width && yn < height;
     const int ys = gd.flip ? height-1-yn : yn;
     int st = 0;
+#if defined(MSDF_EC_ABLATE) && MSDF_EC_ABLATE == 1                          // measurement only: halo load + store, no classification
+    if (false) {
+#else
     if (inside) {
+#endif
         Neighbourhood nb;
         nb.valid = 0;
         MSDF_UNROLL
@@ -604,7 +608,11 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
     waveSync();
 
     // ---- phase B (lane = queued pair): protectEdges' edgeBetweenTexels tests, densely; a hit protects the owning texel
+#if defined(MSDF_EC_ABLATE) && MSDF_EC_ABLATE <= 2
+    const int nProtect = 0;
+#else
     const int nProtect = itemCount[1];
+#endif
     for (int base = 0; base < nProtect; base += WAVE) {
         const int it = base+lane;
         if (it >= nProtect)
@@ -619,7 +627,11 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
     waveSync();
 
     // ---- phase C (lane = queued test): stage 2, densely; verdicts are OR-ed into the owning texel's word
+#if defined(MSDF_EC_ABLATE) && MSDF_EC_ABLATE <= 3
+    const int nItems = 0;
+#else
     const int nItems = itemCount[0];
+#endif
     for (int base = 0; base < nItems; base += WAVE) {
         const int it = base+lane;
         if (it >= nItems)
