@@ -207,10 +207,10 @@ int msdfhip_batch_generate(const MsdfHipBatch *batch, int mode, int width, int h
 /* End to end into HOST memory (what replaces an atlas generator's loop of generate*() calls into caller-owned bitmaps,
  * core/msdfgen.cpp:52-76, README.md:133): HOST descriptors, HOST output. The glyph list is processed in chunks on two streams, so the
  * kernels of one chunk overlap the device-to-host copy of the previous one; synchronous for the caller.
- *   glyphs[g].out_offset / row_stride place tile g in `out` (floats). When the tiles are packed in glyph order (out_offset =
- *   base + g*w*h*N, row_stride = w*N) every chunk is ONE contiguous copy straight into `out`; any other placement (rectangles of a
- *   larger atlas, negative strides) is copied into pinned staging and scattered row by row on the host while the next chunk runs --
- *   texels outside the rectangles are never touched.
+ *   glyphs[g].out_offset / row_stride place tile g in `out` (floats). A chunk whose rectangles exactly tile one contiguous range of
+ *   `out` (tiles packed in glyph order; glyphs in row-major order filling whole row bands of an atlas) is written by the device in that
+ *   layout and copied back as ONE contiguous copy; any other placement (gaps, negative strides) is copied into pinned staging and
+ *   scattered row by row on the host while the next chunk runs -- texels outside the rectangles are never touched.
  *   stencil: NULL or n_glyphs*width*height bytes; written only when an error-correction pass runs (like the reference's buffer).
  * For full copy speed `out` should be pinned (msdfhip_host_alloc); pageable memory works, the runtime then stages the copies. */
 int msdfhip_batch_generate_host(const MsdfHipBatch *batch, int mode, int width, int height, const MsdfHipGlyph *glyphs,
@@ -220,7 +220,7 @@ int msdfhip_batch_generate_host(const MsdfHipBatch *batch, int mode, int width, 
  * `atlas`. The copy back is a quarter of the float tiles'. */
 int msdfhip_batch_generate_bytes_host(const MsdfHipBatch *batch, int mode, int width, int height, const MsdfHipGlyph *glyphs,
                                       uint8_t *atlas, size_t atlas_bytes, const MsdfHipConfig *cfg);
-/* Glyphs per pipeline chunk (0 = automatic: about 48 MB of float tiles). */
+/* Glyphs per pipeline chunk (0 = automatic: about 96 MB of float tiles). */
 int msdfhip_set_pipeline_chunk(int glyphs_per_chunk);
 /* Pinned (page-locked, portable across devices) host memory for outputs of the two functions above. */
 int msdfhip_host_alloc(void **p, size_t bytes);

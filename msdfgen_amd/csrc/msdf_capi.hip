@@ -39,7 +39,7 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
-#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(MSDFHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void) hipGetLastError(); return fail(MSDFHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
 
 // Binds the calling thread to `dev` (>= 0: the device a batch lives on) or to the process default (msdfhip_init; device 0 if never called).
 int ensureDevice(int dev = -1) {
@@ -50,8 +50,10 @@ int ensureDevice(int dev = -1) {
     }
     if (dev < 0)
         dev = gDevice.load();
-    if (hipSetDevice(dev) != hipSuccess)
+    if (hipSetDevice(dev) != hipSuccess) {
+        (void) hipGetLastError();                                // HIP's last error is sticky: do not leave it for an unrelated later check
         return fail(MSDFHIP_ERR_NO_DEVICE, "hipSetDevice(%d) failed", dev);
+    }
     return MSDFHIP_OK;
 }
 
@@ -123,8 +125,6 @@ struct ScopedTimer {
 
 } // namespace
 
-struct PipeSlot;
-
 struct MsdfHipBatch {
     int device;                       // the HIP device the batch lives on; every call on the batch binds the calling thread to it
     int nGlyphs, nContours, nEdges, maxContours, maxEdges;
@@ -153,15 +153,11 @@ struct MsdfHipBatch {
     mutable bool bucketUploaded;
     mutable int nOne, nSmall, smallMaxC, smallMaxE, oneMaxE;
     int glyphCap;                     // per-glyph work buffers are sized for max(nGlyphs, glyphCap) glyphs (views of the host-output pipeline)
-    mutable PipeSlot *pipe;           // the two slots of the host-output pipeline (msdfhip_batch_generate_host / _bytes_host), lazily created
-    mutable std::mutex pipeMutex;     // one host-output call at a time per batch
     MsdfHipBatch() : device(0), nGlyphs(0), nContours(0), nEdges(0), maxContours(0), maxEdges(0), ownsInputs(false), dGlyphContourOffsets(NULL),
                      dContourOffsets(NULL), dPoints(NULL), dTypes(NULL), dColors(NULL), dRecs(NULL), dWindings(NULL), dScratch(NULL), scratchFloats(0),
                      dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
-                     smallMaxC(0), smallMaxE(0), oneMaxE(0), glyphCap(0), pipe(NULL) { }
+                     smallMaxC(0), smallMaxE(0), oneMaxE(0), glyphCap(0) { }
 };
-
-static void destroyPipe(const MsdfHipBatch *b);
 
 namespace {
 
@@ -724,6 +720,14 @@ int msdfhip_batch_create_on(MsdfHipBatch **batch, int device, int n_glyphs, cons
     int rc = checkShapeArrays(n_glyphs, gco, co, points, types, colors, true, hContours, hEdges, maxC, maxE);
     if (rc != MSDFHIP_OK)
         return rc;
+    if (device >= 0) {
+        int count = 0;
+        rc = msdfhip_device_count(&count);
+        if (rc != MSDFHIP_OK)
+            return rc;
+        if (device >= count)
+            return fail(MSDFHIP_ERR_INVALID, "device %d out of range (0..%d)", device, count-1);
+    }
     rc = ensureDevice(device);
     if (rc != MSDFHIP_OK)
         return rc;
@@ -771,8 +775,10 @@ int msdfhip_device_count(int *count) {
     if (!count)
         return fail(MSDFHIP_ERR_INVALID, "NULL argument");
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void) hipGetLastError();
         return fail(MSDFHIP_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    }
     *count = n;
     return MSDFHIP_OK;
 }
@@ -955,7 +961,6 @@ void msdfhip_batch_destroy(MsdfHipBatch *b) {
     if (!b)
         return;
     (void) hipSetDevice(b->device);
-    destroyPipe(b);
     if (b->ownsInputs) {
         hipFree(b->dGlyphContourOffsets);
         hipFree(b->dContourOffsets);
@@ -1178,45 +1183,51 @@ struct PipeSlot {
     MsdfHipBatch view;                // glyph range of the parent batch + this slot's own work buffers
 };
 
-static void destroyPipe(const MsdfHipBatch *b) {
-    if (!b->pipe)
-        return;
-    for (int k = 0; k < 2; ++k) {
-        PipeSlot &p = b->pipe[k];
-        if (p.stream) {
-            hipStreamSynchronize(p.stream);
-            hipStreamDestroy(p.stream);
-        }
-        if (p.done)
-            hipEventDestroy(p.done);
-        hipFree(p.dev);
-        if (p.pinnedGlyphs)
-            pinnedFree(p.pinnedGlyphs);
-        if (p.pinnedTiles)
-            pinnedFree(p.pinnedTiles);
-        hipFree(p.view.dScratch), hipFree(p.view.dDeferred), hipFree(p.view.dEcParams), hipFree(p.view.dGres), hipFree(p.view.dBucket);
-        if (p.view.hBucket)
-            pinnedFree(p.view.hBucket);
-    }
-    delete[] b->pipe;
-    b->pipe = NULL;
-}
+// The two slots of a pipeline in flight. Pipelines live in a process-wide pool per device (like the arenas of the single-shape calls):
+// a host-output call takes one and returns it, so that a caller that builds a fresh batch per atlas does not pay for 100+ MB of
+// device / pinned allocations every time; the pool is bounded by the peak number of concurrent host-output calls.
+struct Pipe {
+    int device;
+    PipeSlot slot[2];
+};
 
-static int ensurePipe(const MsdfHipBatch *b) {
-    if (b->pipe)
+static std::mutex gPipeMutex;
+static std::vector<Pipe *> gPipePool;
+
+struct PipeLease {
+    Pipe *p;
+    PipeLease() : p(NULL) { }
+    ~PipeLease() {
+        if (p) {
+            std::lock_guard<std::mutex> lock(gPipeMutex);
+            gPipePool.push_back(p);
+        }
+    }
+    int take(int device) {
+        {
+            std::lock_guard<std::mutex> lock(gPipeMutex);
+            for (size_t i = gPipePool.size(); i-- > 0; )
+                if (gPipePool[i]->device == device) {
+                    p = gPipePool[i];
+                    gPipePool.erase(gPipePool.begin()+i);
+                    return MSDFHIP_OK;
+                }
+        }
+        Pipe *fresh = new Pipe();
+        fresh->device = device;
+        for (int k = 0; k < 2; ++k) {
+            PipeSlot &s = fresh->slot[k];
+            s.stream = NULL, s.done = NULL, s.busy = false, s.dev = NULL, s.devCap = 0, s.pinnedGlyphs = NULL, s.pinnedGlyphCap = 0, s.viewCap = 0;
+            s.pinnedTiles = NULL, s.pinnedTilesCap = 0, s.pendingFirst = 0, s.pendingCount = 0;
+        }
+        p = fresh;                                               // (returned to the pool even if a creation below fails: its handles stay NULL-safe)
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(hipStreamCreateWithFlags(&fresh->slot[k].stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&fresh->slot[k].done, hipEventDisableTiming));
+        }
         return MSDFHIP_OK;
-    b->pipe = new PipeSlot[2];
-    for (int k = 0; k < 2; ++k) {
-        PipeSlot &p = b->pipe[k];
-        p.stream = NULL, p.done = NULL, p.busy = false, p.dev = NULL, p.devCap = 0, p.pinnedGlyphs = NULL, p.pinnedGlyphCap = 0, p.viewCap = 0;
-        p.pinnedTiles = NULL, p.pinnedTilesCap = 0, p.pendingFirst = 0, p.pendingCount = 0;
     }
-    for (int k = 0; k < 2; ++k) {
-        HIPCHK(hipStreamCreateWithFlags(&b->pipe[k].stream, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&b->pipe[k].done, hipEventDisableTiming));
-    }
-    return MSDFHIP_OK;
-}
+};
 
 // Points slot.view at glyphs [g0, g0+n) of b (shared, read-only inputs; the slot keeps its own work buffers across chunks and calls).
 static void sliceBatch(const MsdfHipBatch *b, MsdfHipBatch &v, int g0, int n) {
@@ -1252,7 +1263,7 @@ static int fetchGlyphCounts(const MsdfHipBatch *b) {             // device-array
     return MSDFHIP_OK;
 }
 
-static std::atomic<int> gPipeChunkGlyphs(0);                     // 0 = automatic (about 48 MB of float tiles per chunk)
+static std::atomic<int> gPipeChunkGlyphs(0);                     // 0 = automatic (about 96 MB of float tiles per chunk)
 
 // Rows of the chunk waiting in the slot's pinned staging -> the caller's rectangles (any offsets / strides; nothing else is touched).
 static void scatterPending(PipeSlot &p, const MsdfHipGlyph *glyphs, char *dst, size_t elem, int w, int h, int N) {
@@ -1281,30 +1292,27 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
     const int nG = b->nGlyphs, N = channelsOf(mode);
     if (nG == 0 || w == 0 || h == 0)
         return MSDFHIP_OK;
-    std::lock_guard<std::mutex> lock(b->pipeMutex);
-    rc = ensurePipe(b);
+    PipeLease lease;
+    rc = lease.take(b->device);
     if (rc == MSDFHIP_OK)
         rc = fetchGlyphCounts(b);
     if (rc != MSDFHIP_OK)
         return rc;
+    PipeSlot *pipe = lease.p->slot;
     const size_t texels = (size_t) w*h, tile = texels*N;         // floats per tile; also bytes per 8-bit tile
     const size_t total = out ? outFloats : atlasBytes, elem = out ? sizeof(float) : 1;
-    // every rectangle must lie inside the caller's buffer. packed: the tiles follow each other in glyph order from `base` on, rows
-    // contiguous -> a chunk is ONE contiguous device-to-host copy straight into the caller's memory. Any other placement (rectangles of
-    // a larger atlas, negative strides): the chunk is copied into pinned staging and its rows are scattered on the host while the next
-    // chunk runs -- texels outside the rectangles are never touched, and devices sharing one atlas cannot disturb each other.
-    const long long base = glyphs[0].out_offset;
-    bool packed = true;
+    // every rectangle must lie inside the caller's buffer (how a chunk travels back is decided per chunk below: one contiguous copy when
+    // its rectangles exactly tile a contiguous range, else pinned staging + a row scatter on the host; either way texels outside the
+    // rectangles are never touched, and devices sharing one atlas cannot disturb each other)
     for (int g = 0; g < nG; ++g) {
         const long long o = glyphs[g].out_offset, rs = glyphs[g].row_stride;
         const long long lo = rs >= 0 ? o : o+rs*(h-1), hi = (rs >= 0 ? o+rs*(h-1) : o)+(long long) w*N;
         if (lo < 0 || (unsigned long long) hi > total)
             return fail(MSDFHIP_ERR_INVALID, "glyph %d's rectangle [%lld, %lld) lies outside the output buffer of %zu elements", g, lo, hi, total);
-        packed = packed && o == base+(long long) ((size_t) g*tile) && rs == w*N;
     }
     int chunk = gPipeChunkGlyphs.load();
     if (chunk <= 0) {
-        chunk = (int) ((48u<<20)/(tile*sizeof(float) ? tile*sizeof(float) : 1));
+        chunk = (int) ((96u<<20)/(tile*sizeof(float) ? tile*sizeof(float) : 1));   // measured on 8192 64x64 glyphs: 512 / 1024 / 2048 / 4096 glyphs per chunk -> 18.6 / 14.6 / 12.7 / 14.7 ms
         chunk = chunk < 64 ? 64 : chunk/64*64;
     }
     if (chunk > nG)
@@ -1312,11 +1320,11 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
     const bool correct = mode >= 3 && cfg->ec_mode != MSDFHIP_EC_DISABLED;
     const bool wantStencil = stencil != NULL && correct;         // the reference leaves the caller's buffer alone when no correction runs
     char *dstBytes = out ? reinterpret_cast<char *>(out) : reinterpret_cast<char *>(atlas);
-    const size_t offGlyphs = 0, offTiles = ((size_t) chunk*sizeof(MsdfHipGlyph)+255)/256*256, tilesBytes = ((size_t) chunk*tile*sizeof(float)+255)/256*256;
+    const size_t offGlyphs = 0, offTiles = (2*(size_t) chunk*sizeof(MsdfHipGlyph)+255)/256*256, tilesBytes = ((size_t) chunk*tile*sizeof(float)+255)/256*256;
     const size_t offStencil = offTiles+tilesBytes, stencilBytes = wantStencil ? ((size_t) chunk*texels+255)/256*256 : 0;
     const size_t offBytes = offStencil+stencilBytes, devBytes = offBytes+(atlas ? (size_t) chunk*tile : 0)+256;
     for (int k = 0; k < 2; ++k) {
-        PipeSlot &p = b->pipe[k];
+        PipeSlot &p = pipe[k];
         if (p.devCap < devBytes) {
             HIPCHK(hipStreamSynchronize(p.stream));
             if (p.dev)
@@ -1329,15 +1337,8 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
             if (p.pinnedGlyphs)
                 HIPCHK(pinnedFree(p.pinnedGlyphs));
             p.pinnedGlyphs = NULL, p.pinnedGlyphCap = 0;
-            HIPCHK(pinnedAlloc((void **) &p.pinnedGlyphs, sizeof(MsdfHipGlyph)*(size_t) chunk));
+            HIPCHK(pinnedAlloc((void **) &p.pinnedGlyphs, sizeof(MsdfHipGlyph)*2*(size_t) chunk));
             p.pinnedGlyphCap = (size_t) chunk;
-        }
-        if (!packed && p.pinnedTilesCap < (size_t) chunk*tile*elem) {
-            if (p.pinnedTiles)
-                HIPCHK(pinnedFree(p.pinnedTiles));
-            p.pinnedTiles = NULL, p.pinnedTilesCap = 0;
-            HIPCHK(pinnedAlloc((void **) &p.pinnedTiles, (size_t) chunk*tile*elem));
-            p.pinnedTilesCap = (size_t) chunk*tile*elem;
         }
         if (p.viewCap < chunk) {                                 // per-glyph work buffers of the view: reallocated on demand by the launches
             HIPCHK(hipStreamSynchronize(p.stream));
@@ -1353,7 +1354,7 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
     int slot = 0;
     for (int g0 = 0; g0 < nG && rc == MSDFHIP_OK; g0 += chunk, slot ^= 1) {
         const int n = nG-g0 < chunk ? nG-g0 : chunk;
-        PipeSlot &p = b->pipe[slot];
+        PipeSlot &p = pipe[slot];
         if (p.busy) {                                            // the slot's previous copy must have left its buffers
             HIPCHK(hipEventSynchronize(p.done));
             p.busy = false;
@@ -1365,24 +1366,56 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
         float *dTiles = reinterpret_cast<float *>(p.dev+offTiles);
         uint8_t *dStencil = wantStencil ? reinterpret_cast<uint8_t *>(p.dev+offStencil) : NULL;
         uint8_t *dBytes = reinterpret_cast<uint8_t *>(p.dev+offBytes);
-        for (int g = 0; g < n; ++g) {                            // the device always renders the chunk as packed tiles (same numbers in floats and bytes)
+        // dense: the chunk's rectangles exactly tile one contiguous range of the caller's buffer (tiles packed in glyph order; whole
+        // row bands of an atlas) -> the device writes that range in the caller's layout and it goes back as ONE copy. Otherwise the
+        // chunk is rendered as packed tiles, copied into pinned staging and scattered row by row on the host (pendingCount).
+        long long spanLo = glyphs[g0].out_offset, spanHi = spanLo;
+        bool dense = true;
+        for (int g = 0; g < n; ++g) {
+            const long long o = glyphs[g0+g].out_offset, rs = glyphs[g0+g].row_stride;
+            dense = dense && rs >= (long long) w*N;
+            const long long lo = rs >= 0 ? o : o+rs*(h-1), hi = (rs >= 0 ? o+rs*(h-1) : o)+(long long) w*N;
+            spanLo = lo < spanLo ? lo : spanLo, spanHi = hi > spanHi ? hi : spanHi;
+        }
+        dense = dense && (unsigned long long) (spanHi-spanLo) == (unsigned long long) n*tile;
+        const bool floatsInCallerLayout = out != NULL && dense;
+        for (int g = 0; g < n; ++g) {                            // descriptors of the generators: the caller's layout (relative to the range) or packed tiles
             p.pinnedGlyphs[g] = glyphs[g0+g];
-            p.pinnedGlyphs[g].out_offset = (int64_t) ((size_t) g*tile), p.pinnedGlyphs[g].row_stride = w*N;
+            if (floatsInCallerLayout)
+                p.pinnedGlyphs[g].out_offset -= spanLo;
+            else
+                p.pinnedGlyphs[g].out_offset = (int64_t) ((size_t) g*tile), p.pinnedGlyphs[g].row_stride = w*N;
         }
         HIPCHK(hipMemcpyAsync(dGlyphs, p.pinnedGlyphs, sizeof(MsdfHipGlyph)*(size_t) n, hipMemcpyHostToDevice, p.stream));
         rc = msdfhip_batch_generate(&p.view, mode, w, h, dGlyphs, dTiles, dStencil, NULL, cfg, p.stream);
         if (rc != MSDFHIP_OK)
             break;
         const char *dResult = reinterpret_cast<const char *>(dTiles);
-        if (atlas) {
-            rc = msdfhip_tiles_to_bytes(dTiles, n, w, h, N, dGlyphs, dBytes, p.stream);
+        if (atlas) {                                             // the conversion reads the packed float tiles and blits into the byte layout
+            MsdfHipGlyph *hBlit = p.pinnedGlyphs+p.pinnedGlyphCap, *dBlit = dGlyphs+chunk;
+            for (int g = 0; g < n; ++g) {
+                hBlit[g] = glyphs[g0+g];
+                if (dense)
+                    hBlit[g].out_offset -= spanLo;
+                else
+                    hBlit[g].out_offset = (int64_t) ((size_t) g*tile), hBlit[g].row_stride = w*N;
+            }
+            HIPCHK(hipMemcpyAsync(dBlit, hBlit, sizeof(MsdfHipGlyph)*(size_t) n, hipMemcpyHostToDevice, p.stream));
+            rc = msdfhip_tiles_to_bytes(dTiles, n, w, h, N, dBlit, dBytes, p.stream);
             if (rc != MSDFHIP_OK)
                 break;
             dResult = reinterpret_cast<const char *>(dBytes);
         }
-        if (packed)
-            HIPCHK(hipMemcpyAsync(dstBytes+((size_t) base+(size_t) g0*tile)*elem, dResult, (size_t) n*tile*elem, hipMemcpyDeviceToHost, p.stream));
+        if (dense)
+            HIPCHK(hipMemcpyAsync(dstBytes+(size_t) spanLo*elem, dResult, (size_t) n*tile*elem, hipMemcpyDeviceToHost, p.stream));
         else {
+            if (p.pinnedTilesCap < (size_t) chunk*tile*elem) {
+                if (p.pinnedTiles)
+                    HIPCHK(pinnedFree(p.pinnedTiles));
+                p.pinnedTiles = NULL, p.pinnedTilesCap = 0;
+                HIPCHK(pinnedAlloc((void **) &p.pinnedTiles, (size_t) chunk*tile*elem));
+                p.pinnedTilesCap = (size_t) chunk*tile*elem;
+            }
             HIPCHK(hipMemcpyAsync(p.pinnedTiles, dResult, (size_t) n*tile*elem, hipMemcpyDeviceToHost, p.stream));
             p.pendingFirst = g0, p.pendingCount = n;
         }
@@ -1392,7 +1425,7 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
         p.busy = true;
     }
     for (int k = 0; k < 2; ++k) {
-        PipeSlot &p = b->pipe[k];
+        PipeSlot &p = pipe[k];
         hipError_t e = hipStreamSynchronize(p.stream);
         p.busy = false;
         if (e != hipSuccess && rc == MSDFHIP_OK)
