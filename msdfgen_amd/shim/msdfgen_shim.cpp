@@ -9,6 +9,7 @@
 //
 // Differences from the reference that a caller can observe: none in the texels (see tests); the functions can now fail (no
 // device, HIP error) and there is deliberately NO CPU fallback -- failures throw std::runtime_error with the library's message.
+#include <atomic>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -88,9 +89,20 @@ MsdfHipConfig makeConfig(bool overlapSupport, const ErrorCorrectionConfig *ec) {
     return cfg;
 }
 
+// The reference's functions return void and cannot fail; these can (no device, HIP error, shape too complex). By default a failure
+// throws std::runtime_error -- also out of a caller's worker thread. A host that cannot take exceptions there switches to the status
+// mode (msdfgen_hip_shim_set_nothrow(1)): a failed call leaves the output untouched and records the status for the calling thread.
+std::atomic<int> gNoThrow(0);
+thread_local int tlsStatus = MSDFHIP_OK;
+thread_local std::string tlsMessage;
+
 void check(int rc, const char *what) {
-    if (rc != MSDFHIP_OK)
-        throw std::runtime_error(std::string("msdfgen_hip: ")+what+" failed: "+msdfhip_last_error());
+    tlsStatus = rc;
+    if (rc == MSDFHIP_OK)
+        return;
+    tlsMessage = std::string("msdfgen_hip: ")+what+" failed: "+msdfhip_last_error();
+    if (!gNoThrow.load())
+        throw std::runtime_error(tlsMessage);
 }
 
 template <int N>
@@ -260,4 +272,13 @@ void distanceSignCorrection(const BitmapSection<float, 4> &sdf, const Shape &sha
     signCorrect<4>(sdf, shape, Projection(scale, translate), .5f, fillRule);
 }
 
+}
+
+// ---- failure reporting of the shim (not part of msdfgen's API) -----------------------------------------------------------------
+extern "C" {
+// 1: failed calls no longer throw; query msdfgen_hip_shim_last_status() / _last_error() on the same thread after a call.
+void msdfgen_hip_shim_set_nothrow(int enable) { msdfgen::gNoThrow.store(enable ? 1 : 0); }
+// MSDFHIP_OK (0) or the MSDFHIP_ERR_* code of the calling thread's last shim call.
+int msdfgen_hip_shim_last_status(void) { return msdfgen::tlsStatus; }
+const char *msdfgen_hip_shim_last_error(void) { return msdfgen::tlsStatus == MSDFHIP_OK ? "" : msdfgen::tlsMessage.c_str(); }
 }

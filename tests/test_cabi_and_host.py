@@ -96,3 +96,46 @@ def test_partition_is_contiguous_balanced_and_deterministic(latin):
         assert sums.max() <= costs.sum()/parts+costs.max()
     assert np.array_equal(partition_contiguous([1, 1, 1, 1], 2), [0, 2, 4])
     assert np.array_equal(partition_contiguous([], 3), [0, 0, 0, 0])
+
+
+def test_shim_status_mode_without_a_device():
+    """The C++ shim's non-throwing mode: without a device every generator fails; with msdfgen_hip_shim_set_nothrow(1)
+    the failure is a per-thread status instead of a std::runtime_error thrown out of the caller's thread. Runs in a child process
+    (the default mode would terminate a ctypes caller)."""
+    import subprocess
+    import sys
+    import textwrap
+    from msdfgen_amd import build as B
+    shim = B.build_shim()
+    if shim is None:
+        pytest.skip("msdfgen headers not available: shim not built")
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    from oracle.pyoracle import REF_SO
+    if not os.path.exists(REF_SO):
+        pytest.skip("the shim links against msdfgen's other objects (here: oracle/_ref), not present")
+    code = textwrap.dedent("""
+        import ctypes as C, sys
+        C.CDLL(%r, mode=C.RTLD_GLOBAL)                       # msdfgen's untouched parts (Projection, DistanceMapping, ...)
+        C.CDLL(%r, mode=C.RTLD_GLOBAL)
+        shim = C.CDLL(%r)
+        shim.msdfgen_hip_shim_last_error.restype = C.c_char_p
+        assert shim.msdfgen_hip_shim_last_status() == 0
+        shim.msdfgen_hip_shim_set_nothrow(1)
+        # renderSDF(BitmapSection<float,1>, BitmapConstSection<float,1>, Range, float): plain structs of pointer + 4 ints, passed by reference
+        class Section(C.Structure):
+            _fields_ = [("pixels", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("rowStride", C.c_int), ("yOrientation", C.c_int)]
+        buf = (C.c_float*16)()
+        a, b = Section(C.addressof(buf), 4, 4, 4, 0), Section(C.addressof(buf), 4, 4, 4, 0)
+        class Range(C.Structure):
+            _fields_ = [("lower", C.c_double), ("upper", C.c_double)]
+        fn = getattr(shim, "_ZN7msdfgen9renderSDFERKNS_13BitmapSectionIfLi1EEERKNS_18BitmapConstSectionIfLi1EEENS_5RangeEf")
+        fn.argtypes = [C.POINTER(Section), C.POINTER(Section), Range, C.c_float]
+        fn(C.byref(a), C.byref(b), Range(-1, 1), C.c_float(.5))
+        assert shim.msdfgen_hip_shim_last_status() == -1, shim.msdfgen_hip_shim_last_status()      # MSDFHIP_ERR_NO_DEVICE
+        assert b"no HIP device" in shim.msdfgen_hip_shim_last_error()
+        print("ok")
+    """) % (REF_SO, B.LIB, shim)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-1500:]
