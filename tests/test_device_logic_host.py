@@ -222,3 +222,28 @@ def test_cooperative_psdf_query_equals_sequential(emu, oracle, latin):
             got = emu.psdf_cooperative(s, overlap, pts)
             assert_bit_equal(got, want, "cooperative PSDF, overlap=%s, %d edges" % (overlap, s.n_edges))
             assert_bit_equal(emu.psdf_cooperative(s, overlap, pts, slotted=True), want, "slotted cooperative PSDF, overlap=%s" % overlap)
+
+
+def test_combiner_restructuring_on_nested_and_overlapping_contours(emu, oracle):
+    """The overlapping combiner as the device walks it (only the shape selector merged eagerly, inner / outer selectors by member count
+    with a second walk for 2+ members; nearest-first survivor order with the visit-index tie-break; msdf_device.hpp) against the oracle
+    on the inputs that exercise it: the font glyphs with the most contours and the hashes of the reference fixture, heavily overlapping
+    blobs (texels inside several contours at once), the 40-contour logo, all selectors."""
+    import hashlib
+    from msdfgen_amd.shape import ShapeBatch
+    z = load_npz("dejavu8192.npz")
+    batch = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
+                       z["colors"].astype(np.int32), np.zeros(len(z["names"]), bool), [str(n) for n in z["names"]])
+    n_c = np.diff(batch.glyph_contour_offsets)
+    for g in sorted(set(np.argsort(n_c)[-6:].tolist()+list(range(5, 8192, 683)))):
+        got = emu.generate(batch.shape(g), 3, 48, 48, z["xf48"][g])
+        assert (np.frombuffer(hashlib.sha256(got.tobytes()).digest(), np.uint8) == z["sha48"][g]).all(), (g, batch.names[g], int(n_c[g]))
+    for seed in range(4):
+        s = synth.random_shape(100+seed, n_contours=6, spread=.25)
+        xf = autoframe(s.bounds(), 36, 36, 4)
+        for mode in (1, 2, 3, 4):
+            assert_bit_equal(emu.generate(s, mode, 36, 36, xf), oracle.generate(s, mode, 36, 36, xf), "overlapping blobs %d mode %d" % (seed, mode))
+        assert_bit_equal(emu.generate(s, 3, 36, 36, xf, ec_dist=2), oracle.generate(s, 3, 36, 36, xf, ec_dist=2), "overlapping blobs %d, always check" % seed)
+    logo = synth.logo_shape(5)
+    xf = autoframe(logo.bounds(), 48, 48, 4)
+    assert_bit_equal(emu.generate(logo, 3, 48, 48, xf), oracle.generate(logo, 3, 48, 48, xf), "logo 48x48")

@@ -42,7 +42,7 @@ def main():
         overlap = bool(rng.integers(0, 2))
         ec_mode, ec_dist = int(rng.integers(0, 4)), int(rng.integers(0, 3))
         px_range = min(float(rng.choice([2, 4, 8, 1.5])), .45*min(w, h))      # autoframe needs room for the range inside the tile
-        kind = int(rng.integers(0, 4))
+        kind = int(rng.integers(0, 5))
         shapes = []
         for i in range(n):
             sd = int(rng.integers(0, 2**31))
@@ -52,6 +52,8 @@ def main():
                 s = synth.random_shape(sd, n_contours=int(rng.integers(1, 3)), edges_per_contour=(3, 14), kinds=(3,), wobble=.6)
             elif kind == 2:
                 s = synth.cjk_like_shape(sd)
+            elif kind == 4:                                                   # heavily overlapping / nested blobs: texels inside several contours at once
+                s = synth.random_shape(sd, n_contours=int(rng.integers(3, 8)), kinds=(1, 2, 3), spread=.25, holes=bool(sd & 1))
             else:
                 s = synth.random_shape(sd, n_contours=int(rng.integers(4, 12)), edges_per_contour=(3, 6), kinds=(1, 2), spread=.9)
             s.inverse_y = bool(rng.integers(0, 2))
