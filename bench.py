@@ -219,7 +219,7 @@ def end_to_end(M, batch, xfs, w, h, reps=3):
 
 def spawn(args):
     """`python bench.py --gpus N` outside torchrun: re-launch under torch.distributed.run, one rank per GPU."""
-    if not args.mock:
+    if not args.mock and not args.same_device:
         import torch
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if have < args.gpus:
@@ -269,6 +269,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / secondary / quality (profiling runs)")
     ap.add_argument("--simple-combiner", action="store_true", help="experiment: overlapSupport=false (NOT the headline config)")
     ap.add_argument("--mock", action="store_true", help="CPU rehearsal of the multi-rank control path (gloo, no kernels); used by the tests")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal of the N > 1 path on a ONE-GPU box: every rank uses cuda:0 and the process "
+                                                                "group is gloo (RCCL refuses two ranks on one device); the number is not a scaling result")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -290,12 +292,17 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: msdfgen_amd has no CPU compute path")
+    if args.same_device:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d has no GPU (only %d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        if args.same_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
     M.init(local_rank)
     lib = M.load()
 
@@ -313,7 +320,7 @@ def main():
 
     elapsed, dist_ms, ec_ms, launches = timed_steps(M, torch, dist, lib, gb, desc, out, cfg, w, h, args.steps, args.warmup, world, dev, stream)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.same_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -333,7 +340,8 @@ def main():
                                    "step = digest + distance field + error correction, inputs/outputs resident in HBM" % (
                                        w, h, args.glyphs, batch.n_edges/batch.n_glyphs, batch.n_contours/batch.n_glyphs),
                        "glyphs_per_gpu": args.glyphs, "tile": [w, h], "mode": "msdf",
-                       "parallelism": "glyph-sharded x%d by W*H*E (msdfgen_amd.shard), no collective; rank 0 owns glyphs [%d, %d) of %d" % (world, lo, hi, world*args.glyphs)},
+                       "parallelism": "glyph-sharded x%d by W*H*E (msdfgen_amd.shard), no collective; rank 0 owns glyphs [%d, %d) of %d%s" % (
+                           world, lo, hi, world*args.glyphs, " -- REHEARSAL: all ranks on one GPU, gloo" if args.same_device else "")},
             "roofline": {"bound": "hbm", "kernel": "k_distance<3,...> distance pass (msdf; three launches: 1-contour glyphs / combiner scratch in LDS / in the global workspace)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS,
                          "traffic": prof["hbm_bytes_per_launch"] if prof else None,
