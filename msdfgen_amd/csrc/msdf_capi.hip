@@ -524,10 +524,15 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
         return rc;
     // k_ec_query parks the single-edge selector states of a glyph in LDS (40 B per edge) when the glyph has at most slotCap edges; its
     // combiner scratch is one double per contour (wave-uniform query point)
-    const int slotCap = b->maxEdges < 1024 ? (b->maxEdges > 0 ? b->maxEdges : 1) : 1024;
+    // (both bounded so that the kernel's LDS does not cap its occupancy -- one 543-edge symbol in the batch had cost every wavefront
+    // 22 KB; measured: 2.67 -> 2.60 ms of correction on the distinct-glyph set)
+    int slotCapWanted = 160, lpcContoursWanted = 8;
+    if (const char *env = getenv("MSDFHIP_QUERY_LDS"))           // experiment knob: "slotCap,lpcMaxContours"
+        sscanf(env, "%d,%d", &slotCapWanted, &lpcContoursWanted);
+    const int slotCap = b->maxEdges < slotCapWanted ? (b->maxEdges > 0 ? b->maxEdges : 1) : slotCapWanted;
     // LDS of a query wavefront: the lane-per-candidate scratch [maxContours][64], or (cooperative) [maxContours] + the slots -- one or the other
     EcQueryPolicy lpcMaxContours;
-    lpcMaxContours.lpcMaxContours = b->maxContours < 192 ? b->maxContours : 192;     // beyond: cooperative only (one double per contour)
+    lpcMaxContours.lpcMaxContours = b->maxContours < lpcContoursWanted ? b->maxContours : lpcContoursWanted;     // beyond: cooperative only (one double per contour)
     // Measured on MI355X (post-distance time in ms: Basic-Latin / CJK-like 48x48 / 8192 DejaVu glyphs / 1024x1024 logo):
     //   cooperative only 1.98 / 5.35 / 2.83 / 4.60;  lane-per-candidate wherever the instruction count favours it 1.76 / 3.57 / 4.23 / 10.3;
     //   lane-per-candidate only for glyphs of at most 48 edges 1.75 / 5.40 / 2.67 / 4.62  <- default: a chunk of a large glyph is one long
