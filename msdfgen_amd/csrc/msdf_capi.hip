@@ -251,7 +251,7 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
     if (nG == 0)
         return MSDFHIP_OK;
     const int tpw = GRES ? 1 : (int) QUAD;                        // tiles per wavefront (msdf_kernels.hpp)
-    const size_t blocks = (size_t) ((nG+7)/8)*8u*(size_t) ((tiles+tpw-1)/tpw);
+    const size_t blocks = (size_t) nG*(size_t) ((tiles+tpw-1)/tpw);               // decodeBlock (msdf_kernels.hpp)
     if (blocks > 0x7fffffffull)
         return fail(MSDFHIP_ERR_INVALID, "launch of %zu tile quads exceeds the grid limit; split the batch", blocks);
     int rc = setLds(k_distance<SEL, OVERLAP, GRES>, plan.bytes);
@@ -489,7 +489,7 @@ template <int N, bool OVERLAP, bool GRES>
 int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, const float *src, float *out, uint8_t *stencil,
              const MsdfHipConfig &cfg, hipStream_t stream) {
     const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE, tiles = tilesX*tilesY;
-    const unsigned blocks = (unsigned) ((b->nGlyphs+7)/8)*8u*(unsigned) tiles;
+    const unsigned blocks = (unsigned) b->nGlyphs*(unsigned) tiles;
     const size_t allTexels = (size_t) b->nGlyphs*w*h;
     if (allTexels >= 0xffffffffull)
         return fail(MSDFHIP_ERR_INVALID, "batch of %zu texels exceeds the 32-bit texel index of the error-correction pass; split the batch", allTexels);
@@ -621,7 +621,7 @@ int launchSign(const MsdfHipBatch *b, int w, int h, const MsdfHipGlyph *dGlyphs,
     while (span > 1 && (size_t) b->nGlyphs*tilesY*((tilesX+span-1)/span) < 4096)
         span = (span+1)/2;
     const int spansX = (tilesX+span-1)/span, spans = spansX*tilesY;
-    const size_t blocks = (size_t) ((b->nGlyphs+7)/8)*8u*(size_t) spans;
+    const size_t blocks = (size_t) b->nGlyphs*(size_t) spans;
     if (blocks > 0x7fffffffull)
         return fail(MSDFHIP_ERR_INVALID, "launch of %zu tile rows exceeds the grid limit; split the batch", blocks);
     // Row-list capacity: every edge yields at most 3 intersections per row. Up to SIGN_CAP_LIMIT entries per row the lists of the

@@ -76,13 +76,22 @@ struct GlyphWork {
     bool valid;
 };
 
-// XCD-aware decode of blockIdx -> (glyph, tile): glyphs are dealt round-robin to the 8 XCDs, every tile of a glyph to the same XCD.
+// XCD-aware decode of blockIdx -> (glyph, tile): glyphs are dealt round-robin to the 8 XCDs, every tile of a glyph to the same XCD
+// (its records stay in one L2). The last, partial group of nGlyphs%8 glyphs is dealt tile by tile instead -- a single 1024x1024 shape
+// would otherwise run on one XCD, an eighth of the device. The launch has exactly nGlyphs*tilesPerGlyph workgroups.
 __device__ inline GlyphWork decodeBlock(int nGlyphs, int tilesPerGlyph, unsigned blockBase = 0) {
     GlyphWork w;
     const unsigned b = blockIdx.x+blockBase;
-    const unsigned xcd = b&7u, slot = b>>3;
-    w.g = (int) ((slot/(unsigned) tilesPerGlyph)*8u+xcd);
-    w.tile = (int) (slot%(unsigned) tilesPerGlyph);
+    const unsigned fullBlocks = ((unsigned) nGlyphs&~7u)*(unsigned) tilesPerGlyph;
+    if (b >= fullBlocks) {
+        const unsigned j = b-fullBlocks;
+        w.g = (int) (((unsigned) nGlyphs&~7u)+j/(unsigned) tilesPerGlyph);
+        w.tile = (int) (j%(unsigned) tilesPerGlyph);
+    } else {
+        const unsigned xcd = b&7u, slot = b>>3;
+        w.g = (int) ((slot/(unsigned) tilesPerGlyph)*8u+xcd);
+        w.tile = (int) (slot%(unsigned) tilesPerGlyph);
+    }
     w.valid = w.g < nGlyphs;
     return w;
 }

@@ -576,7 +576,8 @@ extern "C" double emu_estimate_sdf_error(int N, const float *px, int w, int h, i
 // Diagnostics (tools only): wave-level cost model of phase 2. For one glyph: number of (tile, edge) evaluations a wavefront performs
 // with the current tile cull and the per-texel wave vote, for the simple (overlap = 0) or overlapping combiner, optionally walking
 // each contour's survivors nearest-first (order = 1: ascending cullUpperDistance at the tile centre) instead of in visit order.
-// out[0] = evaluations, out[1] = survivors of the tile cull, out[2] = tiles, out[3] = contour walks (tile x contour with >= 1 survivor).
+// out[0] = evaluations, out[1] = survivors of the tile cull, out[2] = tiles, out[3] = contour walks (tile x contour with >= 1 survivor),
+// out[4] = evaluations repeated by the second walks of the overlapping combiner, out[5] = tiles x passes that take a second walk.
 extern "C" void emu_wave_cost(int w, int h, int nC, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors,
                               const double *xf, int overlap, int order, long *out) {
     Digest d = digest(nC, co, points, types, colors);
@@ -590,10 +591,25 @@ extern "C" void emu_wave_cost(int w, int h, int nC, const int32_t *co, const dou
             Selector<3> sel[64];
             for (int l = 0; l < 64; ++l)
                 selInit(sel[l]);
+            std::vector<long> contourEvals((size_t) nC, 0);                   // overlap: evaluations of each contour's own walk ...
+            std::vector<unsigned long long> innerOf((size_t) nC, 0), outerOf((size_t) nC, 0);   // ... and the lanes for which it is a member of the inner / outer selector
+            int nIn[64] = { 0 }, nOut[64] = { 0 };
             for (int c = 0; c < nC; ++c) {
+                if (overlap && c > 0)
+                    for (int l = 0; l < 64; ++l) {
+                        double dd[3];
+                        selDistance(sel[l], dd);
+                        const double m = resolve<3>(dd);
+                        if (d.windings[c-1] > 0 && m >= 0)
+                            innerOf[c-1] |= 1ull<<l, ++nIn[l];
+                        if (d.windings[c-1] < 0 && m <= 0)
+                            outerOf[c-1] |= 1ull<<l, ++nOut[l];
+                    }
                 if (overlap)
                     for (int l = 0; l < 64; ++l)
                         selInit(sel[l]);
+                const long evalsBefore = out[0];
+                struct Tally { long &slot, &total, before; ~Tally() { slot = total-before; } } tally = { contourEvals[c], out[0], evalsBefore };
                 std::vector<int> walk(tc.list.begin()+tc.cstart[c], tc.list.begin()+tc.cstart[c+1]);
                 if (!walk.empty())
                     ++out[3];
@@ -628,6 +644,27 @@ extern "C" void emu_wave_cost(int w, int h, int nC, const int32_t *co, const dou
                         selAddEdge(sel[l], d.recs[i], i, p);
                     }
                 }
+            }
+            if (overlap && nC > 1) {                                          // out[4]: evaluations of the second walks (shapeDistanceOverlap, passes 1 and 2)
+                for (int l = 0; l < 64; ++l) {
+                    double dd[3];
+                    selDistance(sel[l], dd);
+                    const double m = resolve<3>(dd);
+                    if (d.windings[nC-1] > 0 && m >= 0)
+                        innerOf[nC-1] |= 1ull<<l, ++nIn[l];
+                    if (d.windings[nC-1] < 0 && m <= 0)
+                        outerOf[nC-1] |= 1ull<<l, ++nOut[l];
+                }
+                unsigned long long mineIn = 0, mineOut = 0;
+                for (int l = 0; l < 64; ++l) {
+                    if (nIn[l] >= 2) mineIn |= 1ull<<l;
+                    if (nOut[l] >= 2) mineOut |= 1ull<<l;
+                }
+                for (int c = 0; c < nC; ++c) {
+                    if (innerOf[c]&mineIn) out[4] += contourEvals[c];
+                    if (outerOf[c]&mineOut) out[4] += contourEvals[c];
+                }
+                out[5] += (mineIn != 0)+(mineOut != 0);
             }
         }
 }

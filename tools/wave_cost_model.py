@@ -19,12 +19,12 @@ from msdfgen_amd.shape import ShapeBatch, autoframe, distance_mapping  # noqa: E
 
 
 def cost(e, shapes, xfs, size, overlap, order):
-    tot = np.zeros(4, np.int64)
+    tot = np.zeros(6, np.int64)
     for s, xf in zip(shapes, xfs):
         ms, mt = distance_mapping(xf[4], xf[5])
         x6 = np.array([xf[0], xf[1], xf[2], xf[3], ms, mt])
         keep, args = e._shape(s)
-        out = np.zeros(4, np.int64)
+        out = np.zeros(6, np.int64)
         e.lib.emu_wave_cost(size, size, *args, x6.ctypes.data_as(C.POINTER(C.c_double)), overlap, order, out.ctypes.data_as(C.POINTER(C.c_long)))
         tot += out
     return tot
@@ -45,7 +45,8 @@ def main():
         for ov in (0, 1):
             for order in orders:
                 t = cost(e, sh, xf, size, ov, order)
-                print("%s overlap=%d order=%2d: evals/tile %.2f, survivors/tile %.2f, walks/tile %.2f" % (name, ov, order, t[0]/t[2], t[1]/t[2], t[3]/t[2]), flush=True)
+                print("%s overlap=%d order=%2d: evals/tile %.2f, survivors/tile %.2f, walks/tile %.2f, second-walk evals/tile %.2f (%.2f passes/tile)"
+                      % (name, ov, order, t[0]/t[2], t[1]/t[2], t[3]/t[2], t[4]/t[2], t[5]/t[2]), flush=True)
 
 
 if __name__ == "__main__":
