@@ -191,6 +191,20 @@ struct LdsPlan { size_t bytes; bool globalRes; size_t resBytes, ldsBudget, idxBy
 const size_t GRES_WORKSPACE_CAP = (size_t) 1<<30;   // bound of the global combiner scratch; larger launches are chunked
 const int SMALL_MAX_EDGES = 128;                    // glyphs of the LDS-scratch class have at most this many edges (bounds their survivor lists)
 
+// SIMDs of a device (4 per compute unit): the number of wavefronts of a W-waves-per-SIMD kernel it holds at once is residentSlots()*W.
+int residentSlots(int device) {
+    static std::atomic<int> cus[64];
+    if (device < 0 || device >= 64)
+        return 256;
+    int n = cus[device].load();
+    if (!n) {
+        hipDeviceProp_t prop;
+        n = hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        cus[device].store(n);
+    }
+    return n;
+}
+
 size_t ldsBudget() {
     // The combiner scratch lives in LDS only while 12 wavefronts (3 per SIMD, the register-limited occupancy) fit a CU's 160 KB:
     // beyond ~13 KB per wavefront LDS would cap the occupancy (a 20-contour glyph set ran at 1.25 wavefronts/SIMD), so it moves to a
@@ -244,6 +258,13 @@ int ensureGres(const MsdfHipBatch *b, size_t bytes, double **out) {
 }
 
 template <int SEL, bool OVERLAP, bool GRES>
+void launchDistanceKernel(unsigned grid, size_t lds, hipStream_t stream, const DistanceArgs &a) {
+    hipLaunchKernelGGL((k_distance<SEL, OVERLAP, GRES>), dim3(grid), dim3(WAVE), lds, stream, a.batch.nGlyphs, a.batch.glyphContourOffsets, a.batch.contourOffsets,
+                       a.batch.recs, a.batch.windings, a.glyphs, a.width, a.height, a.tilesX, a.tilesPerGlyph, a.maxEdges, a.dst, a.toScratch, a.blockBase, a.gres,
+                       a.gresStride, a.glyphMap, a.nMapped, a.workQueue, a.workItems);
+}
+
+template <int SEL, bool OVERLAP, bool GRES>
 int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, const LdsPlan &plan, hipStream_t stream,
                    const int *dGlyphMap = NULL, int nMapped = 0) {
     const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE, tiles = tilesX*tilesY;
@@ -259,8 +280,34 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
         return rc;
     double *gres = NULL;
     size_t chunk = blocks, stride = 0;
+    unsigned *queue = NULL;
+    DistanceArgs args;
+    args.batch = viewOf(b), args.glyphs = dGlyphs, args.width = w, args.height = h, args.tilesX = tilesX, args.tilesPerGlyph = tiles, args.maxEdges = plan.listStride;
+    args.dst = dst, args.toScratch = toScratch, args.blockBase = 0, args.gres = NULL, args.gresStride = 0, args.glyphMap = dGlyphMap, args.nMapped = nMapped;
+    args.workQueue = NULL, args.workItems = 0;
     if (GRES && OVERLAP && plan.resBytes) {
         stride = plan.resBytes/sizeof(double);
+        // More items than resident wavefront slots: a PERSISTENT launch -- one workgroup per slot draws tiles from a queue and keeps
+        // its slice of the workspace (3 072 x 30 KB = 92 MB for 20-contour glyphs: Infinity-Cache resident; as one slice per tile the
+        // same launch streamed 9 GB through HBM and had to be cut into chunks of 1 GB of workspace).
+        const size_t slots = (size_t) residentSlots(b->device)*4u*MSDF_DISTANCE_WAVES_PER_SIMD;
+        // (Only for launches of many rounds: a persistent workgroup never yields its slot, so next to the other glyph classes' launches
+        // it freezes the split of the device between them -- measured 2 % slower than the direct mapping at 5 rounds, 12 % faster at 96.)
+        size_t minRounds = 8;
+        if (const char *env = getenv("MSDFHIP_PERSISTENT_ROUNDS"))   // experiment knob; 0 = never
+            minRounds = (size_t) atol(env);
+        if (minRounds && blocks >= minRounds*slots && blocks < 0xffffffffull-8u*slots) {
+            chunk = slots;
+            rc = ensureGres(b, chunk*plan.resBytes+8*sizeof(unsigned), &gres);
+            if (rc != MSDFHIP_OK)
+                return rc;
+            queue = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(gres)+chunk*plan.resBytes);
+            HIPCHK(hipMemsetAsync(queue, 0, 8*sizeof(unsigned), stream));
+            args.gres = gres, args.gresStride = stride, args.workQueue = queue, args.workItems = (unsigned) blocks;
+            launchDistanceKernel<SEL, OVERLAP, GRES>((unsigned) chunk, plan.bytes, stream, args);
+            HIPCHK(hipGetLastError());
+            return MSDFHIP_OK;
+        }
         chunk = GRES_WORKSPACE_CAP/plan.resBytes;
         if (chunk < 256)
             chunk = 256;
@@ -272,8 +319,8 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
     }
     for (size_t base = 0; base < blocks; base += chunk) {
         const size_t n = blocks-base < chunk ? blocks-base : chunk;
-        hipLaunchKernelGGL((k_distance<SEL, OVERLAP, GRES>), dim3((unsigned) n), dim3(WAVE), plan.bytes, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles,
-                           plan.listStride, dst, toScratch, (unsigned) base, gres, stride, dGlyphMap, nMapped);
+        args.gres = gres, args.gresStride = stride, args.blockBase = (unsigned) base;
+        launchDistanceKernel<SEL, OVERLAP, GRES>((unsigned) n, plan.bytes, stream, args);
     }
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
@@ -564,7 +611,8 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     hipLaunchKernelGGL((k_ec_fast<N>), dim3(blocks), dim3(WAVE), fastLds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, src, out, stencil, cfg,
                        (const EcGlyphParams *) b->dEcParams, deferred, seg, b->maxEdges);
     hipLaunchKernelGGL(k_ec_scan, dim3(1), dim3(1024), 0, stream, viewOf(b), reinterpret_cast<const unsigned *>(deferred), seg, offsets, lpcMaxContours);
-    hipLaunchKernelGGL((k_ec_query<N, OVERLAP>), dim3(queryBlocks), dim3(WAVE), queryLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
+    hipLaunchKernelGGL((k_ec_query<N, OVERLAP>), dim3(queryBlocks), dim3(WAVE), queryLds, stream, b->nGlyphs, b->dGlyphContourOffsets, b->dContourOffsets,
+                       (const EdgeRec *) viewOf(b).recs, viewOf(b).windings, dGlyphs, w, h, src, out, stencil, cfg,
                        (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, offsets, slotCap, slotOffset, lpcMaxContours);
     hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowGrid), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
                        (const EcCandidate *) deferred, seg, 1, gres, gresStride);

@@ -79,9 +79,8 @@ struct GlyphWork {
 // XCD-aware decode of blockIdx -> (glyph, tile): glyphs are dealt round-robin to the 8 XCDs, every tile of a glyph to the same XCD
 // (its records stay in one L2). The last, partial group of nGlyphs%8 glyphs is dealt tile by tile instead -- a single 1024x1024 shape
 // would otherwise run on one XCD, an eighth of the device. The launch has exactly nGlyphs*tilesPerGlyph workgroups.
-__device__ inline GlyphWork decodeBlock(int nGlyphs, int tilesPerGlyph, unsigned blockBase = 0) {
+__device__ inline GlyphWork decodeItem(unsigned b, int nGlyphs, int tilesPerGlyph) {
     GlyphWork w;
-    const unsigned b = blockIdx.x+blockBase;
     const unsigned fullBlocks = ((unsigned) nGlyphs&~7u)*(unsigned) tilesPerGlyph;
     if (b >= fullBlocks) {
         const unsigned j = b-fullBlocks;
@@ -94,6 +93,28 @@ __device__ inline GlyphWork decodeBlock(int nGlyphs, int tilesPerGlyph, unsigned
     }
     w.valid = w.g < nGlyphs;
     return w;
+}
+__device__ inline GlyphWork decodeBlock(int nGlyphs, int tilesPerGlyph, unsigned blockBase = 0) {
+    return decodeItem(blockIdx.x+blockBase, nGlyphs, tilesPerGlyph);
+}
+
+// Work queue of a PERSISTENT launch (fewer workgroups than items: each keeps its slice of the global workspace and draws items until
+// none are left). counters[8]: one per XCD, so that a workgroup on XCD x (blockIdx%8, MI355X_MICROARCH.md) first drains the items
+// decodeItem() deals to x -- the glyphs whose records its L2 already holds -- and only then helps the others (steal: 1..7 XCDs further).
+__device__ inline unsigned nextItem(unsigned *counters, unsigned total, int &steal) {
+    const unsigned x = blockIdx.x&7u;
+    while (steal < 8) {
+        const unsigned xx = (x+(unsigned) steal)&7u;
+        unsigned k = 0;
+        if (threadIdx.x == 0)
+            k = atomicAdd(&counters[xx], 1u);
+        k = (unsigned) __builtin_amdgcn_readfirstlane((int) k);
+        const unsigned b = k*8u+xx;
+        if (b < total)
+            return b;
+        ++steal;
+    }
+    return ~0u;
 }
 
 __device__ inline Xform loadXform(const MsdfHipGlyph &gd) {
@@ -184,18 +205,50 @@ enum { QUAD = 4 };   // tiles per wavefront of the LDS-scratch variant (the glob
 #ifndef MSDF_SIMPLE_WAVES_PER_SIMD
 #define MSDF_SIMPLE_WAVES_PER_SIMD 5     // the simple-combiner instantiations need ~96 VGPRs: five wavefronts per SIMD
 #endif
+struct DistanceArgs {
+    BatchView batch;
+    const MsdfHipGlyph *glyphs;
+    int width, height, tilesX, tilesPerGlyph, maxEdges;
+    float *dst;
+    int toScratch;
+    unsigned blockBase;
+    double *gres;
+    size_t gresStride;
+    const int *glyphMap;
+    int nMapped;
+    unsigned *workQueue;               // persistent launch (global-scratch form only): 8 per-XCD item counters, zeroed by the host
+    unsigned workItems;
+};
+
 template <int SEL, bool OVERLAP, bool GRES = false>
 __global__ void __launch_bounds__(WAVE, OVERLAP ? MSDF_DISTANCE_WAVES_PER_SIMD : MSDF_SIMPLE_WAVES_PER_SIMD)
-k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges, float *dst, int toScratch,
-           unsigned blockBase, double *gres, size_t gresStride, const int *glyphMap, int nMapped) {
+k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const int32_t *__restrict__ contourOffsets, const EdgeRec *__restrict__ recs,
+           const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges,
+           float *__restrict__ dst, int toScratch, unsigned blockBase, double *__restrict__ gres, size_t gresStride, const int *__restrict__ glyphMap, int nMapped,
+           unsigned *__restrict__ workQueue, unsigned workItems) {
+    // (every pointer __restrict__: the survivor records are read with SCALAR loads only while the compiler can prove that none of the
+    // kernel's own stores -- tiles, workspace, and in the persistent form those of the previous item -- may have clobbered them)
     enum { NCH = SelTraits<SEL>::NCH, TPW = GRES ? 1 : (int) QUAD, ROW = WAVE/TPW };   // tiles per wavefront, lanes per tile in phase 1
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // One wavefront = TPW consecutive tiles of one glyph. Phase 1 culls for all of them at once -- the edges of a contour rarely fill
     // 64 lanes, so each 16-lane row takes one tile -- and phase 2 then walks the tiles one after the other, lanes = texels.
+    // workQueue (global-scratch form only): a persistent launch -- one workgroup per resident wavefront slot, each drawing items from
+    // the queue and reusing ITS slice of the workspace, which then stays in L2 / Infinity Cache instead of streaming through HBM.
+    BatchView batch;
+    batch.nGlyphs = nGlyphs, batch.glyphContourOffsets = glyphContourOffsets, batch.contourOffsets = contourOffsets, batch.recs = recs, batch.windings = windings;
+    unsigned item = blockIdx.x+blockBase;
+    int steal = 0;
+    const bool persistent = GRES && workQueue != NULL;
+    for (;;) {
+    if (persistent) {
+        item = nextItem(workQueue, workItems, steal);
+        if (item == ~0u)
+            return;
+    }
     const int quadsPerGlyph = (tilesPerGlyph+TPW-1)/TPW;
-    GlyphWork wk = decodeBlock(glyphMap ? nMapped : batch.nGlyphs, quadsPerGlyph, blockBase);
+    GlyphWork wk = decodeItem(item, glyphMap ? nMapped : batch.nGlyphs, quadsPerGlyph);
     if (!wk.valid)
-        return;
+        return;                                                         // (direct mapping only: every queued item is valid)
     if (glyphMap)
         wk.g = glyphMap[wk.g];                                          // this launch covers a subset of the batch (bucketed by contour count)
     const int c0 = batch.glyphContourOffsets[wk.g], C = batch.glyphContourOffsets[wk.g+1]-c0;
@@ -313,6 +366,10 @@ k_distance(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, i
                               : dst+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) NCH*x;
         for (int ch = 0; ch < NCH; ++ch)
             px[ch] = mapDistance(t, d[ch]);                         // msdfgen.cpp:20-48
+    }
+    if (!persistent)
+        return;
+    waveSync();                                                     // the survivor lists in LDS are rebuilt for the next item
     }
 }
 
@@ -749,8 +806,14 @@ k_ec_scan(BatchView batch, const unsigned *header, unsigned seg, int *offsets, E
 // stencil |= ERROR. Several candidates of one texel write identical values.
 template <int N, bool OVERLAP>
 __global__ void __launch_bounds__(WAVE, 2)
-k_ec_query(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, const float *src, float *out, uint8_t *stencilOut,
-           MsdfHipConfig cfg, const EcGlyphParams *glyphParams, const EcCandidate *cands, unsigned seg, int *offsets, int slotCap, int slotOffset, EcQueryPolicy lpcMaxContours) {
+k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const int32_t *__restrict__ contourOffsets, const EdgeRec *__restrict__ recs,
+           const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, const float *__restrict__ src, float *__restrict__ out,
+           uint8_t *__restrict__ stencilOut, MsdfHipConfig cfg, const EcGlyphParams *__restrict__ glyphParams, const EcCandidate *__restrict__ cands, unsigned seg,
+           int *__restrict__ offsets, int slotCap, int slotOffset, EcQueryPolicy lpcMaxContours) {
+    // (__restrict__ throughout, as in k_distance: the lane-per-candidate walk reads the records with scalar loads only if the kernel's
+    // own stores -- corrected texels, stencil bytes, the work counter -- provably do not touch them)
+    BatchView batch;
+    batch.nGlyphs = nGlyphs, batch.glyphContourOffsets = glyphContourOffsets, batch.contourOffsets = contourOffsets, batch.recs = recs, batch.windings = windings;
     extern __shared__ double smemLds[];                             // combiner scratch ([maxContours][64] or [maxContours]) | slotCap PBSlots at slotOffset
     PBSlot *slotBuf = reinterpret_cast<PBSlot *>(smemLds+slotOffset);
     const unsigned *header = reinterpret_cast<const unsigned *>(cands);
