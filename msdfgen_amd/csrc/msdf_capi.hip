@@ -512,8 +512,10 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
 // Records of the per-glyph candidate segments incl. the header (msdf_kernels.hpp, EcCandidate), followed by the work list of
 // k_ec_query: int offsets[nGlyphs+2] (k_ec_scan).
 size_t candidateRecords(int nGlyphs, size_t texelsPerGlyph) { return ecHeaderRecords(nGlyphs)+(size_t) nGlyphs*ecSegment(texelsPerGlyph); }
-size_t deferredRecords(int nGlyphs, size_t texelsPerGlyph) {
-    return candidateRecords(nGlyphs, texelsPerGlyph)+((size_t) (nGlyphs+2)*sizeof(int)+sizeof(EcCandidate)-1)/sizeof(EcCandidate);
+size_t offsetRecords(int nGlyphs) { return ((size_t) (nGlyphs+2)*sizeof(int)+sizeof(EcCandidate)-1)/sizeof(EcCandidate); }
+// ... followed by the corner list of k_ec_params: two ints per edge of the batch.
+size_t deferredRecords(int nGlyphs, size_t texelsPerGlyph, int nEdges) {
+    return candidateRecords(nGlyphs, texelsPerGlyph)+offsetRecords(nGlyphs)+((size_t) (nEdges > 0 ? nEdges : 1)*2*sizeof(int)+sizeof(EcCandidate)-1)/sizeof(EcCandidate);
 }
 
 int ensureDeferred(const MsdfHipBatch *b, size_t cap, EcCandidate **out) {
@@ -564,7 +566,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
         return MSDFHIP_OK;
     }
     const unsigned seg = ecSegment((size_t) w*h);                // candidate records per glyph
-    const size_t cap = deferredRecords(b->nGlyphs, (size_t) w*h);
+    const size_t cap = deferredRecords(b->nGlyphs, (size_t) w*h, b->nEdges);
     EcCandidate *deferred = NULL;
     rc = ensureDeferred(b, cap, &deferred);
     if (rc != MSDFHIP_OK)
@@ -602,14 +604,15 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     if (rc != MSDFHIP_OK)
         return rc;
     int *offsets = reinterpret_cast<int *>(deferred+candidateRecords(b->nGlyphs, (size_t) w*h));
+    int *corners = reinterpret_cast<int *>(deferred+candidateRecords(b->nGlyphs, (size_t) w*h)+offsetRecords(b->nGlyphs));
     // the query kernel is a pool of wavefronts draining one work list: enough of them to fill the device, no more
     // (a wavefront that finds the list empty leaves after one atomic; still, a single 64x64 glyph should not launch thousands of them)
     const size_t wanted = allTexels/512;
     const unsigned queryBlocks = (unsigned) (wanted < 64 ? 64 : wanted > 8192 ? 8192 : wanted);
-    hipLaunchKernelGGL(k_ec_params, dim3((b->nGlyphs+255)/256), dim3(256), 0, stream, b->dEcParams, dGlyphs, b->nGlyphs, cfg,
-                       reinterpret_cast<unsigned *>(deferred));   // also zeroes the candidate header
+    hipLaunchKernelGGL(k_ec_params, dim3((unsigned) b->nGlyphs), dim3(WAVE), 0, stream, b->dEcParams, viewOf(b), dGlyphs, cfg,
+                       reinterpret_cast<unsigned *>(deferred), corners);   // also zeroes the candidate header
     hipLaunchKernelGGL((k_ec_fast<N>), dim3(blocks), dim3(WAVE), fastLds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, src, out, stencil, cfg,
-                       (const EcGlyphParams *) b->dEcParams, deferred, seg, b->maxEdges);
+                       (const EcGlyphParams *) b->dEcParams, deferred, seg, b->maxEdges, (const int *) corners);
     hipLaunchKernelGGL(k_ec_scan, dim3(1), dim3(1024), 0, stream, viewOf(b), reinterpret_cast<const unsigned *>(deferred), seg, offsets, lpcMaxContours);
     hipLaunchKernelGGL((k_ec_query<N, OVERLAP>), dim3(queryBlocks), dim3(WAVE), queryLds, stream, b->nGlyphs, b->dGlyphContourOffsets, b->dContourOffsets,
                        (const EdgeRec *) viewOf(b).recs, viewOf(b).windings, dGlyphs, w, h, src, out, stencil, cfg,
@@ -1791,7 +1794,7 @@ static int runGroup(ShapeCall *const *calls, int n) {
     }
     const size_t texels = (size_t) w*h, tileBytes = texels*channels*sizeof(float);
     const size_t eAlloc = sumE > 0 ? sumE : 1, cAlloc = sumC > 0 ? sumC : 1;
-    const size_t candCap = deferredRecords(n, texels);
+    const size_t candCap = deferredRecords(n, texels, (int) sumE);
 
     // host staging layout (inputs first: one H2D copy; then the results: one D2H copy)
     Carver hc;

@@ -520,15 +520,19 @@ MSDF_HD size_t stencilIndex(size_t texel, int yn, int width, int height, int ste
 struct EcGlyphParams {
     double hSpan, vSpan, dSpan, texelX, texelY;
     float radiusH, radiusV, radiusD;
+    int cornerBegin, nCorners;          // the glyph's colour-change corners in the launch's corner list (k_ec_params)
     int pad;
 };
-static_assert(sizeof(EcGlyphParams) == 56, "EcGlyphParams layout");
+static_assert(sizeof(EcGlyphParams) == 64, "EcGlyphParams layout");
 
-__global__ void k_ec_params(EcGlyphParams *out, const MsdfHipGlyph *glyphs, int nGlyphs, MsdfHipConfig cfg, unsigned *candidateHeader) {
-    const int g = blockIdx.x*blockDim.x+threadIdx.x;
-    if (g >= nGlyphs)
-        return;
-    if (candidateHeader) {                                          // zero the candidate counters for k_ec_fast (saves a memset launch)
+// Per-glyph constants of the error-correction pass, one wavefront per glyph: the spans / radii of MSDFErrorCorrection.cpp:180-187 and
+// the texel corners protectCorners marks (:121-151; lanes = edges, the (l, b) texel pair of every colour-change corner under this
+// call's transform, appended at corners[2*(e0+slot)]). k_ec_fast then needs ONE dependent load per tile (params -> its corner list)
+// instead of walking glyphContourOffsets -> contourOffsets -> the records' flags in each of the glyph's tiles.
+__global__ void __launch_bounds__(WAVE)
+k_ec_params(EcGlyphParams *out, BatchView batch, const MsdfHipGlyph *glyphs, MsdfHipConfig cfg, unsigned *candidateHeader, int *corners) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (candidateHeader && lane == 0) {                             // zero the candidate counters for k_ec_fast (saves a memset launch)
         candidateHeader[1+g] = 0;
         if (g == 0)
             candidateHeader[0] = 0;
@@ -538,10 +542,30 @@ __global__ void k_ec_params(EcGlyphParams *out, const MsdfHipGlyph *glyphs, int 
     p.minDeviationRatio = cfg.min_deviation_ratio;
     p.minImproveRatio = cfg.min_improve_ratio;
     ecDerive(p);
-    EcGlyphParams o;
-    o.hSpan = p.hSpan, o.vSpan = p.vSpan, o.dSpan = p.dSpan, o.texelX = p.texelX, o.texelY = p.texelY;
-    o.radiusH = p.radiusH, o.radiusV = p.radiusV, o.radiusD = p.radiusD, o.pad = 0;
-    out[g] = o;
+    const int c0 = batch.glyphContourOffsets[g], C = batch.glyphContourOffsets[g+1]-c0;
+    const int e0 = batch.contourOffsets[c0], nE = batch.contourOffsets[c0+C]-e0;
+    int nCorners = 0;
+    if (cfg.ec_mode == EC_MODE_EDGE_PRIORITY && corners) {
+        const EdgeRec *rec = batch.recs+e0;
+        for (int base = 0; base < nE; base += WAVE) {
+            const int e = base+lane;
+            const bool corner = e < nE && (rec[e].flags&REC_CORNER);
+            const unsigned long long mask = __ballot(corner);
+            if (corner) {
+                const V2 pp = project(p.t, ld(rec[e].p));
+                const int slot = e0+nCorners+__popcll(mask&((1ull<<lane)-1ull));
+                corners[2*slot] = (int) floor(pp.x-.5);
+                corners[2*slot+1] = (int) floor(pp.y-.5);
+            }
+            nCorners += __popcll(mask);
+        }
+    }
+    if (lane == 0) {
+        EcGlyphParams o;
+        o.hSpan = p.hSpan, o.vSpan = p.vSpan, o.dSpan = p.dSpan, o.texelX = p.texelX, o.texelY = p.texelY;
+        o.radiusH = p.radiusH, o.radiusV = p.radiusV, o.radiusD = p.radiusD, o.cornerBegin = e0, o.nCorners = nCorners, o.pad = 0;
+        out[g] = o;
+    }
 }
 
 // Error correction, fast sweep over ALL texels (msdf_ec_fast.hpp). src: pre-correction field, packed [g][h][w][N] in native row order.
@@ -562,8 +586,8 @@ template <int N>
 __global__ void __launch_bounds__(WAVE, MSDF_EC_FAST_WAVES_PER_SIMD)
 k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph,
           const float *src, float *out, uint8_t *stencilOut, MsdfHipConfig cfg, const EcGlyphParams *glyphParams, EcCandidate *cands, unsigned seg,
-          int maxEdges) {
-    extern __shared__ int smemCorners[];                            // (l, b) per colour-change corner of the glyph, then the regions below
+          int maxEdges, const int *corners) {
+    extern __shared__ int smemCorners[];                            // (l, b) per colour-change corner near this tile, then the regions below
     const GlyphWork wk = decodeBlock(batch.nGlyphs, tilesPerGlyph);
     if (!wk.valid)
         return;
@@ -572,9 +596,6 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
     int *itemCount = verdictLds+WAVE;
     unsigned short *queue = reinterpret_cast<unsigned short *>(itemCount+4);               // [EC_QUEUE_CAP]: lane | k<<6 | j<<9
     unsigned short *protectQueue = queue+EC_QUEUE_CAP;                                      // [EC_PROTECT_QUEUE_CAP]: lane | m<<6
-    const int c0 = batch.glyphContourOffsets[wk.g], C = batch.glyphContourOffsets[wk.g+1]-c0;
-    const int32_t *coff = batch.contourOffsets+c0;
-    const int e0 = coff[0], nE = coff[C]-e0;
     const int lane = threadIdx.x;
     const MsdfHipGlyph gd = glyphs[wk.g];
     EcParams p;
@@ -585,26 +606,33 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
     const EcGlyphParams gp = glyphParams[wk.g];
     p.hSpan = gp.hSpan, p.vSpan = gp.vSpan, p.dSpan = gp.dSpan, p.texelX = gp.texelX, p.texelY = gp.texelY;
     p.radiusH = gp.radiusH, p.radiusV = gp.radiusV, p.radiusD = gp.radiusD;
+    const int tx = wk.tile%tilesX, ty = wk.tile/tilesX;
 
+    // protectCorners (MSDFErrorCorrection.cpp:121-151): of the glyph's corner texel pairs (k_ec_params) only those that touch this tile
     int nCorners = 0;
-    if (p.mode == EC_MODE_EDGE_PRIORITY) {                          // protectCorners (MSDFErrorCorrection.cpp:121-151): lanes = edges, ordered compaction
-        const EdgeRec *rec = batch.recs+e0;
-        for (int base = 0; base < nE; base += WAVE) {
-            const int e = base+lane;
-            const bool corner = e < nE && (rec[e].flags&REC_CORNER);
-            const unsigned long long mask = __ballot(corner);
-            if (corner) {
-                const V2 pp = project(p.t, ld(rec[e].p));
+    if (p.mode == EC_MODE_EDGE_PRIORITY) {
+        const int x0 = tx*TILE, x1 = tx*TILE+TILE-1;
+        const int ya = gd.flip ? height-1-(ty*TILE+TILE-1) : ty*TILE, yb = gd.flip ? height-1-ty*TILE : ty*TILE+TILE-1;   // shape-space rows of the tile
+        const int *list = corners+2*(size_t) gp.cornerBegin;
+        for (int base = 0; base < gp.nCorners; base += WAVE) {
+            const int k = base+lane;
+            int l = 0, b = 0;
+            bool near = false;
+            if (k < gp.nCorners) {
+                l = list[2*k], b = list[2*k+1];
+                near = l+1 >= x0 && l <= x1 && b+1 >= ya && b <= yb;
+            }
+            const unsigned long long mask = __ballot(near);
+            if (near) {
                 const int slot = nCorners+__popcll(mask&((1ull<<lane)-1ull));
-                smemCorners[2*slot] = (int) floor(pp.x-.5);
-                smemCorners[2*slot+1] = (int) floor(pp.y-.5);
+                smemCorners[2*slot] = l;
+                smemCorners[2*slot+1] = b;
             }
             nCorners += __popcll(mask);
         }
     }
 
     // ---- the tile and its one-texel halo go to LDS once (native rows); texels outside the bitmap are never read back
-    const int tx = wk.tile%tilesX, ty = wk.tile/tilesX;
     const float *field = src+(size_t) wk.g*height*width*N;
     for (int idx = lane; idx < EC_HALO*EC_HALO; idx += WAVE) {
         const int hx = tx*TILE+idx%EC_HALO-1, hy = ty*TILE+idx/EC_HALO-1;
