@@ -248,6 +248,15 @@ def test_config4_full_size_atlas_8192_glyphs_48(oracle):
         sub, sx, (lo, hi) = shard(batch, xfs, r, 8, 48, 48)
         parts.append(M.GlyphBatch(sub).generate(3, 48, 48, sx).cpu().numpy())
     assert (bits(np.concatenate(parts)) == bits(got)).all()
+    # 295 k tiles of the global-scratch class = a PERSISTENT launch (work queue, one workspace slice per resident wavefront); the direct
+    # mapping (one slice per tile, chunked launches) must give the same bytes
+    import os
+    os.environ["MSDFHIP_PERSISTENT_ROUNDS"] = "0"
+    try:
+        direct = M.GlyphBatch(batch).generate(3, 48, 48, xfs).cpu().numpy()
+    finally:
+        del os.environ["MSDFHIP_PERSISTENT_ROUNDS"]
+    assert (bits(direct) == bits(got)).all()
     print("config 4: 24 sampled tiles, %d texels differing bitwise" % worst)
 
 
