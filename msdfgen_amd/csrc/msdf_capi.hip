@@ -591,7 +591,8 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
         sscanf(env, "%d,%d,%d", &lpcMaxContours.lpcEdgeCost, &lpcMaxContours.lpcMaxEdges, &lpcMaxContours.lpcMinCount);
     const size_t resLanes = OVERLAP ? (size_t) (lpcMaxContours.lpcMaxContours > 0 ? lpcMaxContours.lpcMaxContours : 1)*WAVE*sizeof(double) : 0;
     const int slotOffset = OVERLAP ? (b->maxContours > 0 ? b->maxContours : 1) : 0;
-    const size_t coopLds = (size_t) slotOffset*sizeof(double)+(size_t) slotCap*sizeof(PBSlot);
+    const int mergedCap = b->maxContours < slotCap ? (b->maxContours > 0 ? b->maxContours : 1) : slotCap;   // per-contour merged states of a glyph that uses the slots
+    const size_t coopLds = (size_t) slotOffset*sizeof(double)+(size_t) (slotCap+mergedCap)*sizeof(PBSlot);
     const size_t queryLds = resLanes > coopLds ? resLanes : coopLds;
     const size_t fastLds = ecFastLdsBytes(b->maxEdges, N);
     if (fastLds > (size_t) gLdsLimit.load() || queryLds > (size_t) gLdsLimit.load())
@@ -1464,9 +1465,27 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
         p.view.glyphCap = p.viewCap;                             // sized for a full chunk whatever the length of the slot's first chunk
         p.pendingCount = 0;
     }
-    int slot = 0;
-    for (int g0 = 0; g0 < nG && rc == MSDFHIP_OK; g0 += chunk, slot ^= 1) {
-        const int n = nG-g0 < chunk ? nG-g0 : chunk;
+    // Chunk lengths: what the pipeline cannot hide is the kernels of the FIRST chunk and the copy of the LAST one -- with enough glyphs
+    // those two are half chunks (8 192 glyphs: 1 024, 2 048, 2 048, 2 048, 1 024).
+    std::vector<int> lengths;
+    {
+        const int half = chunk/2 >= 64 ? chunk/2/64*64 : chunk;
+        int rem = nG;
+        if (nG >= 2*chunk && half < chunk && !getenv("MSDFHIP_PIPELINE_UNIFORM")) {
+            lengths.push_back(half);
+            for (rem -= half; rem > chunk+half; rem -= chunk)
+                lengths.push_back(chunk);
+            if (rem > chunk)
+                lengths.push_back(rem-half), rem = half;
+        } else
+            for (; rem > chunk; rem -= chunk)
+                lengths.push_back(chunk);
+        if (rem > 0)
+            lengths.push_back(rem);
+    }
+    int slot = 0, g0 = 0;
+    for (size_t ci = 0; ci < lengths.size() && rc == MSDFHIP_OK; g0 += lengths[ci], ++ci, slot ^= 1) {
+        const int n = lengths[ci];
         PipeSlot &p = pipe[slot];
         if (p.busy) {                                            // the slot's previous copy must have left its buffers
             HIPCHK(hipEventSynchronize(p.done));

@@ -404,7 +404,8 @@ struct EdgesCooperative {
     const int32_t *coff;
     int lane;
     PBSlot *slots;                      // LDS: one slot per edge of the glyph, or NULL (glyph too large: per-contour lane merge instead)
-    int nE;
+    PBSlot *merged;                     // LDS: one slot per contour (the contour's edges merged in visit order), valid with slots
+    int nE, C;
     MSDF_HD int begin(int c) const { return coff[c]-coff[0]; }
     MSDF_HD int end(int c) const { return coff[c+1]-coff[0]; }
 };
@@ -425,12 +426,22 @@ __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const
                 }
             }
             waveSync();
+            // lanes = contours: each merges ITS contour's slots in visit order (the serial part is the longest contour, not the glyph)
+            for (int cc = edges.lane; cc < edges.C; cc += WAVE) {
+                PB acc;
+                pbInit(acc);
+                const int e = edges.end(cc);
+                for (int i = edges.begin(cc); i < e; ++i) {
+                    const PBSlot one = edges.slots[i];
+                    pbMerge(acc, one);
+                }
+                edges.merged[cc] = acc;
+            }
+            waveSync();
         }
-        const int e = edges.end(c);
-        for (int i = edges.begin(c); i < e; ++i) {
-            const PBSlot one = edges.slots[i];
-            pbMerge(sel.c[0], one);
-        }
+        // merge(sel, merge(...merge(initial, e_first)..., e_last)) == the sequential merges: the earlier state survives ties either way
+        const PBSlot whole = edges.merged[c];
+        pbMerge(sel.c[0], whole);
         return;
     }
     const int e = edges.end(c);
@@ -462,11 +473,11 @@ struct PsdfQueryCooperative {                                       // same quer
     const int8_t *windings;
     int C, lane;
     double *res;
-    PBSlot *slots;
+    PBSlot *slots, *merged;
     __device__ double operator()(V2 q) const {
         double out[1];
         EdgesCooperative edges;
-        edges.coff = coff, edges.lane = lane, edges.slots = slots, edges.nE = coff[C]-coff[0];
+        edges.coff = coff, edges.lane = lane, edges.slots = slots, edges.merged = merged, edges.nE = coff[C]-coff[0], edges.C = C;
         if (slots)
             waveSync();                                             // the previous query's slot reads are done
         if (OVERLAP)
@@ -906,6 +917,7 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.lane = threadIdx.x;
             query.res = smemLds;
             query.slots = nE <= slotCap ? slotBuf : NULL;           // larger glyphs: per-contour cross-lane merge instead of the slots
+            query.merged = slotBuf+slotCap;                         // [min(maxContours, slotCap)]: a glyph of <= slotCap edges has no more contours
             const size_t texel = cand.texel;
             const int rem = (int) (texel-(size_t) g*texelsPerGlyph);
             const int yn = rem/width, x = rem%width;

@@ -440,19 +440,22 @@ extern "C" void emu_rasterize(float *pixels, int w, int h, int rowStride, int fl
 // are merged with the kernel's shuffle tree (lane l <- merge(l, l+off), off = 1, 2, ... 32), chunk results are merged in order.
 namespace msdfhip {
 struct EdgesCoopEmu {
-    bool slotted;                       // true: the kernel's LDS-slot path (all edges first, then a serial merge per contour)
+    bool slotted;                       // true: the kernel's LDS-slot path (all edges first, then lanes = contours merge their own slots)
     const int32_t *coff;
     int begin(int c) const { return coff[c]-coff[0]; }
     int end(int c) const { return coff[c+1]-coff[0]; }
 };
 inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const EdgesCoopEmu &edges, int c, V2 o) {
-    if (edges.slotted) {
+    if (edges.slotted) {                 // single-edge states -> the contour's own merged state (from the initial one) -> merged into sel
+        PB acc;
+        pbInit(acc);
         for (int i = edges.begin(c); i < edges.end(c); ++i) {
             Selector<2> mine;
             selInit(mine);
             selAddEdge(mine, rec[i], i, o);
-            pbMerge(sel.c[0], mine.c[0]);
+            pbMerge(acc, mine.c[0]);
         }
+        pbMerge(sel.c[0], acc);
         return;
     }
     const int e = edges.end(c);
