@@ -510,9 +510,9 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
 }
 
 // Records of the per-glyph candidate segments incl. the header (msdf_kernels.hpp, EcCandidate), followed by the work list of
-// k_ec_query: int offsets[nGlyphs+2] (k_ec_scan).
+// k_ec_query: int offsets[ecOffsetInts(nGlyphs)] (k_ec_scan).
 size_t candidateRecords(int nGlyphs, size_t texelsPerGlyph) { return ecHeaderRecords(nGlyphs)+(size_t) nGlyphs*ecSegment(texelsPerGlyph); }
-size_t offsetRecords(int nGlyphs) { return ((size_t) (nGlyphs+2)*sizeof(int)+sizeof(EcCandidate)-1)/sizeof(EcCandidate); }
+size_t offsetRecords(int nGlyphs) { return (ecOffsetInts(nGlyphs)*sizeof(int)+sizeof(EcCandidate)-1)/sizeof(EcCandidate); }
 // ... followed by the corner list of k_ec_params: two ints per edge of the batch.
 size_t deferredRecords(int nGlyphs, size_t texelsPerGlyph, int nEdges) {
     return candidateRecords(nGlyphs, texelsPerGlyph)+offsetRecords(nGlyphs)+((size_t) (nEdges > 0 ? nEdges : 1)*2*sizeof(int)+sizeof(EcCandidate)-1)/sizeof(EcCandidate);
@@ -575,7 +575,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     // combiner scratch is one double per contour (wave-uniform query point)
     // (both bounded so that the kernel's LDS does not cap its occupancy -- one 543-edge symbol in the batch had cost every wavefront
     // 22 KB; measured: 2.67 -> 2.60 ms of correction on the distinct-glyph set)
-    int slotCapWanted = 160, lpcContoursWanted = 8;
+    int slotCapWanted = 160, lpcContoursWanted = 24;
     if (const char *env = getenv("MSDFHIP_QUERY_LDS"))           // experiment knob: "slotCap,lpcMaxContours"
         sscanf(env, "%d,%d", &slotCapWanted, &lpcContoursWanted);
     const int slotCap = b->maxEdges < slotCapWanted ? (b->maxEdges > 0 ? b->maxEdges : 1) : slotCapWanted;
@@ -586,9 +586,14 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     //   cooperative only 1.98 / 5.35 / 2.83 / 4.60;  lane-per-candidate wherever the instruction count favours it 1.76 / 3.57 / 4.23 / 10.3;
     //   lane-per-candidate only for glyphs of at most 48 edges 1.75 / 5.40 / 2.67 / 4.62  <- default: a chunk of a large glyph is one long
     //   serial walk that the launch ends up waiting for.
+    // Round 2, after the records of the lane-per-candidate walk became scalar loads and the work list heavy-first: with the bound at 128
+    // edges for every launch the CJK-like set gains (4.42 -> 2.82) and the DejaVu set loses (2.33 -> 2.73: 55 k candidates are a latency
+    // chain, not a load) -- k_ec_scan therefore widens the bound only for launches whose cooperative cost exceeds wideLoad instructions.
     lpcMaxContours.lpcEdgeCost = 340, lpcMaxContours.lpcMaxEdges = 48, lpcMaxContours.lpcMinCount = 0x7fffffff;
-    if (const char *env = getenv("MSDFHIP_QUERY_POLICY"))        // experiment knob: "edgeCost,maxEdges,minCount"
-        sscanf(env, "%d,%d,%d", &lpcMaxContours.lpcEdgeCost, &lpcMaxContours.lpcMaxEdges, &lpcMaxContours.lpcMinCount);
+    lpcMaxContours.wideMaxEdges = 128, lpcMaxContours.wideLoad = 4e8f;
+    if (const char *env = getenv("MSDFHIP_QUERY_POLICY"))        // experiment knob: "edgeCost,maxEdges,minCount,wideMaxEdges,wideLoad"
+        sscanf(env, "%d,%d,%d,%d,%f", &lpcMaxContours.lpcEdgeCost, &lpcMaxContours.lpcMaxEdges, &lpcMaxContours.lpcMinCount, &lpcMaxContours.wideMaxEdges,
+               &lpcMaxContours.wideLoad);
     const size_t resLanes = OVERLAP ? (size_t) (lpcMaxContours.lpcMaxContours > 0 ? lpcMaxContours.lpcMaxContours : 1)*WAVE*sizeof(double) : 0;
     const int slotOffset = OVERLAP ? (b->maxContours > 0 ? b->maxContours : 1) : 0;
     const int mergedCap = b->maxContours < slotCap ? (b->maxContours > 0 ? b->maxContours : 1) : slotCap;   // per-contour merged states of a glyph that uses the slots

@@ -787,7 +787,7 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
 //   lane per candidate 64 candidates at a time, every lane walks all edges (uniform control flow, scalar record loads -- the loop of
 //                      k_distance): cost per chunk ~ 340*nE + 1000, whatever the number of live lanes.
 // The first wins for the usual handful of candidates, the second for many (an icon with 186, a 1024x1024 logo with thousands).
-struct EcQueryPolicy { int lpcMaxContours, lpcEdgeCost, lpcMaxEdges, lpcMinCount; };
+struct EcQueryPolicy { int lpcMaxContours, lpcEdgeCost, lpcMaxEdges, lpcMinCount, wideMaxEdges; float wideLoad; };
 MSDF_HD bool ecQueryLanePerCandidate(unsigned count, int nE, int C, EcQueryPolicy q) {
     if (C > q.lpcMaxContours)                                        // its [contour][lane] scratch would not fit the LDS the launch reserved
         return false;
@@ -803,36 +803,66 @@ MSDF_HD int ecQueryItems(unsigned count, unsigned seg, int nE, int C, EcQueryPol
     return ecQueryLanePerCandidate(count, nE, C, lpcMaxContours) ? (int) ((count+WAVE-1)/WAVE) : (int) count;
 }
 
-// Prefix sums of the per-glyph work items of k_ec_query (one workgroup): offsets[g] = items of glyphs < g, offsets[G] = total,
-// offsets[G+1] = the work counter of k_ec_query (zeroed here).
+// Prefix sums of the per-glyph work items of k_ec_query (one workgroup). The list is ordered HEAVY FIRST: the lane-per-candidate chunks
+// (one long serial walk each) of all glyphs, then the cooperative items -- drawn late, a chunk was what the launch ended up waiting
+// for. offsets[0..G] = chunks of glyphs < g (offsets[G] = all chunks); offsets[G+1..2G+1] = the same for the cooperative items,
+// offsets[2G+1] = all of them; offsets[2G+2] = the work counter of k_ec_query (zeroed here). A glyph has items of one kind only.
+// Which glyphs take the lane-per-candidate form depends on the LOAD of the launch: a chunk costs the fewest instructions but is one
+// serial walk of all the glyph's edges by one wavefront. With little work (55 k candidates of the DejaVu set: the kernel is a latency
+// chain) only small glyphs (<= lpcMaxEdges) use it; when the cooperative form of everything would cost more than wideLoad instructions
+// (440 k candidates of the CJK-like set: throughput bound) glyphs up to wideMaxEdges do. offsets[2G+3] = the bound in force.
+MSDF_HD size_t ecOffsetInts(int nGlyphs) { return 2*((size_t) nGlyphs+1)+2; }
+
 __global__ void __launch_bounds__(1024)
 k_ec_scan(BatchView batch, const unsigned *header, unsigned seg, int *offsets, EcQueryPolicy lpcMaxContours) {
-    __shared__ int partial[1024];
+    __shared__ int partial[2][1024];
     const int nGlyphs = batch.nGlyphs;
     const int t = threadIdx.x, per = (nGlyphs+1023)/1024;
     const int lo = t*per < nGlyphs ? t*per : nGlyphs, hi = lo+per < nGlyphs ? lo+per : nGlyphs;
-    int sum = 0;
+    __shared__ float load[1024];
+    float mine = 0;
     for (int g = lo; g < hi; ++g) {
         const int nE = batch.contourOffsets[batch.glyphContourOffsets[g+1]]-batch.contourOffsets[batch.glyphContourOffsets[g]];
-        sum += ecQueryItems(header[1+g], seg, nE, batch.glyphContourOffsets[g+1]-batch.glyphContourOffsets[g], lpcMaxContours);
+        const unsigned count = header[1+g];
+        if (count <= seg)
+            mine += (float) count*(340.f*((nE+WAVE-1)/WAVE)+10.f*nE+1000.f);
     }
-    partial[t] = sum;
+    load[t] = mine;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {                      // inclusive scan of the 1024 partial sums
-        const int v = t >= off ? partial[t-off] : 0;
-        __syncthreads();
-        partial[t] += v;
+    for (int off = 512; off > 0; off >>= 1) {
+        if (t < off)
+            load[t] += load[t+off];
         __syncthreads();
     }
-    int at = partial[t]-sum;
+    if (load[0] > lpcMaxContours.wideLoad && lpcMaxContours.wideMaxEdges > lpcMaxContours.lpcMaxEdges)
+        lpcMaxContours.lpcMaxEdges = lpcMaxContours.wideMaxEdges;
+    int sum[2] = { 0, 0 };
     for (int g = lo; g < hi; ++g) {
-        offsets[g] = at;
+        const int C = batch.glyphContourOffsets[g+1]-batch.glyphContourOffsets[g];
         const int nE = batch.contourOffsets[batch.glyphContourOffsets[g+1]]-batch.contourOffsets[batch.glyphContourOffsets[g]];
-        at += ecQueryItems(header[1+g], seg, nE, batch.glyphContourOffsets[g+1]-batch.glyphContourOffsets[g], lpcMaxContours);
+        sum[ecQueryLanePerCandidate(header[1+g], nE, C, lpcMaxContours) ? 0 : 1] += ecQueryItems(header[1+g], seg, nE, C, lpcMaxContours);
+    }
+    partial[0][t] = sum[0], partial[1][t] = sum[1];
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                      // inclusive scans of the 1024 partial sums
+        const int v0 = t >= off ? partial[0][t-off] : 0, v1 = t >= off ? partial[1][t-off] : 0;
+        __syncthreads();
+        partial[0][t] += v0, partial[1][t] += v1;
+        __syncthreads();
+    }
+    int at[2] = { partial[0][t]-sum[0], partial[1][t]-sum[1] };
+    int *coop = offsets+nGlyphs+1;
+    for (int g = lo; g < hi; ++g) {
+        offsets[g] = at[0], coop[g] = at[1];
+        const int C = batch.glyphContourOffsets[g+1]-batch.glyphContourOffsets[g];
+        const int nE = batch.contourOffsets[batch.glyphContourOffsets[g+1]]-batch.contourOffsets[batch.glyphContourOffsets[g]];
+        at[ecQueryLanePerCandidate(header[1+g], nE, C, lpcMaxContours) ? 0 : 1] += ecQueryItems(header[1+g], seg, nE, C, lpcMaxContours);
     }
     if (t == 1023) {
-        offsets[nGlyphs] = partial[1023];
-        offsets[nGlyphs+1] = 0;
+        offsets[nGlyphs] = partial[0][1023];
+        coop[nGlyphs] = partial[1][1023];
+        coop[nGlyphs+1] = 0;
+        coop[nGlyphs+2] = lpcMaxContours.lpcMaxEdges;
     }
 }
 
@@ -857,8 +887,9 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
     PBSlot *slotBuf = reinterpret_cast<PBSlot *>(smemLds+slotOffset);
     const unsigned *header = reinterpret_cast<const unsigned *>(cands);
     const size_t texelsPerGlyph = (size_t) width*height;
-    const int total = offsets[batch.nGlyphs];
-    int *counter = offsets+batch.nGlyphs+1;
+    const int chunks = offsets[batch.nGlyphs], total = chunks+offsets[2*batch.nGlyphs+1];
+    lpcMaxContours.lpcMaxEdges = offsets[2*batch.nGlyphs+3];        // as k_ec_scan decided for this launch
+    int *counter = offsets+2*batch.nGlyphs+2;
     for (;;) {
         int i = 0;
         if (threadIdx.x == 0)
@@ -866,15 +897,18 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= total)
             break;
-        int lo = 0, hi = batch.nGlyphs-1;                           // the glyph g with offsets[g] <= i < offsets[g+1]
+        const int *part = i < chunks ? offsets : offsets+batch.nGlyphs+1;   // heavy first: the lane-per-candidate chunks, then the cooperative items
+        if (i >= chunks)
+            i -= chunks;
+        int lo = 0, hi = batch.nGlyphs-1;                           // the glyph g with part[g] <= i < part[g+1]
         while (lo < hi) {
             const int mid = (lo+hi)>>1;
-            if (offsets[mid+1] > i)
+            if (part[mid+1] > i)
                 hi = mid;
             else
                 lo = mid+1;
         }
-        const int g = lo, item = i-offsets[g];
+        const int g = lo, item = i-part[g];
         const unsigned count = header[1+g];
         const EcCandidate *segment = cands+ecHeaderRecords(batch.nGlyphs)+(size_t) g*seg;
         const int c0 = batch.glyphContourOffsets[g], C = batch.glyphContourOffsets[g+1]-c0;

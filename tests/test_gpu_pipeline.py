@@ -157,7 +157,7 @@ def test_device_memory_stays_flat_over_many_calls(glyphs):
         [t.start() for t in ts]
         [t.join() for t in ts]
 
-    for _ in range(3):
+    for _ in range(8):                                                        # the pool grows to the largest number of calls ever in flight at once (<= 6 here)
         round_of_threads()
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
@@ -165,7 +165,9 @@ def test_device_memory_stays_flat_over_many_calls(glyphs):
         round_of_threads()
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
-    assert free0-free1 < 8 << 20, "device memory grew by %.1f MB over 25 rounds of fresh threads" % ((free0-free1)/2**20)
+    # a leak of one arena per thread (round 1) would be 150 arenas here; one more pooled arena (a round that happened to overlap more calls
+    # than any warm-up round did) is allowed
+    assert free0-free1 < 24 << 20, "device memory grew by %.1f MB over 25 rounds of fresh threads" % ((free0-free1)/2**20)
 
 
 def test_sharded_into_one_interleaved_atlas(glyphs):
