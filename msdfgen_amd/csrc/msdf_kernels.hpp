@@ -280,7 +280,13 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
         // The bounds U[ch] are per contour for the overlapping combiner (one selector per contour, every contour's own distance is
         // needed) and over the whole shape for the simple combiner (a single selector).
         double U[3] = { DBL_MAX, DBL_MAX, DBL_MAX };
+#if defined(MSDF_ABLATE_PHASE1)                                     // measurement only (with MSDF_ABLATE_PHASE2): launch + header loads + stores
+        const int groups = 0;
+        for (int c = col; c < C; c += ROW)
+            cstart[c] = 0;
+#else
         const int groups = OVERLAP ? C : 1;
+#endif
         for (int grp = 0; grp < groups; ++grp) {
             const int cBegin = OVERLAP ? grp : 0, cEnd = OVERLAP ? grp+1 : C;
             const int b = coff[cBegin]-e0, e = coff[cEnd]-e0;
