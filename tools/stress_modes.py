@@ -21,7 +21,7 @@ desc = gb.descriptors(cx, 48, 48, 3)
 ref = None
 bad = 0
 for i in range(iters):
-    os.environ["MSDFHIP_PERSISTENT_ROUNDS"] = "0" if i % 2 == 0 else "8"
+    os.environ["MSDFHIP_PERSISTENT_ROUNDS"] = (sys.argv[3] if len(sys.argv) > 3 else "0,8").split(",")[i % len((sys.argv[3] if len(sys.argv) > 3 else "0,8").split(","))]
     for _ in range(3):                                   # several steps in flight, as bench_configs does
         gb.digest()
         gb.generate(3, 48, 48, descriptors=desc, out=out)
