@@ -858,6 +858,11 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
         else if (mine)
             selDistance(acc, pass == 1 ? innerD : outerD);
     }
+#if defined(MSDF_ABLATE_EPILOGUE)                                   // measurement only: what the combiner's selection loops over the stored distances cost
+    for (int ch = 0; ch < NCH; ++ch)
+        out[ch] = shapeD[ch]+(double) (nInner+nOuter+firstInner+firstOuter);
+    return;
+#endif
     // merged selector with exactly one member == that member's own selector; with none, the initial state (every channel -DBL_MAX)
     for (int ch = 0; ch < NCH; ++ch) {
         if (nInner == 1)
