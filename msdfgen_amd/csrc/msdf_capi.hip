@@ -205,6 +205,10 @@ int residentSlots(int device) {
     return n;
 }
 
+// LDS of k_distance's phase 1 per tile: survivor list [maxEdges], list offsets per contour [C+1] (+1 spare) and, in the global-scratch
+// form, the per-contour channel bounds [C][3] (the LDS form keeps those in the combiner scratch's region)
+size_t tileListBytes(int maxEdges, int maxContours, bool withBounds) { return ((size_t) maxEdges+(withBounds ? 4 : 1)*(size_t) maxContours+2)*sizeof(int); }
+
 size_t ldsBudget() {
     // The combiner scratch lives in LDS only while 12 wavefronts (3 per SIMD, the register-limited occupancy) fit a CU's 160 KB:
     // beyond ~13 KB per wavefront LDS would cap the occupancy (a 20-contour glyph set ran at 1.25 wavefronts/SIMD), so it moves to a
@@ -221,7 +225,7 @@ int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan, int max
     if (maxEdges < 0)
         maxEdges = b->maxEdges;
     const size_t resBytes = overlap ? (size_t) maxContours*nch*WAVE*sizeof(double) : 0;
-    const size_t idxOne = ((size_t) maxEdges+(size_t) maxContours+2)*sizeof(int);   // survivor list + per-contour offsets of one tile
+    const size_t idxOne = tileListBytes(maxEdges, maxContours, false);   // survivor list + per-contour offsets of one tile
     const size_t idxBytes = (size_t) QUAD*idxOne;                // the LDS-scratch variant culls a quad of tiles per wavefront
     plan.ldsBudget = ldsBudget();
     const size_t limit = (size_t) gLdsLimit.load();
@@ -229,7 +233,7 @@ int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan, int max
     plan.globalRes = overlap && resBytes+idxBytes > plan.ldsBudget;
     plan.idxBytes = idxBytes;
     plan.listStride = maxEdges;
-    plan.bytes = plan.globalRes ? idxOne : resBytes+idxBytes;     // the global-scratch variant takes one tile per wavefront
+    plan.bytes = plan.globalRes ? tileListBytes(maxEdges, maxContours, true) : resBytes+idxBytes;     // the global-scratch variant takes one tile per wavefront
     if (plan.bytes > limit)
         return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours / %d edges: the survivor lists need %zu B of LDS per wavefront, device limit is %zu B",
                     maxContours, maxEdges, plan.bytes, limit);
@@ -416,7 +420,7 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     const bool smallLaunch = (size_t) b->nGlyphs*tilesAll <= 8192 && (!overlap || gresAll <= ((size_t) 64<<20));
     LdsPlan single = plan;                                       // one tile per wavefront: one survivor list, scratch (if any) in global memory
     single.globalRes = true;
-    single.bytes = ((size_t) b->maxEdges+(size_t) b->maxContours+2)*sizeof(int);
+    single.bytes = tileListBytes(b->maxEdges, b->maxContours, true);
     single.resBytes = overlap ? (size_t) b->maxContours*SelTraits<SEL>::NCH*WAVE*sizeof(double) : 0;
     if (!overlap || b->maxContours <= 1) {
         if (smallLaunch)
@@ -433,7 +437,7 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     // how many contours' worth of combiner scratch fit the per-wavefront LDS budget next to the survivor lists of a SMALL_MAX_EDGES glyph
     const size_t perContour = (size_t) SelTraits<SEL>::NCH*WAVE*sizeof(double);
     int limit = 0;
-    while ((size_t) (limit+1)*perContour+(size_t) QUAD*((size_t) SMALL_MAX_EDGES+(limit+1)+2)*sizeof(int) <= plan.ldsBudget)
+    while ((size_t) (limit+1)*perContour+(size_t) QUAD*tileListBytes(SMALL_MAX_EDGES, limit+1, false) <= plan.ldsBudget)
         ++limit;
     if (b->nGlyphs == 1) {                                       // the class is known, no index map
         if (b->maxContours <= limit && b->maxEdges <= SMALL_MAX_EDGES && !plan.globalRes)
@@ -477,7 +481,7 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     if (nRest > 0) {                                             // first: few, heavy glyphs -- the longest tail
         LdsPlan rest = plan;                                     // sized for the batch's largest glyph
         rest.globalRes = true;
-        rest.bytes = ((size_t) b->maxEdges+(size_t) b->maxContours+2)*sizeof(int);
+        rest.bytes = tileListBytes(b->maxEdges, b->maxContours, true);
         rc = launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, rest, sRest, b->dBucket+b->nOne+b->nSmall, nRest);
         if (rc != MSDFHIP_OK)
             return rc;

@@ -70,6 +70,7 @@ MSDF_HD unsigned cullOrderKey(const EdgeRec &e, V2 c, int slot) {
     return (bits&~15u)|(unsigned) (slot&15);
 }
 #define MSDF_CULL_KEY_DROPPED 0x7f800000u                        // non-survivors: behind every survivor
+#define MSDF_CULL_KEY_DROPPED_SEGMENTED 0xfffffff0u              // the same for keys that lead with a contour segment (k_distance, overlapping combiner)
 
 // Channel mask with which an edge takes part in selector SEL (1: all edges one "channel"; 2: ditto; 3/4: its colour bits).
 template <int SEL>
