@@ -285,124 +285,87 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             cstart[c] = 0;
 #else
         const int nE = coff[C]-e0;
+        // Segment-parallel: the lanes of a row take ROW CONSECUTIVE edges of the glyph whatever their contour (a loop per contour left
+        // most lanes idle and cost two dependent gathers per contour: 27 rounds for a 14-contour glyph, now 4).
+        // Pass A: the bounds. Overlapping combiner: every edge lowers the bound of ITS contour and channels with an LDS atomic minimum
+        // (non-negative floats order like their bit patterns); the bounds live in the region of the combiner scratch, which phase 2 only
+        // writes after the barrier below (LDS form), or behind the list offsets (global-scratch form). Simple combiner: one bound per
+        // channel for the whole shape, a DPP minimum per round.
+        unsigned *bounds = (GRES || !OVERLAP ? reinterpret_cast<unsigned *>(cstarts+(size_t) TPW*(C+1)) : reinterpret_cast<unsigned *>(smem))+(size_t) q*C*3;   // [TPW][C][3]
         if (OVERLAP) {
-            // Segment-parallel: the lanes of a row take ROW CONSECUTIVE edges of the glyph whatever their contour (a loop per contour
-            // left most lanes idle and cost two dependent gathers per contour: 27 rounds for a 14-contour glyph, now 4).
-            // Pass A: every edge lowers the bound of ITS contour and channels with an LDS atomic minimum (non-negative floats order like
-            // their bit patterns).
-            // (LDS form: the bounds live in the region of the combiner scratch, which phase 2 only writes after the barrier below;
-            // global-scratch form: behind the list offsets)
-            unsigned *bounds = (GRES ? reinterpret_cast<unsigned *>(cstarts+(size_t) TPW*(C+1)) : reinterpret_cast<unsigned *>(smem))+(size_t) q*C*3;   // [TPW][C][3]
             for (int k = col; k < C*3; k += ROW)
                 bounds[k] = 0x7f800000u;
             waveSync();
-            for (int base = 0; base < nE; base += ROW) {
-                const int i = base+col;
-                if (i < nE && tileValid) {
-                    const int mask = cullMask<SEL>(rec[i]);
-                    if (mask) {
-                        const unsigned ub = (unsigned) __float_as_int(floatAbove(cullUpperDistance(rec[i], tc)));
-                        unsigned *mine = bounds+(size_t) (rec[i].contour-c0)*3;
-                        for (int ch = 0; ch < (SEL <= 2 ? 1 : 3); ++ch)
-                            if ((mask>>ch)&1)
-                                atomicMin(mine+ch, ub);
-                    }
-                }
-            }
-            waveSync();
-            // Pass B: the cull test against the contour's bounds; survivors go to the list grouped by contour (edges are stored contour
-            // by contour, so list order = lane order does it), within a DPP row nearest-first inside each contour's segment.
-            for (int base = 0; base < nE; base += ROW) {
-                const int i = base+col;
-                bool keep = false;
-                int c = 0;
-                if (i < nE) {
-                    c = rec[i].contour-c0;
-                    const int mask = cullMask<SEL>(rec[i]);
-                    if (mask && tileValid) {
-                        const unsigned *mine = bounds+(size_t) c*3;
-                        double umax = 0;
-                        for (int ch = 0; ch < (SEL <= 2 ? 1 : 3); ++ch)
-                            if ((mask>>ch)&1)
-                                umax = dmax(umax, (double) __int_as_float((int) mine[ch]));
-#if defined(MSDF_NO_TILE_CULL)
-                        keep = true;
-#else
-                        keep = cullEdgeSurvives<(SEL >= 2)>(rec[i], tc, tr, umax);
-#endif
-                    }
-                }
-                // key = (contour segment within the 16-lane row | distance | slot): contours stay grouped, nearest first inside each
-                const int rowFirstContour = __shfl(c, lane&~15);
-                unsigned key = MSDF_CULL_KEY_DROPPED_SEGMENTED|(unsigned) (col&15);
-                if (keep) {
-                    const unsigned d = (cullOrderKey(rec[i], tc, 0)>>3)&0x0ffffff0u;
-                    key = ((unsigned) ((c-rowFirstContour)&15)<<28)|(d < 0x0ffffff0u ? d : 0x0fffffe0u)|(unsigned) (col&15);
-                }
-                const int rank = rowRank(key);
-                const unsigned long long ballot = __ballot(keep);
-                const unsigned long long rowBallot = TPW == 1 ? ballot : (ballot>>(ROW*q))&0xffffull;
-                const int before = TPW == 1 ? __popcll(ballot&((1ull<<(col&~15))-1ull)) : 0;     // survivors in the earlier rows of a 64-lane chunk
-                if (keep)
-                    list[nSurv+before+rank] = i;
-                if (i < nE && coff[c]-e0 == i) {                    // first edge of its contour: the contour's list starts here ...
-                    const int at = nSurv+__popcll(rowBallot&((1ull<<col)-1ull));
-                    cstart[c] = at;
-                    for (int cc = c-1; cc >= 0 && coff[cc]-e0 == i; --cc)
-                        cstart[cc] = at;                            // ... and so do the (empty) contours right before it
-                }
-                nSurv += __popcll(rowBallot);
-            }
-            for (int c = col; c < C; c += ROW)                      // empty contours at the end
-                if (coff[c]-e0 == nE)
-                    cstart[c] = nSurv;
-        } else {
-            for (int base = 0; base < nE; base += ROW) {
-                const int i = base+col;
-                double ub = 0;
-                int mask = 0;
-                if (i < nE && tileValid) {
+        }
+        for (int base = 0; base < nE; base += ROW) {
+            const int i = base+col;
+            double ub = 0;
+            int mask = 0;
+            if (i < nE && tileValid) {
+                mask = cullMask<SEL>(rec[i]);
+                if (mask || !OVERLAP)
                     ub = cullUpperDistance(rec[i], tc);
-                    mask = cullMask<SEL>(rec[i]);
+            }
+            const float ubf = floatAbove(ub);
+            if (OVERLAP) {
+                if (mask) {
+                    unsigned *mine = bounds+(size_t) (rec[i].contour-c0)*3;
+                    for (int ch = 0; ch < (SEL <= 2 ? 1 : 3); ++ch)
+                        if ((mask>>ch)&1)
+                            atomicMin(mine+ch, (unsigned) __float_as_int(ubf));
                 }
-                const float ubf = floatAbove(ub);
+            } else
                 for (int ch = 0; ch < (SEL <= 2 ? 1 : 3); ++ch)
                     U[ch] = dmin(U[ch], (double) (TPW == 1 ? waveMinNonNegative((mask>>ch)&1 ? ubf : __int_as_float(0x7f800000))
                                                            : rowMinNonNegative((mask>>ch)&1 ? ubf : __int_as_float(0x7f800000), lane)));
-            }
-            for (int c = 0; c < C; ++c) {
-                const int cb = coff[c]-e0, ce = coff[c+1]-e0;
-                if (col == 0)
-                    cstart[c] = nSurv;
-                for (int base = cb; base < ce; base += ROW) {
-                    const int i = base+col;
-                    bool keep = false;
-                    if (i < ce && tileValid) {
-                        const int mask = cullMask<SEL>(rec[i]);
-                        if (mask) {
-                            double umax = 0;
-                            for (int ch = 0; ch < (SEL <= 2 ? 1 : 3); ++ch)
-                                if ((mask>>ch)&1)
-                                    umax = dmax(umax, U[ch]);
+        }
+        if (OVERLAP)
+            waveSync();
+        // Pass B: the cull test against the bounds; survivors go to the list grouped by contour (edges are stored contour by contour, so
+        // list order = lane order does it), within a DPP row nearest-first inside each contour's segment.
+        for (int base = 0; base < nE; base += ROW) {
+            const int i = base+col;
+            bool keep = false;
+            int c = 0;
+            if (i < nE) {
+                c = rec[i].contour-c0;
+                const int mask = cullMask<SEL>(rec[i]);
+                if (mask && tileValid) {
+                    double umax = 0;
+                    for (int ch = 0; ch < (SEL <= 2 ? 1 : 3); ++ch)
+                        if ((mask>>ch)&1)
+                            umax = dmax(umax, OVERLAP ? (double) __int_as_float((int) bounds[(size_t) c*3+ch]) : U[ch]);
 #if defined(MSDF_NO_TILE_CULL)
-                            keep = true;
+                    keep = true;
 #else
-                            keep = cullEdgeSurvives<(SEL >= 2)>(rec[i], tc, tr, umax);
+                    keep = cullEdgeSurvives<(SEL >= 2)>(rec[i], tc, tr, umax);
 #endif
-                        }
-                    }
-                    // survivors of each group of 16 edges (one DPP row) go to the list nearest-first; groups stay in visit order
-                    const unsigned key = keep ? cullOrderKey(rec[i], tc, col) : (MSDF_CULL_KEY_DROPPED|(unsigned) (col&15));
-                    const int rank = rowRank(key);
-                    const unsigned long long ballot = __ballot(keep);
-                    const unsigned long long rowBallot = TPW == 1 ? ballot : (ballot>>(ROW*q))&0xffffull;
-                    const int before = TPW == 1 ? __popcll(ballot&((1ull<<(col&~15))-1ull)) : 0;     // survivors in the earlier rows of a 64-lane chunk
-                    if (keep)
-                        list[nSurv+before+rank] = i;
-                    nSurv += __popcll(rowBallot);
                 }
             }
+            // key = (contour segment within the 16-lane row | distance | slot): contours stay grouped, nearest first inside each
+            const int rowFirstContour = __shfl(c, lane&~15);
+            unsigned key = MSDF_CULL_KEY_DROPPED_SEGMENTED|(unsigned) (col&15);
+            if (keep) {
+                const unsigned d = (cullOrderKey(rec[i], tc, 0)>>3)&0x0ffffff0u;
+                key = ((unsigned) ((c-rowFirstContour)&15)<<28)|(d < 0x0ffffff0u ? d : 0x0fffffe0u)|(unsigned) (col&15);
+            }
+            const int rank = rowRank(key);
+            const unsigned long long ballot = __ballot(keep);
+            const unsigned long long rowBallot = TPW == 1 ? ballot : (ballot>>(ROW*q))&0xffffull;
+            const int before = TPW == 1 ? __popcll(ballot&((1ull<<(col&~15))-1ull)) : 0;     // survivors in the earlier rows of a 64-lane chunk
+            if (keep)
+                list[nSurv+before+rank] = i;
+            if (i < nE && coff[c]-e0 == i) {                        // first edge of its contour: the contour's list starts here ...
+                const int at = nSurv+__popcll(rowBallot&((1ull<<col)-1ull));
+                cstart[c] = at;
+                for (int cc = c-1; cc >= 0 && coff[cc]-e0 == i; --cc)
+                    cstart[cc] = at;                                // ... and so do the (empty) contours right before it
+            }
+            nSurv += __popcll(rowBallot);
         }
+        for (int c = col; c < C; c += ROW)                          // empty contours at the end
+            if (coff[c]-e0 == nE)
+                cstart[c] = nSurv;
 #endif
         if (col == 0)
             cstart[C] = nSurv;
