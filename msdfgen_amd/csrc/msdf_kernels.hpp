@@ -221,7 +221,7 @@ struct DistanceArgs {
 };
 
 template <int SEL, bool OVERLAP, bool GRES = false>
-__global__ void __launch_bounds__(WAVE, OVERLAP ? MSDF_DISTANCE_WAVES_PER_SIMD : MSDF_SIMPLE_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(WAVE, OVERLAP ? MSDF_DISTANCE_WAVES_PER_SIMD : GRES ? MSDF_SIMPLE_WAVES_PER_SIMD-1 : MSDF_SIMPLE_WAVES_PER_SIMD)   // (simple combiner, one tile per wavefront = latency-bound launches only: 128 VGPRs, no spills)
 k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const int32_t *__restrict__ contourOffsets, const EdgeRec *__restrict__ recs,
            const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges,
            float *__restrict__ dst, int toScratch, unsigned blockBase, double *__restrict__ gres, size_t gresStride, const int *__restrict__ glyphMap, int nMapped,
