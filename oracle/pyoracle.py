@@ -18,6 +18,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "libmsdf_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libmsdfgen_ref.so")
+REF_OMP_SO = os.path.join(HERE, "_ref", "libmsdfgen_ref_omp.so")   # same sources, MSDFGEN_USE_OPENMP (CPU baseline of one large bitmap)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -268,13 +269,14 @@ class Ref:
     def available():
         return os.path.exists(REF_SO)
 
-    def __init__(self):
-        if not os.path.exists(REF_SO):
+    def __init__(self, openmp=False):
+        so = REF_OMP_SO if openmp else REF_SO
+        if not os.path.exists(so):
             if os.path.isdir("/root/reference/core"):
                 build("ref")
             else:
-                raise FileNotFoundError(REF_SO+" (build it in the authoring container: make -C oracle ref)")
-        self.lib = L = C.CDLL(REF_SO)
+                raise FileNotFoundError(so+" (build it in the authoring container: make -C oracle ref)")
+        self.lib = L = C.CDLL(so)
         vp = C.c_void_p
         L.ref_version.restype = C.c_char_p
         L.ref_shape_from_desc.argtypes = [C.c_char_p]

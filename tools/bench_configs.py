@@ -127,6 +127,56 @@ def main():
     lb = ShapeBatch.from_shapes([logo])
     lx = np.stack([autoframe(logo.bounds(), 1024, 1024, 8)])
     report("cfg5: %d-edge cubic logo msdf 1024x1024 default EC" % logo.n_edges, lb, 3, 1024, 1024, lx, reps=max(2, args.reps//3))
+    if not args.only or "cpu" in args.only.split(","):
+        cpu_baselines(dj, zd["xf48"], base, logo, lx[0])
+
+
+def cpu_baselines(dj, xf48, cjk_shapes, logo, logo_xf, budget_s=8.):
+    """SURVEY 8(d) "CPU baseline timing" beside configs 4 and 5: the COMPILED REFERENCE (oracle/_ref, test infrastructure -- timed here as
+    the baseline, never part of the product path) on the host cores of the same box. Config 4: glyph-parallel thread pool over a bounded
+    sample (what msdf-atlas-gen does). Config 5: one 1024x1024 bitmap -- single thread, and the reference's own OpenMP row loops
+    (MSDFGEN_USE_OPENMP, core/msdfgen.cpp:56-64, core/MSDFErrorCorrection.cpp:420-430) on the same number of threads."""
+    import time
+    from bench import available_cores
+    from oracle.pyoracle import Ref
+    from msdfgen_amd.shape import autoframe
+    if not Ref.available():
+        print(json.dumps({"config": "cpu baselines", "skipped": "oracle/_ref not built"}), flush=True)
+        return
+    cores = available_cores()
+    ref = Ref()
+
+    def pool_rate(shapes, xfs, w, h):
+        probe = min(len(shapes), 4*cores)
+        _, secs = ref.generate_batch_timed(shapes[:probe], 3, w, h, xfs[:probe], threads=cores)
+        n = int(min(max(probe, probe/max(secs, 1e-9)*budget_s), 100000))
+        idx = [i % len(shapes) for i in range(n)]
+        _, secs = ref.generate_batch_timed([shapes[i] for i in idx], 3, w, h, xfs[idx], threads=cores)
+        return n, secs
+
+    pick = list(range(0, dj.n_glyphs, 8))
+    n, secs = pool_rate([dj.shape(g) for g in pick], xf48[pick], 48, 48)
+    print(json.dumps({"config": "cpu: cfg4 real fonts msdf 48x48 default EC, compiled reference, glyph-parallel pool", "threads": cores, "glyphs": n,
+                      "seconds": round(secs, 2), "glyphs_per_s": round(n/secs)}), flush=True)
+    cx = np.stack([autoframe(s.bounds(), 48, 48, 4) for s in cjk_shapes[:128]])
+    n, secs = pool_rate(cjk_shapes[:128], cx, 48, 48)
+    print(json.dumps({"config": "cpu: cfg4 CJK-like msdf 48x48 default EC, compiled reference, glyph-parallel pool", "threads": cores, "glyphs": n,
+                      "seconds": round(secs, 2), "glyphs_per_s": round(n/secs)}), flush=True)
+    t0 = time.perf_counter()
+    ref.generate(logo, 3, 1024, 1024, logo_xf)
+    single = time.perf_counter()-t0
+    line = {"config": "cpu: cfg5 logo msdf 1024x1024 default EC, compiled reference", "single_thread_s": round(single, 2)}
+    try:
+        os.environ["OMP_NUM_THREADS"] = str(cores)
+        omp = Ref(openmp=True)
+        omp.generate(logo, 3, 64, 64, autoframe(logo.bounds(), 64, 64, 4))          # spin the OpenMP team up
+        t0 = time.perf_counter()
+        omp.generate(logo, 3, 1024, 1024, logo_xf)
+        line["openmp_rows_s"], line["openmp_threads"] = round(time.perf_counter()-t0, 2), cores
+    except (OSError, FileNotFoundError) as e:
+        line["openmp_rows_s"] = None
+        line["openmp_note"] = str(e)[:120]
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
