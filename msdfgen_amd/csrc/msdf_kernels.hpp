@@ -622,10 +622,10 @@ k_ec_params(EcGlyphParams *out, BatchView batch, const MsdfHipGlyph *glyphs, Msd
 #ifndef MSDF_EC_FAST_WAVES_PER_SIMD
 #define MSDF_EC_FAST_WAVES_PER_SIMD 8   // 64 VGPRs (6 spilled). Measured, ms per 8192 glyphs of the whole correction pass: 4-6 waves 1.83, 7 waves 1.77, 8 waves 1.75
 #endif
-// LDS of k_ec_fast per wavefront: corner list | 10x10 halo tile of the field | per-texel verdict words | item count | item queue.
+// LDS of k_ec_fast per wavefront: 10x10 halo tile of the field | per-texel verdict words | item count | item queue (5.6 KB for msdf).
 enum { EC_HALO = TILE+2, EC_QUEUE_CAP = WAVE*24, EC_PROTECT_QUEUE_CAP = WAVE*8 };
 __host__ __device__ inline size_t ecFastLdsBytes(int maxEdges, int n) {
-    return (size_t) (maxEdges > 0 ? maxEdges : 1)*2*sizeof(int)+(size_t) EC_HALO*EC_HALO*n*sizeof(float)+(WAVE+4)*sizeof(int)
+    return (size_t) EC_HALO*EC_HALO*n*sizeof(float)+(WAVE+4)*sizeof(int)
            +(EC_QUEUE_CAP+EC_PROTECT_QUEUE_CAP)*sizeof(unsigned short);
 }
 
@@ -634,11 +634,11 @@ __global__ void __launch_bounds__(WAVE, MSDF_EC_FAST_WAVES_PER_SIMD)
 k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph,
           const float *src, float *out, uint8_t *stencilOut, MsdfHipConfig cfg, const EcGlyphParams *glyphParams, EcCandidate *cands, unsigned seg,
           int maxEdges, const int *corners) {
-    extern __shared__ int smemCorners[];                            // (l, b) per colour-change corner near this tile, then the regions below
+    extern __shared__ int smemFast[];
     const GlyphWork wk = decodeBlock(batch.nGlyphs, tilesPerGlyph);
     if (!wk.valid)
         return;
-    float *halo = reinterpret_cast<float *>(smemCorners+2*(maxEdges > 0 ? maxEdges : 1));   // [EC_HALO*EC_HALO][N]
+    float *halo = reinterpret_cast<float *>(smemFast);                                      // [EC_HALO*EC_HALO][N]
     int *verdictLds = reinterpret_cast<int *>(halo+EC_HALO*EC_HALO*N);                      // [WAVE]: bits 0-1 judge(), bit 8 protected
     int *itemCount = verdictLds+WAVE;
     unsigned short *queue = reinterpret_cast<unsigned short *>(itemCount+4);               // [EC_QUEUE_CAP]: lane | k<<6 | j<<9
@@ -655,8 +655,12 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
     p.radiusH = gp.radiusH, p.radiusV = gp.radiusV, p.radiusD = gp.radiusD;
     const int tx = wk.tile%tilesX, ty = wk.tile/tilesX;
 
-    // protectCorners (MSDFErrorCorrection.cpp:121-151): of the glyph's corner texel pairs (k_ec_params) only those that touch this tile
-    int nCorners = 0;
+    // protectCorners (MSDFErrorCorrection.cpp:121-151): lanes = the glyph's corner texel pairs (k_ec_params); the few that touch this
+    // tile are broadcast one by one and every texel lane tests itself -- no list in LDS (it had been sized by the batch's largest glyph
+    // and capped the kernel at 4 wavefronts per SIMD on a batch with one 543-edge symbol)
+    const int lxT = lane&(TILE-1), lyT = lane>>3;
+    const int xT = tx*TILE+lxT, ysT = gd.flip ? height-1-(ty*TILE+lyT) : ty*TILE+lyT;
+    bool cornerTexel = false;
     if (p.mode == EC_MODE_EDGE_PRIORITY) {
         const int x0 = tx*TILE, x1 = tx*TILE+TILE-1;
         const int ya = gd.flip ? height-1-(ty*TILE+TILE-1) : ty*TILE, yb = gd.flip ? height-1-ty*TILE : ty*TILE+TILE-1;   // shape-space rows of the tile
@@ -669,13 +673,11 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
                 l = list[2*k], b = list[2*k+1];
                 near = l+1 >= x0 && l <= x1 && b+1 >= ya && b <= yb;
             }
-            const unsigned long long mask = __ballot(near);
-            if (near) {
-                const int slot = nCorners+__popcll(mask&((1ull<<lane)-1ull));
-                smemCorners[2*slot] = l;
-                smemCorners[2*slot+1] = b;
+            for (unsigned long long mask = __ballot(near); mask; mask &= mask-1) {
+                const int src = __ffsll((long long) mask)-1;
+                const int cl = __builtin_amdgcn_readlane(l, src), cb = __builtin_amdgcn_readlane(b, src);
+                cornerTexel = cornerTexel || ((xT == cl || xT == cl+1) && (ysT == cb || ysT == cb+1));
             }
-            nCorners += __popcll(mask);
         }
     }
 
@@ -697,7 +699,6 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
     const int lx = lane&(TILE-1), ly = lane>>3;
     const int x = tx*TILE+lx, yn = ty*TILE+ly;
     const bool inside = x < width && yn < height;
-    const int ys = gd.flip ? height-1-yn : yn;
     int st = 0;
 #if defined(MSDF_EC_ABLATE) && MSDF_EC_ABLATE == 1                          // measurement only: halo load + store, no classification
     if (false) {
@@ -719,13 +720,8 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
             }
         }
         if (p.mode == EC_MODE_EDGE_PRIORITY) {
-            for (int i = 0; i < nCorners; ++i) {
-                const int l = smemCorners[2*i], b = smemCorners[2*i+1];
-                if ((x == l || x == l+1) && (ys == b || ys == b+1)) {
-                    st |= EC_PROTECTED;
-                    break;
-                }
-            }
+            if (cornerTexel)
+                st |= EC_PROTECTED;
             if (!(st&EC_PROTECTED)) {
                 struct PushProtect {
                     unsigned short *queue;
