@@ -209,6 +209,29 @@ def test_degenerate_and_empty_inputs(oracle):
             close(gen(mode, s, 20, 16, xf, cfg(ov)), oracle.generate(s, mode, 20, 16, xf, overlap=ov), "degenerate mode %d ov %d" % (mode, ov))
 
 
+def test_empty_contours_in_batched_launches(oracle):
+    """Empty contours before, between and after the real ones, in launches large enough for the batched forms of k_distance (four tiles
+    per wavefront with the scratch in LDS; global scratch): phase 1 walks the glyph's edges across contour boundaries and has to give
+    every contour -- also an empty one -- the right slice of the survivor list."""
+    def tri(cx, cy, r, colours=(6, 5, 3), flip=False):
+        pts = [(cx+r*np.cos(a), cy+r*np.sin(a)) for a in (0.3, 2.4, 4.5)]
+        if flip:
+            pts = pts[::-1]
+        return [(colours[k], pts[k], pts[(k+1) % 3]) for k in range(3)]
+    few = FlatShape.from_contours([[], tri(.3, .3, .22), [], [], tri(.65, .6, .3, flip=True), []])
+    many = FlatShape.from_contours([[]]+[c for k in range(9) for c in (tri(.15+.08*k, .2+.07*k, .12, flip=bool(k % 2)), [])]+[[], []])
+    assert few.n_contours == 6 and many.n_contours == 21
+    shapes = [few, many]*90                                                   # 180 glyphs x 64 tiles: not a small launch
+    xfs = np.stack([autoframe((0, 0, 1, 1), 64, 64, 4)]*len(shapes))
+    for ov in (True, False):
+        gb = M.GlyphBatch(ShapeBatch.from_shapes(shapes))
+        got = gb.generate(3, 64, 64, xfs, config=cfg(ov)).cpu().numpy()
+        gb.close()
+        for g, s in enumerate((few, many)):
+            close(got[g], oracle.generate(s, 3, 64, 64, xfs[g], overlap=ov), "empty contours, shape %d, overlap %d" % (g, ov))
+        assert (bits(got[0::2]) == bits(got[0])).all() and (bits(got[1::2]) == bits(got[1])).all()
+
+
 def test_many_contours_cjk_like_48(oracle):
     """BASELINE config 4 stand-in at parity size: CJK-like glyphs (8-20 contours, 60-150 edges), msdf 48x48."""
     shapes = [synth.cjk_like_shape(8192+i) for i in range(6)]
