@@ -123,6 +123,8 @@ def main():
     report("8192 distinct DejaVu glyphs msdf 64x64, simple combiner", dj, 3, 64, 64, zd["xf64"], config=M.MSDFGeneratorConfig(False), reps=max(2, args.reps//2))
     report("8192 distinct DejaVu glyphs msdf 64x64, error correction disabled", dj, 3, 64, 64, zd["xf64"],
            config=M.MSDFGeneratorConfig(True, M.ErrorCorrectionConfig(M.EC_DISABLED)), reps=max(2, args.reps//2))
+    report("scanline flow on the 8192 distinct DejaVu glyphs: msdf 64x64 simple combiner -> distanceSignCorrection -> EC without distance check", dj, 3, 64, 64,
+           zd["xf64"], config=scan, scanline_pass=True, reps=max(2, args.reps//2))
     logo = synth.logo_shape(5)
     lb = ShapeBatch.from_shapes([logo])
     lx = np.stack([autoframe(logo.bounds(), 1024, 1024, 8)])
