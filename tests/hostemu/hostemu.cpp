@@ -62,47 +62,63 @@ struct TileCull {
     std::vector<int> list, cstart;
 };
 
+// Phase 1 of k_distance for one tile, as the kernel does it (msdf_kernels.hpp): bounds per contour (overlapping combiner) or per shape
+// (simple combiner) as floats rounded up, one cull pass over the glyph's edges in rows of 16 consecutive edges whatever their contour;
+// the survivors of a row go to the list contour by contour, nearest-first inside each contour's segment of the row.
+static float floatAboveHost(double d) {
+    float f = (float) d;
+    if ((double) f < d)
+        f = std::nextafter(f, INFINITY);
+    return f;
+}
+
 template <int SEL>
 TileCull cullTile(const Digest &d, const int32_t *co, int nC, bool overlap, const Xform &t, int tx, int ty, int tile) {
     TileCull tcull;
     const V2 tc = unproject(t, mk(tx*tile+.5*tile, ty*tile+.5*tile));
     const double hx = (.5*tile-.5)/fabs(t.sx), hy = (.5*tile-.5)/fabs(t.sy);
     const double tr = sqrt(hx*hx+hy*hy);
-    const int groups = overlap ? nC : 1;
-    for (int grp = 0; grp < groups; ++grp) {
-        const int cBegin = overlap ? grp : 0, cEnd = overlap ? grp+1 : nC;
-        const int b = co[cBegin]-co[0], e = co[cEnd]-co[0];
-        double U[3] = { DBL_MAX, DBL_MAX, DBL_MAX };
-        for (int i = b; i < e; ++i) {
-            const double ub = cullUpperDistance(d.recs[i], tc);
+    const int nE = co[nC]-co[0];
+    std::vector<int> contourOf((size_t) nE, 0);
+    for (int c = 0; c < nC; ++c)
+        for (int i = co[c]-co[0]; i < co[c+1]-co[0]; ++i)
+            contourOf[i] = c;
+    std::vector<float> U((size_t) (nC > 0 ? nC : 1)*3, INFINITY);
+    for (int i = 0; i < nE; ++i) {
+        const int mask = cullMask<SEL>(d.recs[i]);
+        const float ub = floatAboveHost(cullUpperDistance(d.recs[i], tc));
+        float *mine = &U[(size_t) (overlap ? contourOf[i] : 0)*3];
+        for (int ch = 0; ch < 3; ++ch)
+            if ((mask>>ch)&1)
+                mine[ch] = ub < mine[ch] ? ub : mine[ch];
+    }
+    std::vector<int> perContour((size_t) nC+1, 0);
+    for (int group = 0; group < nE; group += 16) {                            // one DPP row of phase 1
+        std::vector<std::pair<std::pair<int, unsigned>, int> > keyed;
+        for (int i = group; i < nE && i < group+16; ++i) {
             const int mask = cullMask<SEL>(d.recs[i]);
+            if (!mask)
+                continue;
+            const float *mine = &U[(size_t) (overlap ? contourOf[i] : 0)*3];
+            double umax = 0;
             for (int ch = 0; ch < 3; ++ch)
                 if ((mask>>ch)&1)
-                    U[ch] = dmin(U[ch], ub);
+                    umax = dmax(umax, (double) mine[ch]);
+            if (cullEdgeSurvives<(SEL >= 2)>(d.recs[i], tc, tr, umax))
+                keyed.push_back(std::make_pair(std::make_pair(contourOf[i], cullOrderKey(d.recs[i], tc, i-group)), i));
         }
-        for (int c = cBegin; c < cEnd; ++c) {
-            tcull.cstart.push_back((int) tcull.list.size());
-            const int cb = co[c]-co[0], ce = co[c+1]-co[0];
-            for (int group = cb; group < ce; group += 16) {                  // one DPP row of phase 1: its survivors are listed nearest-first
-                std::vector<std::pair<unsigned, int> > keyed;
-                for (int i = group; i < ce && i < group+16; ++i) {
-                    const int mask = cullMask<SEL>(d.recs[i]);
-                    if (!mask)
-                        continue;
-                    double umax = 0;
-                    for (int ch = 0; ch < 3; ++ch)
-                        if ((mask>>ch)&1)
-                            umax = dmax(umax, U[ch]);
-                    if (cullEdgeSurvives<(SEL >= 2)>(d.recs[i], tc, tr, umax))
-                        keyed.push_back(std::make_pair(cullOrderKey(d.recs[i], tc, i-group), i));
-                }
-                std::sort(keyed.begin(), keyed.end());
-                for (size_t k = 0; k < keyed.size(); ++k)
-                    tcull.list.push_back(keyed[k].second);
-            }
+        std::sort(keyed.begin(), keyed.end());
+        for (size_t k = 0; k < keyed.size(); ++k) {
+            tcull.list.push_back(keyed[k].second);
+            ++perContour[keyed[k].first.first];
         }
     }
-    tcull.cstart.push_back((int) tcull.list.size());
+    int at = 0;
+    for (int c = 0; c < nC; ++c) {                                            // the list is grouped by contour: offsets = running counts
+        tcull.cstart.push_back(at);
+        at += perContour[c];
+    }
+    tcull.cstart.push_back(at);
     return tcull;
 }
 
