@@ -620,7 +620,7 @@ k_ec_params(EcGlyphParams *out, BatchView batch, const MsdfHipGlyph *glyphs, Msd
 // the stencil byte [g][h][w] (native rows). Candidates whose verdict needs an exact shape-distance query are appended to `cands`
 // and judged by k_ec_query; a texel with a cheaply decided ERROR never needs them (the flag is an OR).
 #ifndef MSDF_EC_FAST_WAVES_PER_SIMD
-#define MSDF_EC_FAST_WAVES_PER_SIMD 8   // 64 VGPRs (6 spilled). Measured, ms per 8192 glyphs of the whole correction pass: 4-6 waves 1.83, 7 waves 1.77, 8 waves 1.75
+#define MSDF_EC_FAST_WAVES_PER_SIMD 7   // 72 VGPRs, no spills; the kernel's 5.6 KB of LDS allow 7 wavefronts per SIMD anyway. Correction pass on the distinct-glyph set: 8 -> 1.94 ms, 7 -> 1.90, 6 -> 1.90
 #endif
 // LDS of k_ec_fast per wavefront: 10x10 halo tile of the field | per-texel verdict words | item count | item queue (5.6 KB for msdf).
 enum { EC_HALO = TILE+2, EC_QUEUE_CAP = WAVE*24, EC_PROTECT_QUEUE_CAP = WAVE*8 };
