@@ -9,6 +9,11 @@ compare EVERY tile / texel of the device output against them (tests/test_gpu_ful
                    control-point bounds, and per glyph the sha256 of the reference's msdf 48x48 tile (autoframe, 4 px range,
                    library-default config = overlapping combiner + EDGE_PRIORITY / CHECK_DISTANCE_AT_EDGE error correction) and of
                    its msdf 64x64 tile (the bench workload re-frames the same glyphs at 64x64).
+  dejavu8192_modes.npz  the same 8 192 glyphs in the other three field types (round 3): per-glyph sha256[:16] of the reference's mtsdf 64x64
+                   (config 3's mode on the tail of a real font), sdf 48x48 and psdf 48x48 tiles, library-default config.
+  cjk512.npz       config 4's CJK-like stand-in: the 512 distinct shapes msdfgen_amd.synth.cjk_like_shape(20000..20511) (8-20 contours each:
+                   the only workload that takes the persistent global-scratch form of k_distance), msdf 48x48: per-shape sha256 of the
+                   reference's tile + a checksum of the generated outlines (the test regenerates them from the seeds).
   logo1024.npz     config 5: the 926-edge cubic logo (msdfgen_amd.synth.logo_shape(5)), msdf 1024x1024, 8 px range, default error
                    correction: sha256 of the texels and of the final stencil, per-row sha256 (to localise a mismatch), the
                    pre-correction field's sha256, a 64x64 crop of the texels and of the stencil, and the shape itself.
@@ -69,6 +74,36 @@ def dejavu(ref, threads):
         max(s.n_edges for s in shapes), max(s.n_contours for s in shapes)))
 
 
+def dejavu_modes(ref, threads):
+    """mtsdf / sdf / psdf on the 8 192 distinct glyphs of dejavu8192.npz (which must exist: same shapes, same framing)."""
+    z = np.load(os.path.join(GOLDEN, "dejavu8192.npz"))
+    batch = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
+                       z["colors"].astype(np.int32), np.zeros(len(z["names"]), bool), [str(n) for n in z["names"]])
+    shapes = [batch.shape(g) for g in range(batch.n_glyphs)]
+    out = {}
+    for tag, mode, size in (("mtsdf64", 4, 64), ("sdf48", 1, 48), ("psdf48", 2, 48)):
+        t0 = time.time()
+        tiles, _ = ref.generate_batch_timed(shapes, mode, size, size, z["xf%d" % size], threads=threads)
+        print("dejavu %s: %.1f s" % (tag, time.time()-t0), flush=True)
+        out["sha_"+tag] = np.stack([sha_bytes(t)[:16] for t in tiles])
+        out["sha_all_"+tag] = sha_bytes(tiles)
+        out["sample_"+tag] = tiles[::2048].copy()
+    np.savez_compressed(os.path.join(GOLDEN, "dejavu8192_modes.npz"), **out)
+
+
+def cjk(ref, threads):
+    base = [synth.cjk_like_shape(20000+i) for i in range(512)]
+    batch = ShapeBatch.from_shapes(base)
+    xfs = np.stack([autoframe(s.bounds(), 48, 48, 4) for s in base])
+    t0 = time.time()
+    tiles, _ = ref.generate_batch_timed(base, 3, 48, 48, xfs, threads=threads)
+    print("cjk-like msdf 48x48, 512 shapes: %.1f s" % (time.time()-t0), flush=True)
+    np.savez_compressed(os.path.join(GOLDEN, "cjk512.npz"), sha48=np.stack([sha_bytes(t) for t in tiles]), sha_all48=sha_bytes(tiles),
+                        sha_points=sha_bytes(batch.points), sha_xf=sha_bytes(xfs), n_edges=np.array(batch.n_edges), n_contours=np.array(batch.n_contours),
+                        sample48=tiles[::128].copy())
+    print("cjk512: %d contours, %d edges (%.1f / %.1f per glyph)" % (batch.n_contours, batch.n_edges, batch.n_contours/512, batch.n_edges/512))
+
+
 def logo(ref):
     """The reference's generateMSDF evaluates distances through ShapeDistanceFinder::distance(), whose per-edge cache
     (edge-selectors.cpp:64-79, DISTANCE_DELTA_FACTOR) prunes edges relative to the PREVIOUS texel of its serpentine walk; on this shape
@@ -102,6 +137,9 @@ def logo(ref):
                         n_error=np.array(int((stencil & 1).sum())),
                         cached_diff_yx=diff, cached_diff_values=np.stack([cached[y, x] for y, x in diff]) if len(diff) else np.zeros((0, 3), np.float32),
                         exact_values_there=np.stack([pre[y, x] for y, x in diff]) if len(diff) else np.zeros((0, 3), np.float32),
+                        sha_pre_cached_walk=sha_bytes(cached), sha_stencil_cached_walk=sha_bytes(st_cached),
+                        out_cached_diff_yx=np.argwhere((out.view(np.uint32) != out_cached.view(np.uint32)).any(axis=2)),
+                        out_cached_diff_values=out_cached[(out.view(np.uint32) != out_cached.view(np.uint32)).any(axis=2)],
                         sha_out_cached_walk=sha_bytes(out_cached), n_out_differs_from_cached_walk=np.array(int((out.view(np.uint32) != out_cached.view(np.uint32)).any(axis=2).sum())))
     print("logo1024: %d ERROR texels; final bitmap differs from the cached walk's at %d texel(s)" % (
         int((stencil & 1).sum()), int((out.view(np.uint32) != out_cached.view(np.uint32)).any(axis=2).sum())))
@@ -115,9 +153,13 @@ def main():
     ref = Ref()
     if args.only in ("", "dejavu"):
         dejavu(ref, args.threads)
+    if args.only in ("", "modes"):
+        dejavu_modes(ref, args.threads)
+    if args.only in ("", "cjk"):
+        cjk(ref, args.threads)
     if args.only in ("", "logo"):
         logo(ref)
-    for f in ("dejavu8192.npz", "logo1024.npz"):
+    for f in ("dejavu8192.npz", "dejavu8192_modes.npz", "cjk512.npz", "logo1024.npz"):
         p = os.path.join(GOLDEN, f)
         if os.path.exists(p):
             print("%-16s %8d bytes" % (f, os.path.getsize(p)))
