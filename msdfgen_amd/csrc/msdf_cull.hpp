@@ -24,7 +24,7 @@ namespace msdfhip {
 
 // Upper bound of the distance from c to edge e: the nearest of three on-curve points (both ends and point(0.5)).
 MSDF_HD double cullUpperDistance(const EdgeRec &e, V2 c) {
-    const V2 a = c-ld(e.p), b = c-endPoint(e), m = c-ld(e.mid);
+    const V2 a = c-ld(e.p0), b = c-ld(e.pe), m = c-ld(e.mid);
     const double da = dot(a, a), db = dot(b, b), dm = dot(m, m);
     return sqrt(dmin(dmin(da, db), dm));
 }
@@ -44,11 +44,11 @@ MSDF_HD bool cullEdgeSurvives(const EdgeRec &e, V2 c, double r, double Umax) {
     if (!(cullLowerDistance(e, c)-R > reach))
         return true;
     if (PERP) {
-        const V2 ap = c-ld(e.p), aDir = ld(e.aDirN);
+        const V2 ap = c-ld(e.p0), aDir = ld(e.aDirN);
         const bool outsideA = dot(ap, ld(e.na))+R <= 0 || -dot(ap, aDir)+R <= 0;   // add <= 0 or ts <= 0 on the whole tile
         if (!outsideA && !(fabs(cross(ap, aDir))-R > reach))
             return true;
-        const V2 bp = c-endPoint(e), bDir = ld(e.bDirN);
+        const V2 bp = c-ld(e.pe), bDir = ld(e.bDirN);
         const bool outsideB = -dot(bp, ld(e.nb))+R <= 0 || dot(bp, bDir)+R <= 0;    // bdd <= 0 or ts <= 0 on the whole tile
         if (!outsideB && !(fabs(cross(bp, bDir))-R > reach))
             return true;
@@ -61,7 +61,7 @@ MSDF_HD bool cullEdgeSurvives(const EdgeRec &e, V2 c, double r, double Umax) {
 // from the tile centre to the nearest of three on-curve points, as non-negative float bits with the low four mantissa bits replaced
 // by the edge's position within its group of 16 (keys are then unique within a group: a plain rank is a permutation).
 MSDF_HD unsigned cullOrderKey(const EdgeRec &e, V2 c, int slot) {
-    const V2 a = c-ld(e.p), b = c-endPoint(e), m = c-ld(e.mid);
+    const V2 a = c-ld(e.p0), b = c-ld(e.pe), m = c-ld(e.mid);
     const float d2 = (float) dmin(dmin(dot(a, a), dot(b, b)), dot(m, m));
     unsigned bits;
     memcpy(&bits, &d2, sizeof(bits));

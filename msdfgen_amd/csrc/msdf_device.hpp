@@ -10,6 +10,7 @@
 #pragma once
 
 #include <stdint.h>
+#include <stddef.h>
 #include <math.h>
 #include <float.h>
 
@@ -43,34 +44,66 @@ enum : int32_t {
     REC_FASTDIV = 16  // every pixel-independent divisor of this edge has an exactly usable reciprocal in rcp[] (see divExact)
 };
 
-struct alignas(16) EdgeRec {
-    double p[8];      // control points p0..p3
+struct V2 { double x, y; };
+
+// Laid out in 64-byte BLOCKS, in the order the per-texel walk needs them, so that a wavefront fetches what one edge evaluation reads
+// with a few wide scalar loads issued together (msdf_kernels.hpp: EdgeRegs) instead of one dependent round trip per field:
+//   R  (0x000, 128 B)  everything the per-texel relevance test and the selector's end-point logic read: control box, first / last
+//                      control point, corner bisectors, normalised end tangents
+//   E0 (0x080,  64 B)  ab + the per-type scalars k[]: a LINEAR edge is complete with R + E0
+//   E1 (0x0c0,  64 B)  br, end tangents and their squared norms          (quadratic, cubic)
+//   E2 (0x100,  64 B)  reciprocals, first interior control point, as     (quadratic, cubic)
+//   T  (0x140,  64 B)  what only phase 1 / the scanline pass / the digest read: second interior control point, on-curve sample, ids
+struct alignas(128) EdgeRec {
+    // ---- R
+    double lo[2];     // bounding box of the control points (tile culling, per-texel relevance)
+    double hi[2];
+    double p0[2];     // first control point
+    double pe[2];     // LAST control point = point(1) (p1 / p2 / p3 for linear / quadratic / cubic)
+    double na[2];     // (prevDirN+aDirN).normalize(true)   (edge-selectors.cpp:197)
+    double nb[2];     // (bDirN+nextDirN).normalize(true)   (edge-selectors.cpp:198)
+    double aDirN[2];  // direction(0).normalize(true)       (edge-selectors.cpp:193)
+    double bDirN[2];  // direction(1).normalize(true)       (edge-selectors.cpp:194)
+    // ---- E0
     double ab[2];     // p1-p0
+    double k[6];      // linear:    abab, orthoN.x, orthoN.y, abN.x, abN.y, RN(1/abab)
+                      // quadratic: a, b, 2*dot(ab,ab), b/a, (b/a)^2, (b/a)*(1/3.)
+                      // cubic:     3*ab.x, 3*ab.y, 6*br.x, 6*br.y
+    // ---- E1
     double br[2];     // (p2-p1)-ab                         (quadratic, cubic)
-    double as_[2];    // ((p3-p2)-(p2-p1))-br               (cubic)
     double ep0[2];    // direction(0)                       (edge-segments.cpp:121-139)
     double ep1[2];    // direction(1)
     double e0dot;     // dot(ep0, ep0)
     double e1dot;     // dot(ep1, ep1)
-    double aDirN[2];  // direction(0).normalize(true)       (edge-selectors.cpp:193)
-    double bDirN[2];  // direction(1).normalize(true)       (edge-selectors.cpp:194)
-    double na[2];     // (prevDirN+aDirN).normalize(true)   (edge-selectors.cpp:197)
-    double nb[2];     // (bDirN+nextDirN).normalize(true)   (edge-selectors.cpp:198)
-    double k[6];      // linear:    abab, orthoN.x, orthoN.y, abN.x, abN.y
-                      // quadratic: a, b, 2*dot(ab,ab), b/a, (b/a)^2, (b/a)*(1/3.)
-                      // cubic:     3*ab.x, 3*ab.y, 6*br.x, 6*br.y
-    double lo[2];     // bounding box of the control points (tile culling only, msdf_cull.hpp)
-    double hi[2];
+    // ---- E2
+    double rcp[4];    // RN(1/divisor) of the pixel-independent divisors: quadratic {a, e0dot, e1dot}; cubic {-, e0dot, e1dot}  (linear: k[5])
+    double p1[2];     // second control point (quadratic, cubic)
+    double as_[2];    // ((p3-p2)-(p2-p1))-br               (cubic)
+    // ---- T
+    double p2[2];     // third control point of a cubic (scanline pass, digest)
     double mid[2];    // point(0.5): an on-curve sample (tile culling only)
-    double rcp[4];    // RN(1/divisor) of the pixel-independent divisors: linear {ab.ab}; quadratic {a, e0dot, e1dot}; cubic {-, e0dot, e1dot}
     int32_t type;     // 1, 2, 3
     int32_t color;    // EdgeColor bitmask
     int32_t flags;    // REC_*
     int32_t contour;  // contour index within the batch
-};
-static_assert(sizeof(EdgeRec) == 368, "EdgeRec layout");
+    double pad_[2];
 
-struct V2 { double x, y; };
+    // Accessors: the per-texel math below is written against these, so that it runs unchanged on a record in memory (this struct:
+    // the loads happen where the compiler puts them) and on a record held in scalar registers (msdf_kernels.hpp: EdgeRegs).
+    MSDF_HD V2 Lo() const; MSDF_HD V2 Hi() const; MSDF_HD V2 P0() const; MSDF_HD V2 PE() const; MSDF_HD V2 P1() const;
+    MSDF_HD V2 NA() const; MSDF_HD V2 NB() const; MSDF_HD V2 ADirN() const; MSDF_HD V2 BDirN() const;
+    MSDF_HD V2 AB() const; MSDF_HD V2 BR() const; MSDF_HD V2 AS() const; MSDF_HD V2 EP0() const; MSDF_HD V2 EP1() const;
+    MSDF_HD double E0dot() const { return e0dot; }
+    MSDF_HD double E1dot() const { return e1dot; }
+    MSDF_HD double K(int i) const { return k[i]; }
+    MSDF_HD double Rcp(int i) const { return rcp[i]; }
+    MSDF_HD int Type() const { return type; }
+    MSDF_HD int Color() const { return color; }
+    MSDF_HD int Flags() const { return flags; }
+};
+static_assert(sizeof(EdgeRec) == 384, "EdgeRec layout");
+static_assert(offsetof(EdgeRec, na) == 0x40 && offsetof(EdgeRec, ab) == 0x80 && offsetof(EdgeRec, br) == 0xc0 && offsetof(EdgeRec, rcp) == 0x100 &&
+              offsetof(EdgeRec, p2) == 0x140 && offsetof(EdgeRec, type) == 0x160, "EdgeRec blocks");
 
 MSDF_HD V2 mk(double x, double y) { V2 r; r.x = x; r.y = y; return r; }
 MSDF_HD V2 operator+(V2 a, V2 b) { return mk(a.x+b.x, a.y+b.y); }
@@ -81,6 +114,20 @@ MSDF_HD double dot(V2 a, V2 b) { return a.x*b.x+a.y*b.y; }
 MSDF_HD double cross(V2 a, V2 b) { return a.x*b.y-a.y*b.x; }
 MSDF_HD double vlen(V2 a) { return sqrt(a.x*a.x+a.y*a.y); }
 MSDF_HD V2 ld(const double *p) { return mk(p[0], p[1]); }
+MSDF_HD V2 EdgeRec::Lo() const { return ld(lo); }
+MSDF_HD V2 EdgeRec::Hi() const { return ld(hi); }
+MSDF_HD V2 EdgeRec::P0() const { return ld(p0); }
+MSDF_HD V2 EdgeRec::PE() const { return ld(pe); }
+MSDF_HD V2 EdgeRec::P1() const { return ld(p1); }
+MSDF_HD V2 EdgeRec::NA() const { return ld(na); }
+MSDF_HD V2 EdgeRec::NB() const { return ld(nb); }
+MSDF_HD V2 EdgeRec::ADirN() const { return ld(aDirN); }
+MSDF_HD V2 EdgeRec::BDirN() const { return ld(bDirN); }
+MSDF_HD V2 EdgeRec::AB() const { return ld(ab); }
+MSDF_HD V2 EdgeRec::BR() const { return ld(br); }
+MSDF_HD V2 EdgeRec::AS() const { return ld(as_); }
+MSDF_HD V2 EdgeRec::EP0() const { return ld(ep0); }
+MSDF_HD V2 EdgeRec::EP1() const { return ld(ep1); }
 
 MSDF_HD V2 normalize(V2 a, bool allowZero) {                                 // Vector2.hpp:42-46
     double len = vlen(a);
@@ -296,23 +343,23 @@ MSDF_HD bool sdLess(SD a, SD b) {                                            // 
     return fabs(a.d) < fabs(b.d) || (fabs(a.d) == fabs(b.d) && a.dot < b.dot);
 }
 
-MSDF_HD V2 dirN0(const EdgeRec &e) { return (e.flags&REC_A_ZERO) ? mk(0, 1) : ld(e.aDirN); } // direction(0).normalize()
-MSDF_HD V2 dirN1(const EdgeRec &e) { return (e.flags&REC_B_ZERO) ? mk(0, 1) : ld(e.bDirN); } // direction(1).normalize()
+template <class Rec> MSDF_HD V2 dirN0(const Rec &e) { return (e.Flags()&REC_A_ZERO) ? mk(0, 1) : e.ADirN(); } // direction(0).normalize()
+template <class Rec> MSDF_HD V2 dirN1(const Rec &e) { return (e.Flags()&REC_B_ZERO) ? mk(0, 1) : e.BDirN(); } // direction(1).normalize()
 
-MSDF_HD SD sdLinear(const EdgeRec &e, V2 o, double &param) {                 // edge-segments.cpp:173-185
-    V2 p0 = ld(e.p), p1 = ld(e.p+2), ab = ld(e.ab);
+template <class Rec> MSDF_HD SD sdLinear(const Rec &e, V2 o, double &param) {                 // edge-segments.cpp:173-185
+    V2 p0 = e.P0(), p1 = e.PE(), ab = e.AB();
     V2 aq = o-p0;
-    param = (e.flags&REC_FASTDIV) ? divExact(dot(aq, ab), e.k[0], e.rcp[0]) : dot(aq, ab)/e.k[0];
+    param = (e.Flags()&REC_FASTDIV) ? divExact(dot(aq, ab), e.K(0), e.K(5)) : dot(aq, ab)/e.K(0);
     V2 eq = (param > .5 ? p1 : p0)-o;
     double endpointDistance = vlen(eq);
     if (param > 0 && param < 1) {
-        double orthoDistance = dot(mk(e.k[1], e.k[2]), aq);
+        double orthoDistance = dot(mk(e.K(1), e.K(2)), aq);
         if (fabs(orthoDistance) < endpointDistance) {
             SD r = { orthoDistance, 0 };
             return r;
         }
     }
-    SD r = { nonZeroSign(cross(aq, ab))*endpointDistance, fabs(dot(mk(e.k[3], e.k[4]), normalize(eq, false))) };
+    SD r = { nonZeroSign(cross(aq, ab))*endpointDistance, fabs(dot(mk(e.K(3), e.K(4)), normalize(eq, false))) };
     return r;
 }
 
@@ -328,22 +375,22 @@ MSDF_HD double cosThirdsOne(double t, int i) {
 #endif
 }
 
-MSDF_HD SD sdQuadratic(const EdgeRec &e, V2 o, double &param) {              // edge-segments.cpp:187-226
-    V2 p0 = ld(e.p), p1 = ld(e.p+2), p2 = ld(e.p+4), ab = ld(e.ab), br = ld(e.br);
+template <class Rec> MSDF_HD SD sdQuadratic(const Rec &e, V2 o, double &param) {              // edge-segments.cpp:187-226
+    V2 p0 = e.P0(), p1 = e.P1(), p2 = e.PE(), ab = e.AB(), br = e.BR();
     V2 qa = p0-o;
-    const bool fast = (e.flags&REC_FASTDIV) != 0;
+    const bool fast = (e.Flags()&REC_FASTDIV) != 0;
 
     // solveCubic (equation-solver.cpp:63-70) up to the point where the roots are formed; the roots themselves follow lazily below
     double x0 = 0, x1 = 0, trigT = 0, trigQ = 0;
     int solutions;
     bool trig = false;
     {
-        const double c = e.k[2]+dot(qa, br);
+        const double c = e.K(2)+dot(qa, br);
         const double d = dot(qa, ab);
-        if (e.flags&REC_NORMED) {                                             // solveCubicNormed, equation-solver.cpp:34-61 (a, a*a, a/3 from the record)
-            const double b = fast ? divExact(c, e.k[0], e.rcp[0]) : c/e.k[0];
-            const double cc = fast ? divExact(d, e.k[0], e.rcp[0]) : d/e.k[0];
-            const double a = e.k[3], a2 = e.k[4];
+        if (e.Flags()&REC_NORMED) {                                             // solveCubicNormed, equation-solver.cpp:34-61 (a, a*a, a/3 from the record)
+            const double b = fast ? divExact(c, e.K(0), e.Rcp(0)) : c/e.K(0);
+            const double cc = fast ? divExact(d, e.K(0), e.Rcp(0)) : d/e.K(0);
+            const double a = e.K(3), a2 = e.K(4);
             double q = 1/9.*(a2-3*b);
             const double r = 1/54.*(a*(2*a2-9*b)+27*cc);
             const double r2 = r*r;
@@ -359,36 +406,36 @@ MSDF_HD SD sdQuadratic(const EdgeRec &e, V2 o, double &param) {              // 
             } else {
                 const double u = (r < 0 ? 1. : -1.)*powThird(fabs(r)+sqrt(r2-q3));
                 const double v = u == 0 ? 0 : q/u;
-                x0 = (u+v)-e.k[5];
+                x0 = (u+v)-e.K(5);
                 solutions = 1;
                 if (u == v || fabs(u-v) < 1e-12*fabs(u+v)) {
-                    x1 = -.5*(u+v)-e.k[5];
+                    x1 = -.5*(u+v)-e.K(5);
                     solutions = 2;
                 }
             }
         } else {
             double t[2] = { 0, 0 };
-            solutions = solveQuadratic(t, e.k[1], c, d);
+            solutions = solveQuadratic(t, e.K(1), c, d);
             x0 = t[0], x1 = t[1];
         }
     }
 
-    V2 epDir = ld(e.ep0);
+    V2 epDir = e.EP0();
     double minDistance = nonZeroSign(cross(epDir, qa))*vlen(qa);
-    param = fast ? divExact(-dot(qa, epDir), e.e0dot, e.rcp[1]) : -dot(qa, epDir)/e.e0dot;
+    param = fast ? divExact(-dot(qa, epDir), e.E0dot(), e.Rcp(1)) : -dot(qa, epDir)/e.E0dot();
     {
         V2 qb = p2-o;
         double distance = vlen(qb);
         if (distance < fabs(minDistance)) {
-            epDir = ld(e.ep1);
+            epDir = e.EP1();
             minDistance = nonZeroSign(cross(epDir, qb))*distance;
-            param = fast ? divExact(dot(o-p1, epDir), e.e1dot, e.rcp[2]) : dot(o-p1, epDir)/e.e1dot;
+            param = fast ? divExact(dot(o-p1, epDir), e.E1dot(), e.Rcp(2)) : dot(o-p1, epDir)/e.E1dot();
         }
     }
     MSDF_NOUNROLL
     for (int i = 0; i < 3; ++i) {
         if (i < solutions) {
-            const double ti = trig ? trigQ*cosThirdsOne(trigT, i)-e.k[5] : i == 0 ? x0 : x1;
+            const double ti = trig ? trigQ*cosThirdsOne(trigT, i)-e.K(5) : i == 0 ? x0 : x1;
             if (ti > 0 && ti < 1) {
                 V2 qe = qa+(2*ti)*ab+(ti*ti)*br;
                 double distance = vlen(qe);
@@ -410,21 +457,21 @@ MSDF_HD SD sdQuadratic(const EdgeRec &e, V2 o, double &param) {              // 
     return r;
 }
 
-MSDF_HD SD sdCubic(const EdgeRec &e, V2 o, double &param) {                  // edge-segments.cpp:228-277
-    V2 p0 = ld(e.p), p3 = ld(e.p+6), ab = ld(e.ab), br = ld(e.br), as = ld(e.as_);
-    V2 ab3 = mk(e.k[0], e.k[1]), br6 = mk(e.k[2], e.k[3]);
+template <class Rec> MSDF_HD SD sdCubic(const Rec &e, V2 o, double &param) {                  // edge-segments.cpp:228-277
+    V2 p0 = e.P0(), p3 = e.PE(), ab = e.AB(), br = e.BR(), as = e.AS();
+    V2 ab3 = mk(e.K(0), e.K(1)), br6 = mk(e.K(2), e.K(3));
     V2 qa = p0-o;
-    const bool fast = (e.flags&REC_FASTDIV) != 0;
-    V2 epDir = ld(e.ep0);
+    const bool fast = (e.Flags()&REC_FASTDIV) != 0;
+    V2 epDir = e.EP0();
     double minDistance = nonZeroSign(cross(epDir, qa))*vlen(qa);
-    param = fast ? divExact(-dot(qa, epDir), e.e0dot, e.rcp[1]) : -dot(qa, epDir)/e.e0dot;
+    param = fast ? divExact(-dot(qa, epDir), e.E0dot(), e.Rcp(1)) : -dot(qa, epDir)/e.E0dot();
     {
         V2 qb = p3-o;
         double distance = vlen(qb);
         if (distance < fabs(minDistance)) {
-            epDir = ld(e.ep1);
+            epDir = e.EP1();
             minDistance = nonZeroSign(cross(epDir, qb))*distance;
-            param = fast ? divExact(dot(epDir-qb, epDir), e.e1dot, e.rcp[2]) : dot(epDir-qb, epDir)/e.e1dot;
+            param = fast ? divExact(dot(epDir-qb, epDir), e.E1dot(), e.Rcp(2)) : dot(epDir-qb, epDir)/e.E1dot();
         }
     }
     for (int i = 0; i <= 4; ++i) {                                            // MSDFGEN_CUBIC_SEARCH_STARTS, edge-segments.h:11
@@ -462,26 +509,25 @@ MSDF_HD SD sdCubic(const EdgeRec &e, V2 o, double &param) {                  // 
     return r;
 }
 
-MSDF_HD SD signedDistance(const EdgeRec &e, V2 o, double &param) {
+template <class Rec> MSDF_HD SD signedDistance(const Rec &e, V2 o, double &param) {
 #if defined(MSDF_ONLY_TYPE)
     if (MSDF_ONLY_TYPE == 1) return sdLinear(e, o, param);
     if (MSDF_ONLY_TYPE == 2) return sdQuadratic(e, o, param);
     if (MSDF_ONLY_TYPE == 3) return sdCubic(e, o, param);
 #endif
-    if (e.type == 1)
+    if (e.Type() == 1)
         return sdLinear(e, o, param);
-    if (e.type == 2)
+    if (e.Type() == 2)
         return sdQuadratic(e, o, param);
     return sdCubic(e, o, param);
 }
 
-MSDF_HD V2 endPoint(const EdgeRec &e) { return ld(e.p+2*e.type); }           // point(1) == last control point
 
 // EdgeSegment::distanceToPerpendicularDistance, edge-segments.cpp:28-52
-MSDF_HD void distanceToPerpendicular(const EdgeRec &e, SD &distance, V2 o, double param) {
+template <class Rec> MSDF_HD void distanceToPerpendicular(const Rec &e, SD &distance, V2 o, double param) {
     if (param < 0) {
         V2 dir = dirN0(e);
-        V2 aq = o-ld(e.p);
+        V2 aq = o-e.P0();
         double ts = dot(aq, dir);
         if (ts < 0) {
             double perp = cross(aq, dir);
@@ -492,7 +538,7 @@ MSDF_HD void distanceToPerpendicular(const EdgeRec &e, SD &distance, V2 o, doubl
         }
     } else if (param > 1) {
         V2 dir = dirN1(e);
-        V2 bq = o-endPoint(e);
+        V2 bq = o-e.PE();
         double ts = dot(bq, dir);
         if (ts > 0) {
             double perp = cross(bq, dir);
@@ -598,8 +644,8 @@ MSDF_HD bool sdReplaces(SD sd, int idx, SD cur, int curIdx) {
 }
 
 // addEdge: edge-selectors.cpp:19-29 (true), :129-160 (perpendicular), :174-227 (multi)
-template <int SEL>
-MSDF_HD void selAddEdge(Selector<SEL> &s, const EdgeRec &e, int idx, V2 o) {
+template <int SEL, class Rec>
+MSDF_HD void selAddEdge(Selector<SEL> &s, const Rec &e, int idx, V2 o) {
     if (SEL == 1) {
         double dummy;
         SD sd = signedDistance(e, o, dummy);
@@ -607,7 +653,7 @@ MSDF_HD void selAddEdge(Selector<SEL> &s, const EdgeRec &e, int idx, V2 o) {
             s.m = sd, s.idx[0] = idx;
         return;
     }
-    const int mask = SEL == 2 ? 1 : (e.color&7);
+    const int mask = SEL == 2 ? 1 : (e.Color()&7);
     if (!mask)
         return;                                  // MultiDistanceSelector ignores BLACK edges (edge-selectors.cpp:175-179)
     double param;
@@ -626,13 +672,13 @@ MSDF_HD void selAddEdge(Selector<SEL> &s, const EdgeRec &e, int idx, V2 o) {
             if (nearer[i])
                 s.c[i].td = sd.d, s.c[i].tdot = sd.dot, s.c[i].perp = conv.d, s.idx[i] = idx;
     }
-    V2 ap = o-ld(e.p);
-    V2 bp = o-endPoint(e);
-    double add = dot(ap, ld(e.na));
-    double bdd = -dot(bp, ld(e.nb));
+    V2 ap = o-e.P0();
+    V2 bp = o-e.PE();
+    double add = dot(ap, e.NA());
+    double bdd = -dot(bp, e.NB());
     if (add > 0) {
         double pd = sd.d;
-        if (getPerpendicularDistance(pd, ap, -ld(e.aDirN))) {
+        if (getPerpendicularDistance(pd, ap, -e.ADirN())) {
             pd = -pd;
             for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
                 if (mask&(1<<i))
@@ -641,7 +687,7 @@ MSDF_HD void selAddEdge(Selector<SEL> &s, const EdgeRec &e, int idx, V2 o) {
     }
     if (bdd > 0) {
         double pd = sd.d;
-        if (getPerpendicularDistance(pd, bp, ld(e.bDirN))) {
+        if (getPerpendicularDistance(pd, bp, e.BDirN())) {
             for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
                 if (mask&(1<<i))
                     pbAddPerp(s.c[i], pd);
@@ -657,13 +703,13 @@ MSDF_HD void selAddEdge(Selector<SEL> &s, const EdgeRec &e, int idx, V2 o) {
 //    values) or the perpendicular distance exceeds that bound, in which case it cannot survive computeDistance()/merge() because
 //    the nearest edge's own (pseudo-)distance is smaller (see msdf_cull.hpp).
 // The kernel evaluates the edge if ANY lane of the wavefront needs it (wave-uniform control flow); evaluating more is harmless.
-template <int SEL>
-MSDF_HD bool selEdgeRelevant(const Selector<SEL> &s, const EdgeRec &e, V2 o) {
+template <int SEL, class Rec>
+MSDF_HD bool selEdgeRelevant(const Selector<SEL> &s, const Rec &e, V2 o) {
     double bound2;                                   // squared bound, inflated
     if (SEL == 1)
         bound2 = s.m.d*s.m.d;
     else {
-        const int mask = SEL == 2 ? 1 : (e.color&7);
+        const int mask = SEL == 2 ? 1 : (e.Color()&7);
         if (!mask)
             return false;
         bound2 = 0;
@@ -672,19 +718,19 @@ MSDF_HD bool selEdgeRelevant(const Selector<SEL> &s, const EdgeRec &e, V2 o) {
                 bound2 = dmax(bound2, s.c[i].td*s.c[i].td);
     }
     bound2 *= 1+1e-9;                                // (-DBL_MAX)^2 = inf: nothing is skipped until a channel has a candidate
-    const double dx = dmax(dmax(e.lo[0]-o.x, o.x-e.hi[0]), 0.);
-    const double dy = dmax(dmax(e.lo[1]-o.y, o.y-e.hi[1]), 0.);
+    const double dx = dmax(dmax(e.Lo().x-o.x, o.x-e.Hi().x), 0.);
+    const double dy = dmax(dmax(e.Lo().y-o.y, o.y-e.Hi().y), 0.);
     if (!(dx*dx+dy*dy > bound2))
         return true;
     if (SEL >= 2) {
-        const V2 ap = o-ld(e.p), aDir = ld(e.aDirN);
-        if (dot(ap, ld(e.na)) > 0 && dot(ap, -aDir) > 0) {             // add > 0 && ts > 0 (edge-selectors.cpp:199-202, :43-44)
+        const V2 ap = o-e.P0(), aDir = e.ADirN();
+        if (dot(ap, e.NA()) > 0 && dot(ap, -aDir) > 0) {             // add > 0 && ts > 0 (edge-selectors.cpp:199-202, :43-44)
             const double perp = cross(ap, aDir);
             if (!(perp*perp > bound2))
                 return true;
         }
-        const V2 bp = o-endPoint(e), bDir = ld(e.bDirN);
-        if (-dot(bp, ld(e.nb)) > 0 && dot(bp, bDir) > 0) {             // bdd > 0 && ts > 0 (:212-215)
+        const V2 bp = o-e.PE(), bDir = e.BDirN();
+        if (-dot(bp, e.NB()) > 0 && dot(bp, bDir) > 0) {             // bdd > 0 && ts > 0 (:212-215)
             const double perp = cross(bp, bDir);
             if (!(perp*perp > bound2))
                 return true;
@@ -758,7 +804,7 @@ struct EdgesCulled {                    // survivors of the per-tile cull (msdf_
     const int *list;                    // record index per position, or NULL if the surviving records were copied in this order
     MSDF_HD int begin(int c) const { return MSDF_UNIFORM(cstart[c]); }
     MSDF_HD int end(int c) const { return MSDF_UNIFORM(cstart[c+1]); }
-    MSDF_HD int at(int k) const { return list ? MSDF_UNIFORM(list[k]) : k; }   // uniform index -> scalar loads of the record
+    MSDF_HD int at(int k) const { return list ? MSDF_UNIFORM(list[k])&0xfffff : k; }   // uniform index -> scalar loads of the record (entries are packed: msdf_kernels.hpp)
 };
 
 // Feeds contour c's edges to the selector, in visit order (ShapeDistanceFinder.hpp:45-57). The default walks them one after the

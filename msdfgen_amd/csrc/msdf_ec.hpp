@@ -314,7 +314,7 @@ MSDF_HD bool texelHasError(const SdfView &sdf, const EcParams &p, int x, int y, 
 MSDF_HD bool protectedByCorners(const EdgeRec *rec, int nE, const Xform &t, int x, int ys) {
     for (int i = 0; i < nE; ++i)
         if (rec[i].flags&REC_CORNER) {
-            V2 pp = project(t, ld(rec[i].p));
+            V2 pp = project(t, ld(rec[i].p0));
             int l = (int) floor(pp.x-.5);
             int b = (int) floor(pp.y-.5);
             if ((x == l || x == l+1) && (ys == b || ys == b+1))

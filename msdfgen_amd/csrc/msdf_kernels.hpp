@@ -200,6 +200,109 @@ __device__ inline int rowRank(unsigned key) {
     return rank;
 }
 
+// ---- survivor records in SCALAR REGISTERS ---------------------------------------------------------------------------------------
+// Phase 2 walks a tile's survivor list with wave-uniform record reads. Left to the compiler, every field of a record is loaded where it
+// is first used: one DEPENDENT scalar-cache round trip per field group -- flags, control box, p0 + bisector, tangent, type, ... about ten
+// per evaluated edge, a third of them missing the 16 KB scalar cache (profiles/r02_scalar_cache.txt) -- and a wavefront spent 44 % of its
+// life in s_waitcnt. Here the walk is laid out by hand instead:
+//   * the survivor list holds PACKED entries (record index | type | colour | flags): nothing has to be loaded to know what an edge is;
+//   * EdgeRec is stored in 64-byte blocks in the order of use (msdf_device.hpp); the relevance test + a whole linear evaluation need
+//     R + E0 = three s_load_dwordx16, issued together with the LDS read of the NEXT list entry and waited for ONCE;
+//   * right after that wait, the lines of the next survivor's record are requested into a dummy register and NOT waited for: by the time
+//     the walk gets there (a relevance test or a full evaluation later) they sit in the scalar cache;
+//   * a curve fetches E1 + E2 after the wave vote said the edge matters (second round trip, cache-warm).
+// SMEM returns out of order, so the only usable wait is lgkmcnt(0): every asm statement that issues loads it needs ends with one, and the
+// prefetch's dummy destination is threaded through the next such statement ("+s") so that the register stays allocated until then.
+typedef double d8 __attribute__((ext_vector_type(8)));
+
+enum { ENTRY_INDEX_BITS = 20, ENTRY_INDEX_MASK = (1<<ENTRY_INDEX_BITS)-1 };   // 1 M edges per glyph (the LDS lists hold far fewer)
+__device__ inline unsigned packEntry(int i, const EdgeRec &e) {
+    return (unsigned) i|(unsigned) e.type<<20|(unsigned) (e.color&7)<<22|(unsigned) (e.flags&7)<<25|(unsigned) ((e.flags>>4)&1)<<28;
+}
+
+struct EdgeRegs {
+    d8 r0, r1, e0, e1, e2;              // blocks R (two halves), E0, E1, E2 of EdgeRec
+    unsigned meta;                      // the packed list entry
+    __device__ V2 Lo() const { return mk(r0[0], r0[1]); }
+    __device__ V2 Hi() const { return mk(r0[2], r0[3]); }
+    __device__ V2 P0() const { return mk(r0[4], r0[5]); }
+    __device__ V2 PE() const { return mk(r0[6], r0[7]); }
+    __device__ V2 NA() const { return mk(r1[0], r1[1]); }
+    __device__ V2 NB() const { return mk(r1[2], r1[3]); }
+    __device__ V2 ADirN() const { return mk(r1[4], r1[5]); }
+    __device__ V2 BDirN() const { return mk(r1[6], r1[7]); }
+    __device__ V2 AB() const { return mk(e0[0], e0[1]); }
+    __device__ double K(int i) const { return e0[2+i]; }
+    __device__ V2 BR() const { return mk(e1[0], e1[1]); }
+    __device__ V2 EP0() const { return mk(e1[2], e1[3]); }
+    __device__ V2 EP1() const { return mk(e1[4], e1[5]); }
+    __device__ double E0dot() const { return e1[6]; }
+    __device__ double E1dot() const { return e1[7]; }
+    __device__ double Rcp(int i) const { return e2[i]; }
+    __device__ V2 P1() const { return mk(e2[4], e2[5]); }
+    __device__ V2 AS() const { return mk(e2[6], e2[7]); }
+    __device__ int Type() const { return (int) (meta>>20)&3; }
+    __device__ int Color() const { return (int) (meta>>22)&7; }
+    __device__ int Flags() const { return (int) ((meta>>25)&7)|(int) ((meta>>28)&1)<<4; }
+};
+static_assert(REC_A_ZERO == 1 && REC_B_ZERO == 2 && REC_NORMED == 4 && REC_FASTDIV == 16, "packEntry / EdgeRegs::Flags");
+
+struct EdgesCulledPacked {              // survivors of the per-tile cull as packed entries, grouped by contour, nearest-first within a row
+    const int *cstart;                  // C+1 compacted offsets
+    const int *list;                    // packed entries (LDS)
+    int total;                          // cstart[C]
+    __device__ int begin(int c) const { return MSDF_UNIFORM(cstart[c]); }
+    __device__ int end(int c) const { return MSDF_UNIFORM(cstart[c+1]); }
+};
+
+template <int SEL>
+__device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, const EdgesCulledPacked &edges, int c, V2 o) {
+    const int e = edges.end(c);
+    int k = edges.begin(c);
+    if (k >= e)
+        return;
+    unsigned cur = (unsigned) MSDF_UNIFORM(edges.list[k]);
+    int pf = 0;                                                     // dummy destination of the prefetch loads (never read)
+    MSDF_NOUNROLL
+    for (; k < e; ++k) {
+        const EdgeRec *rp = rec+(cur&ENTRY_INDEX_MASK);
+        EdgeRegs r;
+        r.meta = cur;
+        unsigned nextV;
+        const unsigned nextAddr = (unsigned) (size_t) (edges.list+k+1);       // LDS byte address (low half of the flat address)
+#if defined(MSDF_EAGER_CURVES)                                      // A/B only: a curve's E1 + E2 with the first batch (one round trip, 80 SGPRs)
+        if (r.Type() >= 2)
+            asm volatile("ds_read_b32 %0, %7\n\ts_load_dwordx16 %1, %8, 0x0\n\ts_load_dwordx16 %2, %8, 0x40\n\ts_load_dwordx16 %3, %8, 0x80\n\t"
+                         "s_load_dwordx16 %4, %8, 0xc0\n\ts_load_dwordx16 %5, %8, 0x100\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(nextV), "=&s"(r.r0), "=&s"(r.r1), "=&s"(r.e0), "=&s"(r.e1), "=&s"(r.e2), "+s"(pf) : "v"(nextAddr), "s"(rp));
+        else
+#endif
+        asm volatile("ds_read_b32 %0, %5\n\ts_load_dwordx16 %1, %6, 0x0\n\ts_load_dwordx16 %2, %6, 0x40\n\ts_load_dwordx16 %3, %6, 0x80\n\ts_waitcnt lgkmcnt(0)"
+                     : "=v"(nextV), "=&s"(r.r0), "=&s"(r.r1), "=&s"(r.e0), "+s"(pf) : "v"(nextAddr), "s"(rp));
+        // the next survivor (of this contour, or the first of the next one): warm its record's lines, no wait
+        const unsigned next = k+1 < edges.total ? (unsigned) __builtin_amdgcn_readfirstlane((int) nextV) : cur;
+        const EdgeRec *np = rec+(next&ENTRY_INDEX_MASK);
+#if !defined(MSDF_NO_PREFETCH)                                     // (A/B switch)
+        if (((next>>20)&3) >= 2)
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\ts_load_dword %0, %1, 0xc0\n\ts_load_dword %0, %1, 0x100"
+                         : "=&s"(pf) : "s"(np));
+        else
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80" : "=&s"(pf) : "s"(np));
+#else
+        (void) np;
+#endif
+        if (MSDF_WAVE_ANY(selEdgeRelevant(sel, r, o))) {
+#if !defined(MSDF_EAGER_CURVES)
+            if (r.Type() >= 2)
+                asm volatile("s_load_dwordx16 %0, %3, 0xc0\n\ts_load_dwordx16 %1, %3, 0x100\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r.e1), "=&s"(r.e2), "+s"(pf) : "s"(rp));
+#endif
+            selAddEdge(sel, r, (int) (cur&ENTRY_INDEX_MASK), o);
+        }
+        cur = next;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pf));                 // the dummy register is free again only once its loads have landed
+}
+
 enum { QUAD = 4 };   // tiles per wavefront of the LDS-scratch variant (the global-scratch variant, GRES, takes one: measured faster there)
 
 #ifndef MSDF_SIMPLE_WAVES_PER_SIMD
@@ -354,7 +457,7 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             const unsigned long long rowBallot = TPW == 1 ? ballot : (ballot>>(ROW*q))&0xffffull;
             const int before = TPW == 1 ? __popcll(ballot&((1ull<<(col&~15))-1ull)) : 0;     // survivors in the earlier rows of a 64-lane chunk
             if (keep)
-                list[nSurv+before+rank] = i;
+                list[nSurv+before+rank] = (int) packEntry(i, rec[i]);
             if (i < nE && coff[c]-e0 == i) {                        // first edge of its contour: the contour's list starts here ...
                 const int at = nSurv+__popcll(rowBallot&((1ull<<col)-1ull));
                 cstart[c] = at;
@@ -384,7 +487,12 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             continue;
         const V2 p = fastXf ? mk(divExact(x+.5, t.sx, rsx)-t.tx, divExact(y+.5, t.sy, rsy)-t.ty)
                             : unproject(t, mk(x+.5, y+.5));         // msdfgen.cpp:68 (coord/scale-translate, correctly rounded either way)
+#if defined(MSDF_LAZY_RECORDS)                                      // A/B only: compiler-placed field loads, one dependent round trip each
         EdgesCulled edges;
+#else
+        EdgesCulledPacked edges;
+        edges.total = MSDF_UNIFORM(cstarts[(size_t) q*(C+1)+C]);
+#endif
         edges.cstart = cstarts+(size_t) q*(C+1);
         edges.list = lists+(size_t) q*maxEdges;
         double d[NCH];
@@ -599,7 +707,7 @@ k_ec_params(EcGlyphParams *out, BatchView batch, const MsdfHipGlyph *glyphs, Msd
             const bool corner = e < nE && (rec[e].flags&REC_CORNER);
             const unsigned long long mask = __ballot(corner);
             if (corner) {
-                const V2 pp = project(p.t, ld(rec[e].p));
+                const V2 pp = project(p.t, ld(rec[e].p0));
                 const int slot = e0+nCorners+__popcll(mask&((1ull<<lane)-1ull));
                 corners[2*slot] = (int) floor(pp.x-.5);
                 corners[2*slot+1] = (int) floor(pp.y-.5);

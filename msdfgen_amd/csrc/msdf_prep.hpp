@@ -54,8 +54,11 @@ MSDF_HD void st(double *dst, V2 v) { dst[0] = v.x, dst[1] = v.y; }
 
 // Builds the record of edge `cur` whose cyclic neighbours in its contour are `prev` and `next`.
 MSDF_HD void buildRecord(EdgeRec &r, const RawEdge &prev, const RawEdge &cur, const RawEdge &next, int contour) {
-    for (int i = 0; i < 4; ++i)
-        st(r.p+2*i, i <= cur.type ? cur.p[i] : mk(0, 0));
+    st(r.p0, cur.p[0]);
+    st(r.pe, cur.p[cur.type]);                                               // point(1): the last control point
+    st(r.p1, cur.type >= 2 ? cur.p[1] : mk(0, 0));
+    st(r.p2, cur.type == 3 ? cur.p[2] : mk(0, 0));
+    r.pad_[0] = r.pad_[1] = 0;
     for (int i = 0; i < 6; ++i)
         r.k[i] = 0;
     const V2 ab = cur.p[1]-cur.p[0];
@@ -121,7 +124,7 @@ MSDF_HD void buildRecord(EdgeRec &r, const RawEdge &prev, const RawEdge &cur, co
     bool fast;
     if (cur.type == 1) {
         fast = divSafe(r.k[0]);
-        r.rcp[0] = 1/r.k[0];
+        r.k[5] = 1/r.k[0];                                                    // (a linear edge is complete with the R and E0 blocks)
     } else {
         fast = divSafe(r.e0dot) && divSafe(r.e1dot) && (cur.type == 3 || !(flags&REC_NORMED) || divSafe(r.k[0]));
         r.rcp[0] = cur.type == 2 ? 1/r.k[0] : 0;

@@ -18,7 +18,7 @@ MSDF_HD int isign(double n) { return (0 < n)-(n < 0); }                      // 
 
 // EdgeSegment::scanlineIntersections from the digested record (control points, ab, br, as). Returns the count; x[3], dy[3].
 MSDF_HD int scanlineIntersections(const EdgeRec &e, double x[3], int dy[3], double y) {
-    const V2 p0 = ld(e.p), p1 = ld(e.p+2), p2 = ld(e.p+4), p3 = ld(e.p+6);
+    const V2 p0 = ld(e.p0), p1 = e.type == 1 ? ld(e.pe) : ld(e.p1), p2 = e.type == 2 ? ld(e.pe) : ld(e.p2), p3 = ld(e.pe);   // control points as stored (EdgeRec blocks)
     if (e.type == 1) {                                                        // edge-segments.cpp:279-287
         if ((y >= p0.y && y < p1.y) || (y >= p1.y && y < p0.y)) {
             const double param = (y-p0.y)/(p1.y-p0.y);

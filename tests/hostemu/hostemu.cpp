@@ -293,7 +293,7 @@ void emu_generate(int mode, int correctionOnly, float *pixels, int w, int h, int
     if (ecMode == EC_MODE_EDGE_PRIORITY)
         for (int e = 0; e < nE; ++e)
             if (d.recs[e].flags&REC_CORNER) {
-                V2 pp = project(t, ld(d.recs[e].p));
+                V2 pp = project(t, ld(d.recs[e].p0));
                 corners.push_back((int) floor(pp.x-.5));
                 corners.push_back((int) floor(pp.y-.5));
             }
@@ -658,10 +658,25 @@ extern "C" void emu_wave_cost(int w, int h, int nC, const int32_t *co, const dou
                     if (!relevant)
                         continue;
                     ++out[0];
+                    // out[6..]: how many evaluations change NO lane's state (what a tighter relevance test could still drop), by edge type
+                    Selector<3> before[64];
+                    memcpy(before, sel, sizeof(sel));
                     for (int l = 0; l < 64; ++l) {
                         const V2 p = unproject(t, mk(tx*8+(l&7)+.5, ty*8+(l>>3)+.5));
                         selAddEdge(sel[l], d.recs[i], i, p);
                     }
+                    const int ty_ = d.recs[i].type;
+                    ++out[7+ty_];
+                    bool trueChanged = false, anyChanged = false;
+                    for (int l = 0; l < 64; ++l)
+                        for (int ch = 0; ch < 3; ++ch) {
+                            trueChanged = trueChanged || sel[l].idx[ch] != before[l].idx[ch];
+                            anyChanged = anyChanged || sel[l].idx[ch] != before[l].idx[ch] || sel[l].c[ch].neg != before[l].c[ch].neg || sel[l].c[ch].pos != before[l].c[ch].pos;
+                        }
+                    if (!anyChanged)
+                        ++out[6], ++out[10+ty_];
+                    else if (!trueChanged)
+                        ++out[14];
                 }
             }
             if (overlap && nC > 1) {                                          // out[4]: evaluations of the second walks (shapeDistanceOverlap, passes 1 and 2)

@@ -19,12 +19,12 @@ from msdfgen_amd.shape import ShapeBatch, autoframe, distance_mapping  # noqa: E
 
 
 def cost(e, shapes, xfs, size, overlap, order):
-    tot = np.zeros(6, np.int64)
+    tot = np.zeros(16, np.int64)
     for s, xf in zip(shapes, xfs):
         ms, mt = distance_mapping(xf[4], xf[5])
         x6 = np.array([xf[0], xf[1], xf[2], xf[3], ms, mt])
         keep, args = e._shape(s)
-        out = np.zeros(6, np.int64)
+        out = np.zeros(16, np.int64)
         e.lib.emu_wave_cost(size, size, *args, x6.ctypes.data_as(C.POINTER(C.c_double)), overlap, order, out.ctypes.data_as(C.POINTER(C.c_long)))
         tot += out
     return tot
@@ -47,6 +47,8 @@ def main():
                 t = cost(e, sh, xf, size, ov, order)
                 print("%s overlap=%d order=%2d: evals/tile %.2f, survivors/tile %.2f, walks/tile %.2f, second-walk evals/tile %.2f (%.2f passes/tile)"
                       % (name, ov, order, t[0]/t[2], t[1]/t[2], t[3]/t[2], t[4]/t[2], t[5]/t[2]), flush=True)
+                print("    evaluations that change no lane's state: %.1f %% (linear %.1f %% of %d, quadratic %.1f %% of %d, cubic %.1f %% of %d); only perpendicular minima changed: %.1f %%"
+                      % (100.*t[6]/t[0], 100.*t[11]/max(t[8], 1), t[8], 100.*t[12]/max(t[9], 1), t[9], 100.*t[13]/max(t[10], 1), t[10], 100.*t[14]/t[0]), flush=True)
 
 
 if __name__ == "__main__":
