@@ -2327,3 +2327,22 @@ int msdfhip_kernel_timing(double *avgDistance, double *avgCorrection, int *launc
 }
 
 } // extern "C"
+
+// Measurement builds only (-DMSDF_PROFILE_WAITS, tools/profile_waits.py): reads (and optionally clears) the per-wavefront cycle table of
+// k_distance. A regular build has no such table and reports zeros.
+extern "C" int msdfhip_debug_wait_profile(unsigned long long *out24, int reset) {
+#if defined(MSDF_PROFILE_WAITS)
+    unsigned long long zero[24] = { 0 };
+    if (out24)
+        HIPCHK(hipMemcpyFromSymbol(out24, HIP_SYMBOL(msdfhip::gWaitProfile), sizeof(zero)));
+    if (reset)
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(msdfhip::gWaitProfile), zero, sizeof(zero)));
+    return MSDFHIP_OK;
+#else
+    if (out24)
+        memset(out24, 0, 24*sizeof(unsigned long long));
+    (void) reset;
+    return MSDFHIP_OK;
+#endif
+}
+

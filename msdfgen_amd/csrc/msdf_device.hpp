@@ -821,6 +821,10 @@ MSDF_HD void selAddContourSerial(Selector<SEL> &sel, const EdgeRec *rec, const E
 template <int SEL> MSDF_HD void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, const EdgesAll &edges, int c, V2 o) { selAddContourSerial(sel, rec, edges, c, o); }
 template <int SEL> MSDF_HD void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, const EdgesCulled &edges, int c, V2 o) { selAddContourSerial(sel, rec, edges, c, o); }
 
+// Measurement hooks (no-ops unless an edge policy overloads them: msdf_kernels.hpp under MSDF_PROFILE_WAITS).
+template <class Edges> MSDF_HD void profAdd(const Edges &, int, unsigned long long) { }
+template <class Edges> MSDF_HD unsigned long long profNow(const Edges &) { return 0; }
+
 template <int SEL, class Edges>
 MSDF_HD void shapeDistanceSimple(const EdgeRec *rec, const Edges &edges, int C, V2 o, double *out) { // contour-combiners.cpp:34-50
     Selector<SEL> sel;
@@ -840,8 +844,10 @@ MSDF_HD void shapeDistanceSimple(const EdgeRec *rec, const Edges &edges, int C, 
 // The second walk is wave-uniform (any lane needing it) and rare for font outlines; it buys 60 fewer live registers per lane than
 // three merged selectors, which is what lets the kernel run without scratch spills. All walks share ONE instance of the edge loop
 // (pass 0: every contour; pass 1 / 2: the members of the inner / outer selector) to keep the kernel's code and register demand down.
-template <int SEL, class Edges>
-MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const int8_t *windings, int C, V2 o, double *res, int rstride, double *out) {
+// windings: anything indexable by contour that yields Contour::winding -- the int8 array in memory, or (k_distance) two bit masks in scalar
+// registers: a wave-uniform byte load from global memory per contour and loop iteration was a third of this function's time.
+template <int SEL, class Edges, class Wind>
+MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const Wind windings, int C, V2 o, double *res, int rstride, double *out) {
     enum { NCH = SelTraits<SEL>::NCH };
     Selector<SEL> acc;                               // pass 0: the shape selector; pass 1 / 2: the inner / outer selector of the lanes that need one
     int nInner = 0, nOuter = 0, firstInner = 0, firstOuter = 0;
@@ -871,7 +877,10 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
             }
             Selector<SEL> sel;
             selInit(sel);
+            const unsigned long long tw0 = profNow(edges);
             selAddContour(sel, rec, edges, c, o);
+            const unsigned long long tw1 = profNow(edges);
+            profAdd(edges, pass == 0 ? 8 : 10, tw1-tw0);
             if (pass == 0 && C == 1) {
                 // One contour: the shape/inner/outer selectors can only ever hold that contour's own state, and every branch of
                 // contour-combiners.cpp:104-133 then returns that contour's distance -- identical to the simple combiner.
@@ -898,6 +907,7 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
                 }
             } else if (member)
                 selMerge(acc, sel);
+            profAdd(edges, 9, profNow(edges)-tw1);
         }
         if (pass == 0)
             selDistance(acc, shapeD);
@@ -909,6 +919,7 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
         out[ch] = shapeD[ch]+(double) (nInner+nOuter+firstInner+firstOuter);
     return;
 #endif
+    const unsigned long long te0 = profNow(edges);
     // merged selector with exactly one member == that member's own selector; with none, the initial state (every channel -DBL_MAX)
     for (int ch = 0; ch < NCH; ++ch) {
         if (nInner == 1)
@@ -953,6 +964,7 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
     } else {
         for (int ch = 0; ch < NCH; ++ch)
             out[ch] = shapeD[ch];
+        profAdd(edges, 11, profNow(edges)-te0);
         return;
     }
     for (int c = 0; c < C; ++c)
@@ -970,6 +982,7 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
             dist[ch] = shapeD[ch];
     for (int ch = 0; ch < NCH; ++ch)
         out[ch] = dist[ch];
+    profAdd(edges, 11, profNow(edges)-te0);
 }
 
 // -------------------------------------------------------------------------------------------------------- transform

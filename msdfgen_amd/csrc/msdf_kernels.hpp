@@ -208,11 +208,9 @@ __device__ inline int rowRank(unsigned key) {
 //   * the survivor list holds PACKED entries (record index | type | colour | flags): nothing has to be loaded to know what an edge is;
 //   * EdgeRec is stored in 64-byte blocks in the order of use (msdf_device.hpp); the relevance test + a whole linear evaluation need
 //     R + E0 = three s_load_dwordx16, issued together with the LDS read of the NEXT list entry and waited for ONCE;
-//   * right after that wait, the lines of the next survivor's record are requested into a dummy register and NOT waited for: by the time
-//     the walk gets there (a relevance test or a full evaluation later) they sit in the scalar cache;
-//   * a curve fetches E1 + E2 after the wave vote said the edge matters (second round trip, cache-warm).
-// SMEM returns out of order, so the only usable wait is lgkmcnt(0): every asm statement that issues loads it needs ends with one, and the
-// prefetch's dummy destination is threaded through the next such statement ("+s") so that the register stays allocated until then.
+//   * a curve fetches E1 + E2 after the wave vote said the edge matters (second round trip).
+// SMEM returns out of order, so the only usable wait is lgkmcnt(0): every asm statement issues its loads AND waits for them -- no load is
+// ever in flight across C++ code, whose register allocation could move or reuse a pending destination.
 typedef double d8 __attribute__((ext_vector_type(8)));
 
 enum { ENTRY_INDEX_BITS = 20, ENTRY_INDEX_MASK = (1<<ENTRY_INDEX_BITS)-1 };   // 1 M edges per glyph (the LDS lists hold far fewer)
@@ -247,13 +245,45 @@ struct EdgeRegs {
 };
 static_assert(REC_A_ZERO == 1 && REC_B_ZERO == 2 && REC_NORMED == 4 && REC_FASTDIV == 16, "packEntry / EdgeRegs::Flags");
 
+#if defined(MSDF_PROFILE_WAITS)
+// Measurement build only (tools/profile_waits.sh): where a k_distance wavefront's cycles go. s_memtime stamps inside the hand-placed load
+// batches; per-wave sums are added to this table by lane 0 when the wavefront ends. [0] waves [1] wave cycles [2] phase 1 [3] cycles in
+// the R+E0 batch (issue -> landed) [4] batches [5] cycles in the E1+E2 batch [6] batches [7] cycles evaluating edges (selAddEdge) [8]
+// evaluations [9] cycles in relevance tests + vote [10] phase 2 total [11] batches that took > 1000 cycles [12] > 3000 cycles
+__device__ unsigned long long gWaitProfile[24];
+#define MSDF_STAMP(x) const unsigned long long x = __builtin_readcyclecounter()
+#endif
+
+// Contour::winding of a glyph's contours as two bit masks in scalar registers (bit c: winding > 0 / < 0), built once per wavefront from one
+// vector load + two ballots; contours beyond 63 (global-scratch class only) are read from memory.
+struct WindingMasks {
+    unsigned long long pos, neg;
+    const int8_t *mem;
+    __device__ int operator[](int c) const {
+        if (c < 64)
+            return (int) ((pos>>c)&1ull)-(int) ((neg>>c)&1ull);
+        return mem[c];
+    }
+};
+
 struct EdgesCulledPacked {              // survivors of the per-tile cull as packed entries, grouped by contour, nearest-first within a row
     const int *cstart;                  // C+1 compacted offsets
     const int *list;                    // packed entries (LDS)
     int total;                          // cstart[C]
-    __device__ int begin(int c) const { return MSDF_UNIFORM(cstart[c]); }
-    __device__ int end(int c) const { return MSDF_UNIFORM(cstart[c+1]); }
+    int cstartLane;                     // lane c holds cstart[c] (c <= C) when the glyph has fewer than 64 contours, see inLanes
+    bool inLanes;
+#if defined(MSDF_PROFILE_WAITS)
+    mutable unsigned long long prof[16]; // [8] contour walks of pass 0 [9] per-contour bookkeeping after a walk [10] second walks [11] combiner epilogue [12] tile prologue [13] tile stores | [0] batch cycles [1] batches [2] E batch cycles [3] E batches [4] eval cycles [5] evals [6] relevance cycles [7] slow batches (>1000) | (>3000)<<32
+#endif
+    // (a cross-lane read instead of an LDS round trip per contour and tile)
+    __device__ int begin(int c) const { return inLanes ? __builtin_amdgcn_readlane(cstartLane, c) : MSDF_UNIFORM(cstart[c]); }
+    __device__ int end(int c) const { return inLanes ? __builtin_amdgcn_readlane(cstartLane, c+1) : MSDF_UNIFORM(cstart[c+1]); }
 };
+
+#if defined(MSDF_PROFILE_WAITS)
+__device__ inline void profAdd(const EdgesCulledPacked &edges, int i, unsigned long long dt) { edges.prof[i] += dt; }
+__device__ inline unsigned long long profNow(const EdgesCulledPacked &) { return __builtin_readcyclecounter(); }
+#endif
 
 template <int SEL>
 __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, const EdgesCulledPacked &edges, int c, V2 o) {
@@ -262,7 +292,6 @@ __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, con
     if (k >= e)
         return;
     unsigned cur = (unsigned) MSDF_UNIFORM(edges.list[k]);
-    int pf = 0;                                                     // dummy destination of the prefetch loads (never read)
     MSDF_NOUNROLL
     for (; k < e; ++k) {
         const EdgeRec *rp = rec+(cur&ENTRY_INDEX_MASK);
@@ -270,37 +299,47 @@ __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, con
         r.meta = cur;
         unsigned nextV;
         const unsigned nextAddr = (unsigned) (size_t) (edges.list+k+1);       // LDS byte address (low half of the flat address)
-#if defined(MSDF_EAGER_CURVES)                                      // A/B only: a curve's E1 + E2 with the first batch (one round trip, 80 SGPRs)
-        if (r.Type() >= 2)
-            asm volatile("ds_read_b32 %0, %7\n\ts_load_dwordx16 %1, %8, 0x0\n\ts_load_dwordx16 %2, %8, 0x40\n\ts_load_dwordx16 %3, %8, 0x80\n\t"
-                         "s_load_dwordx16 %4, %8, 0xc0\n\ts_load_dwordx16 %5, %8, 0x100\n\ts_waitcnt lgkmcnt(0)"
-                         : "=v"(nextV), "=&s"(r.r0), "=&s"(r.r1), "=&s"(r.e0), "=&s"(r.e1), "=&s"(r.e2), "+s"(pf) : "v"(nextAddr), "s"(rp));
-        else
+#if defined(MSDF_PROFILE_WAITS)
+        MSDF_STAMP(t0);
 #endif
-        asm volatile("ds_read_b32 %0, %5\n\ts_load_dwordx16 %1, %6, 0x0\n\ts_load_dwordx16 %2, %6, 0x40\n\ts_load_dwordx16 %3, %6, 0x80\n\ts_waitcnt lgkmcnt(0)"
-                     : "=v"(nextV), "=&s"(r.r0), "=&s"(r.r1), "=&s"(r.e0), "+s"(pf) : "v"(nextAddr), "s"(rp));
-        // the next survivor (of this contour, or the first of the next one): warm its record's lines, no wait
+        asm volatile("ds_read_b32 %0, %4\n\ts_load_dwordx16 %1, %5, 0x0\n\ts_load_dwordx16 %2, %5, 0x40\n\ts_load_dwordx16 %3, %5, 0x80\n\ts_waitcnt lgkmcnt(0)"
+                     : "=v"(nextV), "=&s"(r.r0), "=&s"(r.r1), "=&s"(r.e0) : "v"(nextAddr), "s"(rp));
+#if defined(MSDF_PROFILE_WAITS)
+        MSDF_STAMP(t1);
+        edges.prof[0] += t1-t0, edges.prof[1] += 1;
+        if (t1-t0 > 1000) edges.prof[7] += 1;
+        if (t1-t0 > 3000) edges.prof[7] += 1ull<<32;
+#endif
         const unsigned next = k+1 < edges.total ? (unsigned) __builtin_amdgcn_readfirstlane((int) nextV) : cur;
-        const EdgeRec *np = rec+(next&ENTRY_INDEX_MASK);
-#if !defined(MSDF_NO_PREFETCH)                                     // (A/B switch)
-        if (((next>>20)&3) >= 2)
-            asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\ts_load_dword %0, %1, 0xc0\n\ts_load_dword %0, %1, 0x100"
-                         : "=&s"(pf) : "s"(np));
-        else
-            asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80" : "=&s"(pf) : "s"(np));
-#else
-        (void) np;
+        // (Requesting the NEXT survivor's lines here without waiting for them -- a scalar-cache warm-up -- was measured: no change, 6.26 vs
+        // 6.28 ms per step; a batch lands in 380 cycles on average, 4 % of a wavefront's life. It also cannot be made safe in C++: the
+        // dummy destination of an unwaited s_load may be copied or spilled by the register allocator and its register reused while the
+        // load is still in flight. Gone.)
+        const bool relevant = MSDF_WAVE_ANY(selEdgeRelevant(sel, r, o));
+#if defined(MSDF_PROFILE_WAITS)
+        MSDF_STAMP(t2);
+        edges.prof[6] += t2-t1;
 #endif
-        if (MSDF_WAVE_ANY(selEdgeRelevant(sel, r, o))) {
-#if !defined(MSDF_EAGER_CURVES)
-            if (r.Type() >= 2)
-                asm volatile("s_load_dwordx16 %0, %3, 0xc0\n\ts_load_dwordx16 %1, %3, 0x100\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r.e1), "=&s"(r.e2), "+s"(pf) : "s"(rp));
+        if (relevant) {
+            if (r.Type() >= 2)                                       // (fetching a curve's E1 + E2 with the first batch: measured, no gain)
+                asm volatile("s_load_dwordx16 %0, %2, 0xc0\n\ts_load_dwordx16 %1, %2, 0x100\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r.e1), "=&s"(r.e2) : "s"(rp));
+#if defined(MSDF_PROFILE_WAITS)
+            MSDF_STAMP(t3);
+            if (r.Type() >= 2) edges.prof[2] += t3-t2, edges.prof[3] += 1;
 #endif
             selAddEdge(sel, r, (int) (cur&ENTRY_INDEX_MASK), o);
+#if defined(MSDF_PROFILE_WAITS)
+            {
+                double keep = sel.c[0].td;                          // the stamp must not move above the evaluation
+                asm volatile("" : "+v"(keep));
+                sel.c[0].td = keep;
+            }
+            MSDF_STAMP(t4);
+            edges.prof[4] += t4-t3, edges.prof[5] += 1;
+#endif
         }
         cur = next;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pf));                 // the dummy register is free again only once its loads have landed
 }
 
 enum { QUAD = 4 };   // tiles per wavefront of the LDS-scratch variant (the global-scratch variant, GRES, takes one: measured faster there)
@@ -366,6 +405,16 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
 
     const MsdfHipGlyph gd = glyphs[wk.g];
     const Xform t = loadXform(gd);
+    WindingMasks wind;
+    wind.mem = batch.windings+c0;
+    if (OVERLAP) {
+        const int w = lane < C ? (int) wind.mem[lane] : 0;
+        wind.pos = __ballot(w > 0), wind.neg = __ballot(w < 0);
+    }
+#if defined(MSDF_PROFILE_WAITS)
+    MSDF_STAMP(pStart);
+    unsigned long long pAcc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
 
     // ---- phase 1: cull + compact (row q of 16 lanes = tile q of the quad; lanes of a row = edges)
     const double rsx = 1/t.sx, rsy = 1/t.sy;                        // two divisions per wavefront; texel positions below use divExact
@@ -388,6 +437,14 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             cstart[c] = 0;
 #else
         const int nE = coff[C]-e0;
+#if defined(MSDF_PROFILE_WAITS)
+        unsigned long long pHdr;
+        {
+            int sink = nE+(int) gd.flip;                            // the header loads have landed when these are usable
+            asm volatile("" : "+s"(sink));
+            pHdr = __builtin_readcyclecounter()+(unsigned long long) (sink&0);
+        }
+#endif
         // Segment-parallel: the lanes of a row take ROW CONSECUTIVE edges of the glyph whatever their contour (a loop per contour left
         // most lanes idle and cost two dependent gathers per contour: 27 rounds for a 14-contour glyph, now 4).
         // Pass A: the bounds. Overlapping combiner: every edge lowers the bound of ITS contour and channels with an LDS atomic minimum
@@ -424,6 +481,10 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
         }
         if (OVERLAP)
             waveSync();
+#if defined(MSDF_PROFILE_WAITS)
+        MSDF_STAMP(pPassA);
+        pAcc[14] = pHdr-pStart, pAcc[15] = pPassA-pHdr;
+#endif
         // Pass B: the cull test against the bounds; survivors go to the list grouped by contour (edges are stored contour by contour, so
         // list order = lane order does it), within a DPP row nearest-first inside each contour's segment.
         for (int base = 0; base < nE; base += ROW) {
@@ -474,6 +535,9 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             cstart[C] = nSurv;
     }
     waveSync();
+#if defined(MSDF_PROFILE_WAITS)
+    MSDF_STAMP(pPhase2);
+#endif
 
     // ---- phase 2: per-texel selection over the survivors (lanes = texels), tile after tile
     MSDF_NOUNROLL
@@ -483,6 +547,9 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             break;
         const int tx = tile%tilesX, ty = tile/tilesX;
         const int x = tx*TILE+(lane&(TILE-1)), y = ty*TILE+(lane>>3);
+        // (read by every lane BEFORE texels outside the bitmap drop out: the walk fetches its contour offsets from lanes 0..C with readlane)
+        int cstartLane = cstarts[(size_t) q*(C+1)+(lane < C ? lane : C)];
+        asm volatile("" : "+v"(cstartLane));                        // pins the load HERE: sunk below the branch, inactive lanes would never load
         if (x >= width || y >= height)
             continue;
         const V2 p = fastXf ? mk(divExact(x+.5, t.sx, rsx)-t.tx, divExact(y+.5, t.sy, rsy)-t.ty)
@@ -491,7 +558,14 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
         EdgesCulled edges;
 #else
         EdgesCulledPacked edges;
-        edges.total = MSDF_UNIFORM(cstarts[(size_t) q*(C+1)+C]);
+        edges.inLanes = C < WAVE;
+        edges.cstartLane = cstartLane;
+        edges.total = edges.inLanes ? __builtin_amdgcn_readlane(edges.cstartLane, C) : MSDF_UNIFORM(cstarts[(size_t) q*(C+1)+C]);
+#if defined(MSDF_PROFILE_WAITS)
+        for (int i = 0; i < 16; ++i)
+            edges.prof[i] = 0;
+        MSDF_STAMP(tTile0);
+#endif
 #endif
         edges.cstart = cstarts+(size_t) q*(C+1);
         edges.list = lists+(size_t) q*maxEdges;
@@ -501,7 +575,7 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             d[ch] = (double) edges.cstart[C];
 #else
         if (OVERLAP)
-            shapeDistanceOverlap<SEL>(rec, edges, batch.windings+c0, C, p, res+lane, WAVE, d);
+            shapeDistanceOverlap<SEL>(rec, edges, wind, C, p, res+lane, WAVE, d);
         else
             shapeDistanceSimple<SEL>(rec, edges, C, p, d);
 #endif
@@ -510,7 +584,29 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
                               : dst+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) NCH*x;
         for (int ch = 0; ch < NCH; ++ch)
             px[ch] = mapDistance(t, d[ch]);                         // msdfgen.cpp:20-48
+#if defined(MSDF_PROFILE_WAITS) && !defined(MSDF_LAZY_RECORDS)
+        {
+            MSDF_STAMP(tTile1);
+            edges.prof[13] += tTile1-tTile0;                        // whole tile: prologue + distance + stores
+        }
+        for (int i = 0; i < 16; ++i)
+            pAcc[i] += edges.prof[i];
+#endif
     }
+#if defined(MSDF_PROFILE_WAITS)
+    {
+        MSDF_STAMP(pEnd);
+        if (lane == 0) {
+            atomicAdd(&gWaitProfile[0], 1ull), atomicAdd(&gWaitProfile[1], pEnd-pStart), atomicAdd(&gWaitProfile[2], pPhase2-pStart);
+            atomicAdd(&gWaitProfile[3], pAcc[0]), atomicAdd(&gWaitProfile[4], pAcc[1]), atomicAdd(&gWaitProfile[5], pAcc[2]), atomicAdd(&gWaitProfile[6], pAcc[3]);
+            atomicAdd(&gWaitProfile[7], pAcc[4]), atomicAdd(&gWaitProfile[8], pAcc[5]), atomicAdd(&gWaitProfile[9], pAcc[6]), atomicAdd(&gWaitProfile[10], pEnd-pPhase2);
+            atomicAdd(&gWaitProfile[11], pAcc[7]&0xffffffffull), atomicAdd(&gWaitProfile[12], pAcc[7]>>32);
+            atomicAdd(&gWaitProfile[13], pAcc[8]), atomicAdd(&gWaitProfile[14], pAcc[9]), atomicAdd(&gWaitProfile[15], pAcc[10]);
+            atomicAdd(&gWaitProfile[16], pAcc[11]), atomicAdd(&gWaitProfile[17], pAcc[13]);
+            atomicAdd(&gWaitProfile[18], pAcc[14]), atomicAdd(&gWaitProfile[19], pAcc[15]);
+        }
+    }
+#endif
     if (!persistent)
         return;
     waveSync();                                                     // the survivor lists in LDS are rebuilt for the next item

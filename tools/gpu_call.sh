@@ -1,7 +1,7 @@
 # One gpurun call of round 3: parity tests, A/B of build variants (variants/<name>.so) on the BASELINE configs, optional profile script.
 # Usage: bash tools/gpu_call.sh <tag> "<variants>" [profile-script args...]
 TAG=$1; VARIANTS=$2; shift 2
-timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/${TAG}_gputests.log
+timeout 600 python -m pytest tests -m gpu -q -x 2>&1 | grep -v "^  File \|dist-packages" | tail -60 > gpurun_out/${TAG}_gputests.log
 tail -4 gpurun_out/${TAG}_gputests.log
 ONLY=${ONLY:-"headline,bench workload,cfg4: 8192 CJK,cfg4 real,cfg5,DejaVu glyphs msdf 64x64, simple"}
 timeout 300 python tools/bench_configs.py --reps 6 --only "$ONLY" > gpurun_out/${TAG}_ab_main.jsonl 2> gpurun_out/${TAG}_ab_main.err

@@ -82,6 +82,14 @@ struct Stamp { unsigned long long cycles, ticks100MHz; };
 #define X_DPP(i) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(n[i]) : "v"(m[i]));
 #define X_READLANE(i) asm volatile("v_readlane_b32 s20, %0, 3" : : "v"(n[i]) : "s20");
 #define X_READFIRST(i) asm volatile("v_readfirstlane_b32 s20, %0" : : "v"(n[i]) : "s20");
+// (c_cndmask_b32 above reads a vcc nobody wrote and measured 22 cycles -- an artefact; these are the forms the kernels execute)
+#define X_CMPCND(i) asm volatile("v_cmp_lt_u32 vcc, %1, %0\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(n[i]) : "v"(m[i]) : "vcc");
+#define X_CNDSGPR(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[22:23]" : "+v"(n[i]) : "v"(m[i]));
+#define X_CMP64S(i) asm volatile("v_cmp_lt_f64_e64 s[24:25], %0, %1" : : "v"(d[i]), "v"(e[i]) : "s24", "s25");
+#define X_MOV64(i) asm volatile("v_mov_b64 %0, %1" : "=v"(d[i]) : "v"(e[i]));
+#define X_SMOV8(i) asm volatile("s_mov_b32 s2%c0, 0x3ff00000" : : "i"(i) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+#define X_SAND64(i) asm volatile("s_and_b64 s[24:25], s[26:27], exec" : : : "s24", "s25", "scc");
+#define X_SNOP(i) asm volatile("s_nop 0");
 // ---- scalar unit (one wave's stream; shows what SALU work costs a wave that has nothing else to issue)
 #define X_SMOV(i) asm volatile("s_mov_b32 s20, 0x3ff00000" : : : "s20");
 #define X_SADD(i) asm volatile("s_add_u32 s20, s20, 3" : : : "s20", "scc");
@@ -96,6 +104,8 @@ DEF(c_cvt_f64_i32, X_CVT_F64_I32) DEF(c_fma_f32, X_FMA32) DEF(c_add_f32, X_ADD32
 DEF(c_cmp_f32, X_CMP32) DEF(c_mov_b32, X_MOV32) DEF(c_cndmask_b32, X_CNDMASK) DEF(c_add_u32, X_ADDU32) DEF(c_and_b32, X_AND32) DEF(c_mul_lo_u32, X_MULLO32)
 DEF(c_lshl_b64, X_LSHL64) DEF(c_mad_u64_u32, X_MADU64) DEF(c_mov_dpp, X_DPP) DEF(c_readlane, X_READLANE) DEF(c_readfirstlane, X_READFIRST)
 DEF(c_s_mov, X_SMOV) DEF(c_s_add, X_SADD) DEF(c_mix5, X_MIX)
+DEF(c_cmp_cndmask_pair, X_CMPCND) DEF(c_cndmask_sgprmask, X_CNDSGPR) DEF(c_cmp_f64_to_sgpr, X_CMP64S) DEF(c_mov_b64, X_MOV64) DEF(c_s_mov_8dst, X_SMOV8)
+DEF(c_s_and_b64, X_SAND64) DEF(c_s_nop, X_SNOP)
 
 // The compiler's own fp64 division and sqrt (IEEE-correct, as the product is built): 8 independent quotients per iteration.
 __global__ void __launch_bounds__(256) c_ieee_div_f64(Stamp *stamps, double *sink, int iters) {
@@ -212,6 +222,8 @@ int main(int argc, char **argv) {
         C(c_fma_f32, "FMA_F32"), C(c_add_f32, "ADD_F32"), C(c_mul_f32, "MUL_F32"), C(c_rcp_f32, "TRANS_F32"), C(c_sqrt_f32, "TRANS_F32"), C(c_cmp_f32, "other"),
         C(c_mov_b32, "other"), C(c_cndmask_b32, "other"), C(c_add_u32, "INT32"), C(c_and_b32, "INT32"), C(c_mul_lo_u32, "INT32"), C(c_lshl_b64, "INT64"),
         C(c_mad_u64_u32, "INT64"), C(c_mov_dpp, "other"), C(c_readlane, "other"), C(c_readfirstlane, "other"), C(c_s_mov, "SALU"), C(c_s_add, "SALU"),
+        { "c_cmp_cndmask_pair", c_cmp_cndmask_pair, BODY*2, "other (v_cmp_lt_u32 + v_cndmask_b32 through vcc; per instruction)" },
+        C(c_cndmask_sgprmask, "other"), C(c_cmp_f64_to_sgpr, "other"), C(c_mov_b64, "other"), C(c_s_mov_8dst, "SALU"), C(c_s_and_b64, "SALU"), C(c_s_nop, "-"),
         { "c_mix5", c_mix5, BODY*5, "mixed: 2 fp64 + s_mov + cmp + cndmask per unit" },
         { "c_ieee_div_f64", c_ieee_div_f64, 8, "compiler's IEEE fp64 division (instruction sequence), per quotient" },
         { "c_ieee_sqrt_f64", c_ieee_sqrt_f64, 8, "compiler's IEEE fp64 sqrt (+1 add), per root" },
