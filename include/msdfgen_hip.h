@@ -296,6 +296,17 @@ int msdfhip_simulate_8bit_host(float *pixels, int width, int height, int row_str
 int msdfhip_set_kernel_timing(int enable);
 int msdfhip_kernel_timing(double *avg_ms_distance, double *avg_ms_correction, int *launches, int reset);
 
+/* Frees the pooled resources of the host-pointer entry points (arenas of the single-shape calls, pipelines of the host-output calls) that are
+ * not in use right now. The pools grow to the peak number of concurrent calls and are otherwise kept for the life of the process. */
+int msdfhip_trim(void);
+
+/* The library reads its MSDFHIP_* environment knobs ("environment") once, at first use. Tests and A/B scripts that change
+ * the environment of a running process call this to have them read again. Not meant for production code. */
+int msdfhip_reload_tuning(void);
+/* Measurement builds only (-DMSDF_PROFILE_WAITS, tools/profile_waits.py): the per-wavefront cycle table of the distance kernel; a regular
+ * build reports zeros. out24: 24 counters. */
+int msdfhip_debug_wait_profile(unsigned long long *out24, int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,8 +100,13 @@ class MSDFGeneratorConfig(GeneratorConfig):
     _stage_limit: int = 0  # test hook: stop the stencil pipeline after stage k (see MsdfHipConfig.ec_stage_limit)
 
 
-def _c_config(config) -> _lib.Config:
+def _c_config(config, y_orientation=None) -> _lib.Config:
+    """y_orientation: the OUTPUT bitmap's orientation; the reference keeps the stencil's rows upward whatever it is
+    (core/MSDFErrorCorrection.cpp:122,192,415), which is what MsdfHipConfig.stencil_y_down tells the device -- set on every path that
+    takes a stencil, single-shape and batched alike."""
     cfg = _lib.default_config()
+    if y_orientation is not None:
+        cfg.stencil_y_down = int(y_orientation == Y_DOWNWARD)
     if config is None:
         return cfg
     cfg.overlap_support = 1 if config.overlap_support else 0
@@ -444,7 +449,7 @@ class GlyphBatch:
             descriptors = self.descriptors(xfs, width, height, n, y_orientation)
         if out is None:
             out = torch.empty((self.n_glyphs, height, width, n), dtype=torch.float32, device=self.device)
-        cfg = _c_config(config if config is not None else (MSDFGeneratorConfig() if mode >= 3 else GeneratorConfig()))
+        cfg = _c_config(config if config is not None else (MSDFGeneratorConfig() if mode >= 3 else GeneratorConfig()), y_orientation)
         _with_scanline_pass(cfg, scanline_pass, fill_rule, sdf_zero_value)
         scratch_ptr = None
         stages = int(mode >= 3 and cfg.ec_mode != EC_DISABLED)+int(bool(scanline_pass))   # intermediate fields, msdfgen_hip.h
@@ -539,7 +544,7 @@ class HostBatch:
         assert out.dtype == np.float32 and out.flags.c_contiguous
         d = _descriptors_host(self.shapes, xfs, np.arange(self.n_glyphs, dtype=np.int64)*tile if out_offsets is None else out_offsets,
                               width*n if row_stride is None else row_stride, y_orientation)
-        cfg = _c_config(config if config is not None else (MSDFGeneratorConfig() if mode >= 3 else GeneratorConfig()))
+        cfg = _c_config(config if config is not None else (MSDFGeneratorConfig() if mode >= 3 else GeneratorConfig()), y_orientation)
         if stencil is not None:
             assert stencil.dtype == np.uint8 and stencil.flags.c_contiguous and stencil.size >= self.n_glyphs*width*height
         _lib.check(_lib.load().msdfhip_batch_generate_host(self._handle, mode, width, height, d.ctypes.data, out.ctypes.data, out.size,
@@ -550,7 +555,7 @@ class HostBatch:
         """8-bit output (pixelFloatToByte, core/pixel-conversion.hpp:8-10) blitted into the host uint8 `atlas`; offsets / stride in bytes."""
         assert atlas.dtype == np.uint8 and atlas.flags.c_contiguous
         d = _descriptors_host(self.shapes, xfs, out_offsets, row_stride, y_orientation)
-        cfg = _c_config(config if config is not None else (MSDFGeneratorConfig() if mode >= 3 else GeneratorConfig()))
+        cfg = _c_config(config if config is not None else (MSDFGeneratorConfig() if mode >= 3 else GeneratorConfig()), y_orientation)
         _lib.check(_lib.load().msdfhip_batch_generate_bytes_host(self._handle, mode, width, height, d.ctypes.data, atlas.ctypes.data, atlas.size, C.byref(cfg)))
         return atlas
 
@@ -565,7 +570,7 @@ def generate_sharded(devices, shapes: ShapeBatch, mode, width, height, xfs, out=
         out = np.zeros((shapes.n_glyphs, height, width, n), np.float32)
     d = _descriptors_host(shapes, xfs, np.arange(shapes.n_glyphs, dtype=np.int64)*tile if out_offsets is None else out_offsets,
                           width*n if row_stride is None else row_stride, y_orientation)
-    cfg = _c_config(config if config is not None else (MSDFGeneratorConfig() if mode >= 3 else GeneratorConfig()))
+    cfg = _c_config(config if config is not None else (MSDFGeneratorConfig() if mode >= 3 else GeneratorConfig()), y_orientation)
     gco = np.ascontiguousarray(shapes.glyph_contour_offsets, np.int32)
     co = np.ascontiguousarray(shapes.contour_offsets, np.int32)
     pts = np.ascontiguousarray(shapes.points, np.float64).reshape(-1, 8)

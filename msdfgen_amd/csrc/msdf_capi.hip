@@ -39,6 +39,53 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// Measurement / experiment knobs from the environment, read ONCE (first use, or msdfhip_reload_tuning() -- tests and A/B scripts flip them
+// between calls); the launch paths never touch getenv.
+struct Tuning {
+    size_t resLdsBudget;             // MSDFHIP_RES_LDS_BUDGET      bytes of LDS per wavefront up to which the combiner scratch stays in LDS
+    long persistentRounds;           // MSDFHIP_PERSISTENT_ROUNDS   global-scratch launches of at least this many rounds run persistent; 0 = never
+    bool serialClasses;              // MSDFHIP_SERIAL_CLASSES      glyph classes one after the other instead of on side streams
+    int querySlotCap, queryLpcContours;   // MSDFHIP_QUERY_LDS      "slotCap,lpcMaxContours"
+    bool hasQueryPolicy;             // MSDFHIP_QUERY_POLICY        "edgeCost,maxEdges,minCount,wideMaxEdges,wideLoad"
+    int qpEdgeCost, qpMaxEdges, qpMinCount, qpWideMaxEdges;
+    float qpWideLoad;
+    size_t signCap;                  // MSDFHIP_SIGN_CAP            row-list capacity of the sign pass
+    bool pipelineUniform;            // MSDFHIP_PIPELINE_UNIFORM    equal pipeline chunks (no half chunks at the ends)
+    int microbatch;                  // MSDFHIP_MICROBATCH          0 / 1 disables the grouping of concurrent single-shape calls; N caps the group
+    char devices[256];               // MSDFHIP_DEVICES             "all" | "0,1,..." devices the single-shape front door spreads over
+};
+Tuning gTuning;
+std::once_flag gTuningOnce;
+
+void readTuning() {
+    Tuning t;
+    const char *env;
+    t.resLdsBudget = (env = getenv("MSDFHIP_RES_LDS_BUDGET")) ? (size_t) atol(env) : (size_t) 13*1024;
+    t.persistentRounds = (env = getenv("MSDFHIP_PERSISTENT_ROUNDS")) ? atol(env) : 8;
+    t.serialClasses = getenv("MSDFHIP_SERIAL_CLASSES") != NULL;
+    t.querySlotCap = 160, t.queryLpcContours = 24;
+    if ((env = getenv("MSDFHIP_QUERY_LDS")))
+        sscanf(env, "%d,%d", &t.querySlotCap, &t.queryLpcContours);
+    t.qpEdgeCost = 340, t.qpMaxEdges = 48, t.qpMinCount = 0x7fffffff, t.qpWideMaxEdges = 128, t.qpWideLoad = 4e8f;
+    t.hasQueryPolicy = (env = getenv("MSDFHIP_QUERY_POLICY")) != NULL;
+    if (env)
+        sscanf(env, "%d,%d,%d,%d,%f", &t.qpEdgeCost, &t.qpMaxEdges, &t.qpMinCount, &t.qpWideMaxEdges, &t.qpWideLoad);
+    t.signCap = (env = getenv("MSDFHIP_SIGN_CAP")) ? (size_t) atol(env) : (size_t) 192;
+    t.pipelineUniform = getenv("MSDFHIP_PIPELINE_UNIFORM") != NULL;
+    t.microbatch = (env = getenv("MSDFHIP_MICROBATCH")) ? atoi(env) : 256;
+    if (t.microbatch < 1)
+        t.microbatch = 1;
+    t.devices[0] = 0;
+    if ((env = getenv("MSDFHIP_DEVICES")))
+        snprintf(t.devices, sizeof(t.devices), "%s", env);
+    gTuning = t;
+}
+
+const Tuning &tuning() {
+    std::call_once(gTuningOnce, readTuning);
+    return gTuning;
+}
+
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void) hipGetLastError(); return fail(MSDFHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
 
 // Binds the calling thread to `dev` (>= 0: the device a batch lives on) or to the process default (msdfhip_init; device 0 if never called).
@@ -50,6 +97,20 @@ int ensureDevice(int dev = -1) {
     }
     if (dev < 0)
         dev = gDevice.load();
+    else if (dev != gDevice.load()) {                            // another device of the node: it must be a gfx950 too (checked once per device)
+        static std::atomic<unsigned long long> checked(0);
+        if (dev >= 64 || !((checked.load()>>dev)&1ull)) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+                (void) hipGetLastError();
+                return fail(MSDFHIP_ERR_NO_DEVICE, "hipGetDeviceProperties(%d) failed", dev);
+            }
+            if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+                return fail(MSDFHIP_ERR_NO_DEVICE, "device %d is %s; libmsdfgen_hip is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+            if (dev < 64)
+                checked.fetch_or(1ull<<dev);
+        }
+    }
     if (hipSetDevice(dev) != hipSuccess) {
         (void) hipGetLastError();                                // HIP's last error is sticky: do not leave it for an unrelated later check
         return fail(MSDFHIP_ERR_NO_DEVICE, "hipSetDevice(%d) failed", dev);
@@ -213,9 +274,7 @@ size_t ldsBudget() {
     // The combiner scratch lives in LDS only while 12 wavefronts (3 per SIMD, the register-limited occupancy) fit a CU's 160 KB:
     // beyond ~13 KB per wavefront LDS would cap the occupancy (a 20-contour glyph set ran at 1.25 wavefronts/SIMD), so it moves to a
     // global workspace instead -- written and read once per contour with lane-consecutive addresses.
-    if (const char *env = getenv("MSDFHIP_RES_LDS_BUDGET"))      // experiment knob (bytes)
-        return (size_t) atol(env);
-    return 13*1024;
+    return tuning().resLdsBudget;                                // 13 KB unless MSDFHIP_RES_LDS_BUDGET says otherwise
 }
 
 // maxContours / maxEdges: of the glyphs this launch covers (default: of the whole batch).
@@ -297,9 +356,7 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
         const size_t slots = (size_t) residentSlots(b->device)*4u*MSDF_DISTANCE_WAVES_PER_SIMD;
         // (Only for launches of many rounds: a persistent workgroup never yields its slot, so next to the other glyph classes' launches
         // it freezes the split of the device between them -- measured 2 % slower than the direct mapping at 5 rounds, 12 % faster at 96.)
-        size_t minRounds = 8;
-        if (const char *env = getenv("MSDFHIP_PERSISTENT_ROUNDS"))   // experiment knob; 0 = never
-            minRounds = (size_t) atol(env);
+        const size_t minRounds = (size_t) tuning().persistentRounds;   // 8; MSDFHIP_PERSISTENT_ROUNDS, 0 = never
         if (minRounds && blocks >= minRounds*slots && blocks < 0xffffffffull-8u*slots) {
             chunk = slots;
             rc = ensureGres(b, chunk*plan.resBytes+8*sizeof(unsigned), &gres);
@@ -462,7 +519,7 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     // two on the batch's side streams, forked and joined by events), so that the tail of one fills with the wavefronts of the others --
     // two processes sharing the GPU had measured 12 % more throughput than one.
     const int classes = (b->nOne > 0)+(b->nSmall > 0)+(nRest > 0);
-    const bool concurrent = classes > 1 && !getenv("MSDFHIP_SERIAL_CLASSES");
+    const bool concurrent = classes > 1 && !tuning().serialClasses;
     hipStream_t sOne = stream, sRest = stream;
     if (concurrent) {
         rc = ensureSideStreams(b);
@@ -478,39 +535,49 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
             HIPCHK(hipStreamWaitEvent(sOne, b->forkEvent, 0));
         }
     }
+    // (an error between fork and join must not leave side-stream kernels unordered with the caller's stream: the launches only set rc,
+    // the join below always runs)
     if (nRest > 0) {                                             // first: few, heavy glyphs -- the longest tail
         LdsPlan rest = plan;                                     // sized for the batch's largest glyph
         rest.globalRes = true;
         rest.bytes = tileListBytes(b->maxEdges, b->maxContours, true);
         rc = launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, rest, sRest, b->dBucket+b->nOne+b->nSmall, nRest);
-        if (rc != MSDFHIP_OK)
-            return rc;
     }
-    if (b->nSmall > 0) {
+    if (rc == MSDFHIP_OK && b->nSmall > 0) {
         LdsPlan small;
         rc = planLds(b, SelTraits<SEL>::NCH, true, small, b->smallMaxC, b->smallMaxE);
         if (rc == MSDFHIP_OK)
             rc = launchDistance<SEL, true, false>(b, dGlyphs, w, h, dst, toScratch, small, stream, b->dBucket+b->nOne, b->nSmall);
-        if (rc != MSDFHIP_OK)
-            return rc;
     }
-    if (b->nOne > 0) {
+    if (rc == MSDFHIP_OK && b->nOne > 0) {
         LdsPlan simple;
         rc = planLds(b, SelTraits<SEL>::NCH, false, simple, 1, b->oneMaxE);
         if (rc == MSDFHIP_OK)
             rc = launchDistance<SEL, false, false>(b, dGlyphs, w, h, dst, toScratch, simple, sOne, b->dBucket, b->nOne);
-        if (rc != MSDFHIP_OK)
-            return rc;
     }
+    hipError_t joinError = hipSuccess;
     if (sRest != stream) {
-        HIPCHK(hipEventRecord(b->joinEvent[0], sRest));
-        HIPCHK(hipStreamWaitEvent(stream, b->joinEvent[0], 0));
+        hipError_t e = hipEventRecord(b->joinEvent[0], sRest);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(stream, b->joinEvent[0], 0);
+        joinError = e != hipSuccess ? e : joinError;
     }
     if (sOne != stream) {
-        HIPCHK(hipEventRecord(b->joinEvent[1], sOne));
-        HIPCHK(hipStreamWaitEvent(stream, b->joinEvent[1], 0));
+        hipError_t e = hipEventRecord(b->joinEvent[1], sOne);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(stream, b->joinEvent[1], 0);
+        joinError = e != hipSuccess ? e : joinError;
     }
-    return MSDFHIP_OK;
+    if (joinError != hipSuccess) {                               // could not order the streams by events: fall back to waiting for them here
+        (void) hipGetLastError();
+        if (sRest != stream)
+            (void) hipStreamSynchronize(sRest);
+        if (sOne != stream)
+            (void) hipStreamSynchronize(sOne);
+        if (rc == MSDFHIP_OK)
+            rc = fail(MSDFHIP_ERR_HIP, "joining the glyph-class streams failed: %s", hipGetErrorString(joinError));
+    }
+    return rc;
 }
 
 // Records of the per-glyph candidate segments incl. the header (msdf_kernels.hpp, EcCandidate), followed by the work list of
@@ -579,9 +646,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     // combiner scratch is one double per contour (wave-uniform query point)
     // (both bounded so that the kernel's LDS does not cap its occupancy -- one 543-edge symbol in the batch had cost every wavefront
     // 22 KB; measured: 2.67 -> 2.60 ms of correction on the distinct-glyph set)
-    int slotCapWanted = 160, lpcContoursWanted = 24;
-    if (const char *env = getenv("MSDFHIP_QUERY_LDS"))           // experiment knob: "slotCap,lpcMaxContours"
-        sscanf(env, "%d,%d", &slotCapWanted, &lpcContoursWanted);
+    const int slotCapWanted = tuning().querySlotCap, lpcContoursWanted = tuning().queryLpcContours;   // 160, 24 (MSDFHIP_QUERY_LDS)
     const int slotCap = b->maxEdges < slotCapWanted ? (b->maxEdges > 0 ? b->maxEdges : 1) : slotCapWanted;
     // LDS of a query wavefront: the lane-per-candidate scratch [maxContours][64], or (cooperative) [maxContours] + the slots -- one or the other
     EcQueryPolicy lpcMaxContours;
@@ -593,11 +658,8 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     // Round 2, after the records of the lane-per-candidate walk became scalar loads and the work list heavy-first: with the bound at 128
     // edges for every launch the CJK-like set gains (4.42 -> 2.82) and the DejaVu set loses (2.33 -> 2.73: 55 k candidates are a latency
     // chain, not a load) -- k_ec_scan therefore widens the bound only for launches whose cooperative cost exceeds wideLoad instructions.
-    lpcMaxContours.lpcEdgeCost = 340, lpcMaxContours.lpcMaxEdges = 48, lpcMaxContours.lpcMinCount = 0x7fffffff;
-    lpcMaxContours.wideMaxEdges = 128, lpcMaxContours.wideLoad = 4e8f;
-    if (const char *env = getenv("MSDFHIP_QUERY_POLICY"))        // experiment knob: "edgeCost,maxEdges,minCount,wideMaxEdges,wideLoad"
-        sscanf(env, "%d,%d,%d,%d,%f", &lpcMaxContours.lpcEdgeCost, &lpcMaxContours.lpcMaxEdges, &lpcMaxContours.lpcMinCount, &lpcMaxContours.wideMaxEdges,
-               &lpcMaxContours.wideLoad);
+    lpcMaxContours.lpcEdgeCost = tuning().qpEdgeCost, lpcMaxContours.lpcMaxEdges = tuning().qpMaxEdges, lpcMaxContours.lpcMinCount = tuning().qpMinCount;   // 340, 48, never
+    lpcMaxContours.wideMaxEdges = tuning().qpWideMaxEdges, lpcMaxContours.wideLoad = tuning().qpWideLoad;                                                   // 128, 4e8 (MSDFHIP_QUERY_POLICY)
     const size_t resLanes = OVERLAP ? (size_t) (lpcMaxContours.lpcMaxContours > 0 ? lpcMaxContours.lpcMaxContours : 1)*WAVE*sizeof(double) : 0;
     const int slotOffset = OVERLAP ? (b->maxContours > 0 ? b->maxContours : 1) : 0;
     const int mergedCap = b->maxContours < slotCap ? (b->maxContours > 0 ? b->maxContours : 1) : slotCap;   // per-contour merged states of a glyph that uses the slots
@@ -687,9 +749,7 @@ int launchSign(const MsdfHipBatch *b, int w, int h, const MsdfHipGlyph *dGlyphs,
         return fail(MSDFHIP_ERR_INVALID, "launch of %zu tile rows exceeds the grid limit; split the batch", blocks);
     // Row-list capacity: every edge yields at most 3 intersections per row. Up to capLimit entries per row the lists of the
     // whole shape fit; beyond, the kernel walks the edges in chunks of cap/3.
-    size_t capLimit = 192;                                       // 23 KB per wavefront at the limit (384: 46 KB = 3 wavefronts per CU; distinct-glyph set 2.95 -> 2.60 ms)
-    if (const char *env = getenv("MSDFHIP_SIGN_CAP"))            // experiment knob
-        capLimit = (size_t) atol(env);
+    const size_t capLimit = tuning().signCap;                    // 192: 23 KB per wavefront at the limit (384: 46 KB = 3 wavefronts per CU; distinct-glyph set 2.95 -> 2.60 ms)
     size_t cap = 3*(size_t) (b->maxEdges > 0 ? b->maxEdges : 1);
     if (cap > capLimit)
         cap = capLimit;
@@ -781,11 +841,11 @@ int msdfhip_batch_create_device(MsdfHipBatch **batch, int n_glyphs, int n_contou
                                 const double *d_points, const uint8_t *d_types, const uint8_t *d_colors, void *stream) {
     if (!batch || n_glyphs < 0 || n_contours < 0 || n_edges < 0)
         return fail(MSDFHIP_ERR_INVALID, "bad batch dimensions");
-    int rc = ensureDevice();
+    int rc = ensureDeviceOf(d_points ? (const void *) d_points : (const void *) d_glyph_contour_offsets);   // the device that OWNS the caller's arrays (a torch tensor on cuda:1 ...)
     if (rc != MSDFHIP_OK)
         return rc;
     MsdfHipBatch *b = new MsdfHipBatch();
-    b->device = currentDevice();                                 // where the caller's arrays live: the device bound by msdfhip_init
+    b->device = currentDevice();                                 // ... not the process default
     b->nGlyphs = n_glyphs, b->nContours = n_contours, b->nEdges = n_edges;
     b->maxContours = max_contours_per_glyph, b->maxEdges = max_edges_per_glyph;
     b->ownsInputs = false;
@@ -1319,11 +1379,19 @@ struct Pipe {
 static std::mutex gPipeMutex;
 static std::vector<Pipe *> gPipePool;
 
+static void destroyPipe(Pipe *p);                                // (below, next to msdfhip_trim)
+
 struct PipeLease {
     Pipe *p;
     PipeLease() : p(NULL) { }
     ~PipeLease() {
         if (p) {
+            // Whatever exit the call took (an error return may leave copies into caller memory / kernels in flight on the slots' streams):
+            // nothing of this call is pending when the next caller takes the pipe. Idle streams answer at once.
+            for (int k = 0; k < 2; ++k)
+                if (p->slot[k].stream)
+                    (void) hipStreamSynchronize(p->slot[k].stream);
+            (void) hipGetLastError();
             std::lock_guard<std::mutex> lock(gPipeMutex);
             gPipePool.push_back(p);
         }
@@ -1345,11 +1413,17 @@ struct PipeLease {
             s.stream = NULL, s.done = NULL, s.busy = false, s.dev = NULL, s.devCap = 0, s.pinnedGlyphs = NULL, s.pinnedGlyphCap = 0, s.viewCap = 0;
             s.pinnedTiles = NULL, s.pinnedTilesCap = 0, s.pendingFirst = 0, s.pendingCount = 0;
         }
-        p = fresh;                                               // (returned to the pool even if a creation below fails: its handles stay NULL-safe)
-        for (int k = 0; k < 2; ++k) {
-            HIPCHK(hipStreamCreateWithFlags(&fresh->slot[k].stream, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&fresh->slot[k].done, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) {                            // a half-built pipe never reaches the pool
+            hipError_t e = hipStreamCreateWithFlags(&fresh->slot[k].stream, hipStreamNonBlocking);
+            if (e == hipSuccess)
+                e = hipEventCreateWithFlags(&fresh->slot[k].done, hipEventDisableTiming);
+            if (e != hipSuccess) {
+                (void) hipGetLastError();
+                destroyPipe(fresh);
+                return fail(MSDFHIP_ERR_HIP, "host-output pipeline: creating a stream / event failed: %s", hipGetErrorString(e));
+            }
         }
+        p = fresh;
         return MSDFHIP_OK;
     }
 };
@@ -1482,7 +1556,7 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
     {
         const int half = chunk/2 >= 64 ? chunk/2/64*64 : chunk;
         int rem = nG;
-        if (nG >= 2*chunk && half < chunk && !getenv("MSDFHIP_PIPELINE_UNIFORM")) {
+        if (nG >= 2*chunk && half < chunk && !tuning().pipelineUniform) {
             lengths.push_back(half);
             for (rem -= half; rem > chunk+half; rem -= chunk)
                 lengths.push_back(chunk);
@@ -1521,6 +1595,31 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
             spanLo = lo < spanLo ? lo : spanLo, spanHi = hi > spanHi ? hi : spanHi;
         }
         dense = dense && (unsigned long long) (spanHi-spanLo) == (unsigned long long) n*tile;
+        // Equal area is an exact tiling only if the rectangles are DISJOINT (two glyphs on one cell + a free cell elsewhere have the same
+        // area: the free cell would come back as whatever the device buffer held). Accept the two layouts that make it so by construction:
+        // packed tiles in glyph order, or the cells of a grid whose pitch is the common row stride, each used once.
+        if (dense) {
+            bool packed = true;
+            for (int g = 0; g < n && packed; ++g)
+                packed = glyphs[g0+g].row_stride == (int64_t) w*N && glyphs[g0+g].out_offset == spanLo+(long long) g*(long long) tile;
+            if (!packed) {
+                const long long pitch = glyphs[g0].row_stride, cellW = (long long) w*N;
+                bool grid = pitch > 0 && pitch%cellW == 0 && (long long) n%(pitch/cellW) == 0;
+                std::vector<bool> used(grid ? (size_t) n : 0, false);
+                for (int g = 0; g < n && grid; ++g) {
+                    const long long rel = glyphs[g0+g].out_offset-spanLo;
+                    const long long row = rel/pitch, col = rel%pitch;
+                    grid = glyphs[g0+g].row_stride == pitch && row%h == 0 && col%cellW == 0;
+                    if (grid) {
+                        const size_t cell = (size_t) ((row/h)*(pitch/cellW)+col/cellW);
+                        grid = cell < used.size() && !used[cell];
+                        if (grid)
+                            used[cell] = true;
+                    }
+                }
+                dense = grid;
+            }
+        }
         const bool floatsInCallerLayout = out != NULL && dense;
         for (int g = 0; g < n; ++g) {                            // descriptors of the generators: the caller's layout (relative to the range) or packed tiles
             p.pinnedGlyphs[g] = glyphs[g0+g];
@@ -1722,6 +1821,10 @@ struct ArenaLease {
     ArenaLease() : a(NULL) { }
     ~ArenaLease() {
         if (a) {
+            if (a->stream) {                                     // (an error exit may leave copies / kernels of this call in flight)
+                (void) hipStreamSynchronize(a->stream);
+                (void) hipGetLastError();
+            }
             std::lock_guard<std::mutex> lock(gArenaMutex);
             gArenaPool.push_back(a);
         }
@@ -1765,6 +1868,30 @@ static int arenaReserve(ThreadArena &a, size_t devBytes, size_t pinnedBytes) {
         a.pinnedCap = cap;
     }
     return MSDFHIP_OK;
+}
+
+static void destroyPipe(Pipe *p) {
+    (void) hipSetDevice(p->device);
+    for (int k = 0; k < 2; ++k) {
+        PipeSlot &s = p->slot[k];
+        if (s.stream)
+            (void) hipStreamSynchronize(s.stream);
+        destroySideStreams(&s.view);
+        hipFree(s.view.dScratch), hipFree(s.view.dDeferred), hipFree(s.view.dEcParams), hipFree(s.view.dGres), hipFree(s.view.dBucket);
+        if (s.view.hBucket)
+            pinnedFree(s.view.hBucket);
+        hipFree(s.dev);
+        if (s.pinnedGlyphs)
+            pinnedFree(s.pinnedGlyphs);
+        if (s.pinnedTiles)
+            pinnedFree(s.pinnedTiles);
+        if (s.done)
+            hipEventDestroy(s.done);
+        if (s.stream)
+            hipStreamDestroy(s.stream);
+    }
+    (void) hipGetLastError();
+    delete p;
 }
 
 struct Carver {                                                  // 256-byte aligned sub-allocation inside an arena
@@ -1961,10 +2088,7 @@ static const size_t GROUP_BYTES_LIMIT = 256u<<20;                // tiles of one
 static int maxGroup() {
     int v = gMaxGroup.load();
     if (v < 0) {
-        const char *env = getenv("MSDFHIP_MICROBATCH");          // 0 disables; N > 1 caps the group size
-        v = env ? atoi(env) : 256;
-        if (v < 1)
-            v = 1;
+        v = tuning().microbatch;                                 // MSDFHIP_MICROBATCH: 0 disables; N > 1 caps the group size (256)
         gMaxGroup.store(v);
     }
     return v;
@@ -2296,6 +2420,48 @@ int msdfhip_shape_distance(int selector, int overlap, const int32_t *co, int nC,
 }
 
 // -------------------------------------------------------------------------------------------------------- timing hook
+
+// The pools of the host-pointer entry points (one arena per concurrent single-shape call, one two-slot pipeline per concurrent host-output
+// call: ~100-200 MB of device + pinned memory each) only ever grow to the PEAK concurrency. A long-lived process that is done with a
+// burst returns them here; resources of calls in flight are not in the pools and stay untouched.
+int msdfhip_trim(void) {
+    std::vector<ThreadArena *> arenas;
+    std::vector<Pipe *> pipes;
+    {
+        std::lock_guard<std::mutex> lock(gArenaMutex);
+        arenas.swap(gArenaPool);
+    }
+    {
+        std::lock_guard<std::mutex> lock(gPipeMutex);
+        pipes.swap(gPipePool);
+    }
+    int prev = 0;
+    (void) hipGetDevice(&prev);
+    for (size_t i = 0; i < arenas.size(); ++i) {
+        ThreadArena *a = arenas[i];
+        (void) hipSetDevice(a->device);
+        if (a->stream)
+            (void) hipStreamSynchronize(a->stream);
+        hipFree(a->dev);
+        if (a->pinned)
+            pinnedFree(a->pinned);
+        if (a->stream)
+            hipStreamDestroy(a->stream);
+        delete a;
+    }
+    for (size_t i = 0; i < pipes.size(); ++i)
+        destroyPipe(pipes[i]);
+    (void) hipSetDevice(prev);
+    (void) hipGetLastError();
+    return MSDFHIP_OK;
+}
+
+int msdfhip_reload_tuning(void) {
+    tuning();                                                     // (make sure the one-time read is behind us)
+    readTuning();
+    gMaxGroup.store(-1);
+    return MSDFHIP_OK;
+}
 
 int msdfhip_set_kernel_timing(int enable) {
     gTiming.store(enable ? 1 : 0);

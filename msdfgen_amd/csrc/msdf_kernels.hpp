@@ -506,12 +506,16 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
 #endif
                 }
             }
-            // key = (contour segment within the 16-lane row | distance | slot): contours stay grouped, nearest first inside each
-            const int rowFirstContour = __shfl(c, lane&~15);
+            // key = (contour segment within the 16-lane row | distance | slot): contours stay grouped, nearest first inside each.
+            // The segment is the number of contour CHANGES up to this lane within its row (at most 15) -- not the difference of contour
+            // indices, which empty contours (valid input: they own no edge) can push past 15.
+            const int cPrev = __shfl(i < nE ? c : -1, lane > 0 ? lane-1 : 0);
+            const unsigned long long changes = __ballot((lane&15) != 0 && i < nE && c != cPrev);
+            const int segment = __popcll((changes>>(lane&~15))&((2ull<<(lane&15))-1ull));
             unsigned key = MSDF_CULL_KEY_DROPPED_SEGMENTED|(unsigned) (col&15);
             if (keep) {
                 const unsigned d = (cullOrderKey(rec[i], tc, 0)>>3)&0x0ffffff0u;
-                key = ((unsigned) ((c-rowFirstContour)&15)<<28)|(d < 0x0ffffff0u ? d : 0x0fffffe0u)|(unsigned) (col&15);
+                key = ((unsigned) segment<<28)|(d < 0x0ffffff0u ? d : 0x0fffffe0u)|(unsigned) (col&15);
             }
             const int rank = rowRank(key);
             const unsigned long long ballot = __ballot(keep);
@@ -1186,8 +1190,11 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             PsdfQueryCooperative<OVERLAP> query;
             query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.lane = threadIdx.x;
             query.res = smemLds;
-            query.slots = nE <= slotCap ? slotBuf : NULL;           // larger glyphs: per-contour cross-lane merge instead of the slots
-            query.merged = slotBuf+slotCap;                         // [min(maxContours, slotCap)]: a glyph of <= slotCap edges has no more contours
+            // larger glyphs: per-contour cross-lane merge instead of the slots. `merged` holds min(maxContours, slotCap) states: a glyph of
+            // <= slotCap edges normally has no more contours than that, but EMPTY contours (valid input) do not count as edges -- such a
+            // glyph takes the other path too.
+            query.slots = nE <= slotCap && C <= slotCap ? slotBuf : NULL;
+            query.merged = slotBuf+slotCap;
             const size_t texel = cand.texel;
             const int rem = (int) (texel-(size_t) g*texelsPerGlyph);
             const int yn = rem/width, x = rem%width;

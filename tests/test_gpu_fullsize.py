@@ -111,12 +111,14 @@ def test_config4_cjk_like_512_distinct_shapes_every_tile_both_mappings(oracle):
     for knob, what in ((None, "persistent"), ("0", "direct")):
         if knob is not None:
             os.environ["MSDFHIP_PERSISTENT_ROUNDS"] = knob
+            M.load().msdfhip_reload_tuning()
         try:
             gb = M.GlyphBatch(batch)
             tiles = gb.generate(M.MODE_MSDF, 48, 48, xfs).cpu().numpy()
             gb.close()
         finally:
             os.environ.pop("MSDFHIP_PERSISTENT_ROUNDS", None)
+            M.load().msdfhip_reload_tuning()
         bad = [g for g in range(8192) if not (sha(tiles[g]) == want[g % 512]).all()]
         for g in bad[:4]:
             ref = oracle.generate(base[g % 512], 3, 48, 48, xfs[g])

@@ -221,15 +221,22 @@ def test_empty_contours_in_batched_launches(oracle):
     few = FlatShape.from_contours([[], tri(.3, .3, .22), [], [], tri(.65, .6, .3, flip=True), []])
     many = FlatShape.from_contours([[]]+[c for k in range(9) for c in (tri(.15+.08*k, .2+.07*k, .12, flip=bool(k % 2)), [])]+[[], []])
     assert few.n_contours == 6 and many.n_contours == 21
-    shapes = [few, many]*90                                                   # 180 glyphs x 64 tiles: not a small launch
+    # 16 or more contour INDICES inside one 16-edge row of phase 1 (a run of empty contours between two small ones) -- the rank
+    # key's contour segment must count contour changes, not index differences -- and more contours than edges in k_ec_query's slot path.
+    runs = FlatShape.from_contours([tri(.25, .3, .2)]+[[]]*19+[tri(.6, .55, .3, flip=True)]+[[]]*17+[tri(.75, .25, .15)]+[[]]*3)
+    assert runs.n_contours == 42 and runs.n_edges == 9
+    shapes = [few, many, runs]*60                                             # 180 glyphs x 64 tiles: not a small launch
     xfs = np.stack([autoframe((0, 0, 1, 1), 64, 64, 4)]*len(shapes))
     for ov in (True, False):
         gb = M.GlyphBatch(ShapeBatch.from_shapes(shapes))
         got = gb.generate(3, 64, 64, xfs, config=cfg(ov)).cpu().numpy()
         gb.close()
-        for g, s in enumerate((few, many)):
+        for g, s in enumerate((few, many, runs)):
             close(got[g], oracle.generate(s, 3, 64, 64, xfs[g], overlap=ov), "empty contours, shape %d, overlap %d" % (g, ov))
-        assert (bits(got[0::2]) == bits(got[0])).all() and (bits(got[1::2]) == bits(got[1])).all()
+        assert (bits(got[0::3]) == bits(got[0])).all() and (bits(got[1::3]) == bits(got[1])).all() and (bits(got[2::3]) == bits(got[2])).all()
+    one = np.zeros((64, 64, 3), np.float32)                                   # the single-shape call (one tile per wavefront, small-launch forms)
+    M.generate_msdf(one, runs, M.SDFTransformation.from_xf(xfs[2]))
+    close(one, oracle.generate(runs, 3, 64, 64, xfs[2]), "empty contour runs, single-shape call")
 
 
 def test_many_contours_cjk_like_48(oracle):
@@ -275,10 +282,12 @@ def test_config4_full_size_atlas_8192_glyphs_48(oracle):
     # mapping (one slice per tile, chunked launches) must give the same bytes
     import os
     os.environ["MSDFHIP_PERSISTENT_ROUNDS"] = "0"
+    M.load().msdfhip_reload_tuning()
     try:
         direct = M.GlyphBatch(batch).generate(3, 48, 48, xfs).cpu().numpy()
     finally:
         del os.environ["MSDFHIP_PERSISTENT_ROUNDS"]
+        M.load().msdfhip_reload_tuning()
     assert (bits(direct) == bits(got)).all()
     print("config 4: 24 sampled tiles, %d texels differing bitwise" % worst)
 
@@ -742,3 +751,29 @@ def test_stencil_rows_follow_the_reference_for_y_downward_bitmaps(ref):
     untouched = np.full((64, 64), 77, np.uint8)
     gen(3, batch.shape(g), 64, 64, z["xf64"][g], cfg(ec_mode=M.EC_DISABLED, buffer=untouched))
     assert (untouched == 77).all()
+
+
+def test_stencil_rows_of_the_batched_paths_for_y_downward_bitmaps(ref):
+    """The same contract on the BATCHED entry points: GlyphBatch.generate (device tensors) and HostBatch.generate_host take
+    y_orientation and a stencil, and must lay the stencil out like the single-shape path and the compiled reference do."""
+    import torch
+    z = load_npz("latin.npz")
+    batch = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
+                       z["colors"].astype(np.int32), z["inverse_y"], [str(n) for n in z["names"]])
+    pick = [batch.names.index(n) for n in ("U+0040", "U+0067", "U+0025")]
+    sub, xfs = batch.select(pick), z["xf64"][pick]
+    for y in (M.Y_UPWARD, M.Y_DOWNWARD):
+        want_st = np.zeros((3, 64, 64), np.uint8)
+        want = np.stack([ref.generate(sub.shape(g), 3, 64, 64, xfs[g], y_down=(y == M.Y_DOWNWARD), stencil=want_st[g]) for g in range(3)])
+        gb = M.GlyphBatch(sub)
+        st = torch.full((3, 64, 64), 77, dtype=torch.uint8, device="cuda")
+        got = gb.generate(3, 64, 64, xfs, stencil=st, y_orientation=y).cpu().numpy()
+        gb.close()
+        close(got, want, "GlyphBatch.generate y=%d" % y)
+        assert (st.cpu().numpy() == want_st).all(), "GlyphBatch.generate: stencil rows, y_orientation %d" % y
+        hb = M.HostBatch(sub)
+        hst = np.full((3, 64, 64), 77, np.uint8)
+        hgot = hb.generate_host(3, 64, 64, xfs, stencil=hst, y_orientation=y)
+        hb.close()
+        close(hgot, want, "HostBatch.generate_host y=%d" % y)
+        assert (hst == want_st).all(), "HostBatch.generate_host: stencil rows, y_orientation %d" % y

@@ -88,6 +88,34 @@ def test_host_pipeline_atlas_rectangles_preserve_the_rest(glyphs):
     assert (atlas[~covered] == -5.).all()
 
 
+def test_host_pipeline_overlapping_rectangles_leave_the_gap_alone(glyphs):
+    """a chunk whose rectangles have the AREA of a contiguous range but are not disjoint -- two glyphs on one cell of a
+    gap-free atlas and one cell nobody writes -- must not take the single-copy path: the free cell keeps the caller's values (it used to
+    come back as whatever the device buffer held)."""
+    sub, xfs, want = glyphs
+    n, cols = 128, 16
+    aw = cols*48
+    atlas = np.full((n//cols*48, aw, 3), -7., np.float32)
+    cell = list(range(n))
+    cell[5] = 4                                                           # glyphs 4 and 5 share cell 4; cell 5 stays free
+    offs = np.array([((c//cols)*48*aw+(c % cols)*48)*3 for c in cell], np.int64)
+    hb = M.HostBatch(sub.select(list(range(n))))
+    try:
+        L.load().msdfhip_set_pipeline_chunk(128)
+        hb.generate_host(M.MODE_MSDF, 48, 48, xfs[:n], out=atlas, out_offsets=offs, row_stride=np.full(n, aw*3, np.int32))
+    finally:
+        L.load().msdfhip_set_pipeline_chunk(0)
+        hb.close()
+    for g in range(n):
+        c = cell[g]
+        rect = atlas[(c//cols)*48:(c//cols)*48+48, (c % cols)*48:(c % cols)*48+48]
+        if g == 4:
+            assert (bits(rect) == bits(want[4])).all() or (bits(rect) == bits(want[5])).all()   # shared cell: one of the two, whole
+        elif g != 5:
+            assert (bits(rect) == bits(want[g])).all(), g
+    assert (atlas[0:48, 5*48:6*48] == -7.).all(), "the free cell was overwritten"
+
+
 def test_bytes_pipeline_matches_pixel_float_to_byte(glyphs, oracle):
     sub, xfs, want = glyphs
     n = 1024
@@ -184,3 +212,27 @@ def test_sharded_into_one_interleaved_atlas(glyphs):
         y0, x0 = (g % 8)*48+1, (g//8)*48
         assert (bits(atlas[y0:y0+48, x0:x0+48]) == bits(want[g])).all(), g
     assert (atlas[0] == -3.).all() and (atlas[-1] == -3.).all()
+
+
+def test_trim_returns_the_pooled_memory(glyphs):
+    """msdfhip_trim: the pools of the host-pointer entry points grow to the peak concurrency and are otherwise kept; a process that is
+    done with a burst hands them back, and the next call simply builds new ones."""
+    import torch
+    sub, xfs, want = glyphs
+    part = sub.select(list(range(512)))
+    hb = M.HostBatch(part)
+    out = hb.generate_host(M.MODE_MSDF, 48, 48, xfs[:512])
+    one = np.zeros((48, 48, 3), np.float32)
+    M.generate_msdf(one, sub.shape(3), M.SDFTransformation.from_xf(xfs[3]))
+    hb.close()
+    torch.cuda.synchronize()
+    before = torch.cuda.mem_get_info()[0]
+    assert L.load().msdfhip_trim() == 0
+    after = torch.cuda.mem_get_info()[0]
+    assert after > before+(8 << 20), "trim returned only %d bytes of device memory" % (after-before)
+    hb = M.HostBatch(part)                                                    # the pools rebuild on demand
+    again = hb.generate_host(M.MODE_MSDF, 48, 48, xfs[:512])
+    hb.close()
+    assert (bits(again) == bits(out)).all() and (bits(out) == bits(want[:512])).all()
+    M.generate_msdf(one, sub.shape(3), M.SDFTransformation.from_xf(xfs[3]))
+    assert (bits(one) == bits(want[3])).all()
