@@ -136,6 +136,10 @@ int msdfhip_generate_mtsdf(float *pixels, int width, int height, int row_stride,
 int msdfhip_error_correction(int channels, float *pixels, int width, int height, int row_stride, int flip,
                              const int32_t *contour_offsets, int n_contours, const double *points, const uint8_t *types, const uint8_t *colors,
                              const double *xf, const MsdfHipConfig *cfg, uint8_t *stencil);
+/* msdfFastDistanceErrorCorrection (protect_all = 0) / msdfFastEdgeErrorCorrection (protect_all = 1): findErrors(sdf) + apply with no shape.
+ *   replaces core/msdf-error-correction.cpp:50-59, 87-113 (declared core/msdf-error-correction.h:21-34). */
+int msdfhip_error_correction_shapeless(int channels, float *pixels, int width, int height, int row_stride, const double *xf,
+                                       double min_deviation_ratio, int protect_all);
 
 /* distanceSignCorrection(sdf, shape, projection, sdfZeroValue, fillRule) on an existing 1-, 3- or 4-channel bitmap, in place.
  *   replaces core/rasterization.cpp:19-92 (declared core/rasterization.h:17-19; the legacy overloads :21-27 forward).

@@ -205,6 +205,24 @@ def msdf_error_correction(sdf, shape, transformation, config: Optional[MSDFGener
     return sdf
 
 
+def _fast_error_correction(sdf, transformation, min_deviation_ratio, protect_all):
+    assert sdf.dtype == np.float32 and sdf.ndim == 3 and sdf.shape[2] in (3, 4) and sdf.flags.c_contiguous
+    h, w, n = sdf.shape
+    xf = np.ascontiguousarray(transformation.xf6(), np.float64)
+    _lib.check(_lib.load().msdfhip_error_correction_shapeless(n, _lib.ptr(sdf, _lib._fp), w, h, w*n, _lib.ptr(xf, _lib._dp), float(min_deviation_ratio), int(protect_all)))
+    return sdf
+
+
+def msdf_fast_distance_error_correction(sdf, transformation, min_deviation_ratio=DEFAULT_MIN_DEVIATION_RATIO):
+    """msdfFastDistanceErrorCorrection(sdf, transformation, minDeviationRatio), core/msdf-error-correction.h:21-26: findErrors(sdf) + apply, no shape."""
+    return _fast_error_correction(sdf, transformation, min_deviation_ratio, False)
+
+
+def msdf_fast_edge_error_correction(sdf, transformation, min_deviation_ratio=DEFAULT_MIN_DEVIATION_RATIO):
+    """msdfFastEdgeErrorCorrection(sdf, transformation, minDeviationRatio), core/msdf-error-correction.h:29-34: protectAll + findErrors(sdf) + apply."""
+    return _fast_error_correction(sdf, transformation, min_deviation_ratio, True)
+
+
 def distance_sign_correction(sdf, shape, projection, sdf_zero_value=.5, fill_rule=FILL_NONZERO, y_orientation=Y_UPWARD):
     """distanceSignCorrection (core/rasterization.h:15-19), in place on a 1-, 3- or 4-channel bitmap. `projection` is a Projection
     (or anything with one: SDFTransformation)."""

@@ -462,8 +462,41 @@ void destroySideStreams(const MsdfHipBatch *b) {
     b->forkEvent = NULL;
 }
 
+// A batch with a glyph whose survivor lists exceed a CU's LDS: every glyph of it takes the list-free kernel (see k_distance_unculled).
+template <int SEL, bool OVERLAP>
+int launchUnculled(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, hipStream_t stream) {
+    const int tilesX = (w+TILE-1)/TILE, tiles = tilesX*((h+TILE-1)/TILE);
+    const size_t items = (size_t) b->nGlyphs*(size_t) tiles;
+    if (items == 0)
+        return MSDFHIP_OK;
+    if (items > 0xfffffff0ull)
+        return fail(MSDFHIP_ERR_INVALID, "launch of %zu tiles exceeds the work-queue range; split the batch", items);
+    const size_t resBytes = OVERLAP ? (size_t) (b->maxContours > 0 ? b->maxContours : 1)*SelTraits<SEL>::NCH*WAVE*sizeof(double) : 0;
+    // workgroups: two per SIMD, fewer if their workspace slices would exceed 2 GB
+    size_t groups = (size_t) residentSlots(b->device)*4u*2u;
+    if (resBytes && groups*resBytes > ((size_t) 2<<30))
+        groups = ((size_t) 2<<30)/resBytes;
+    groups = groups < 1 ? 1 : groups > items ? items : groups;
+    double *gres = NULL;
+    int rc = ensureGres(b, groups*resBytes+256, &gres);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    unsigned *counter = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(gres)+groups*resBytes);
+    HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), stream));
+    const BatchView v = viewOf(b);
+    hipLaunchKernelGGL((k_distance_unculled<SEL, OVERLAP>), dim3((unsigned) groups), dim3(WAVE), 0, stream, v.nGlyphs, v.glyphContourOffsets, v.contourOffsets, v.recs,
+                       v.windings, dGlyphs, w, h, tilesX, tiles, dst, toScratch, gres, resBytes/sizeof(double), counter, (unsigned) items);
+    HIPCHK(hipGetLastError());
+    return MSDFHIP_OK;
+}
+
 template <int SEL>
 int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, bool overlap, hipStream_t stream) {
+    if (tileListBytes(b->maxEdges, b->maxContours, true) > (size_t) gLdsLimit.load()) {   // the reference cannot fail on a large shape; neither may this
+        ScopedTimer timer(stream, 0);
+        return overlap && b->maxContours > 1 ? launchUnculled<SEL, true>(b, dGlyphs, w, h, dst, toScratch, stream)
+                                             : launchUnculled<SEL, false>(b, dGlyphs, w, h, dst, toScratch, stream);
+    }
     LdsPlan plan;
     int rc = planLds(b, SelTraits<SEL>::NCH, overlap, plan);
     if (rc != MSDFHIP_OK)
@@ -666,6 +699,14 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     const size_t coopLds = (size_t) slotOffset*sizeof(double)+(size_t) (slotCap+mergedCap)*sizeof(PBSlot);
     const size_t queryLds = resLanes > coopLds ? resLanes : coopLds;
     const size_t fastLds = ecFastLdsBytes(b->maxEdges, N);
+    if (GRES && queryLds > (size_t) gLdsLimit.load() && fastLds <= (size_t) gLdsLimit.load()) {
+        // More contours than k_ec_query's per-contour LDS scratch holds (~19 000): the full per-texel pipeline with its scratch in the global
+        // workspace takes every texel -- slow, but a valid shape is corrected instead of refused (the reference cannot fail either).
+        hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowGrid), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
+                           (const EcCandidate *) NULL, 0u, 0, gres, gresStride);
+        HIPCHK(hipGetLastError());
+        return MSDFHIP_OK;
+    }
     if (fastLds > (size_t) gLdsLimit.load() || queryLds > (size_t) gLdsLimit.load())
         return fail(MSDFHIP_ERR_TOO_COMPLEX, "a glyph has %d contours / %d edges: the error-correction pass needs %zu B of LDS per wavefront, device limit is %d B",
                     b->maxContours, b->maxEdges, fastLds > queryLds ? fastLds : queryLds, gLdsLimit.load());
@@ -2315,6 +2356,22 @@ int msdfhip_error_correction(int channels, float *pixels, int w, int h, int rowS
     return singleShape(channels, channels, OP_ERROR_CORRECTION, pixels, w, h, rowStride, flip, co, nC, points, types, colors, xf, cfg, stencil);
 }
 
+// msdfFastDistanceErrorCorrection / msdfFastEdgeErrorCorrection (core/msdf-error-correction.cpp:50-59, 87-113): findErrors(sdf) + apply with
+// no shape -- no corner / edge protection, optionally protectAll() first. That is msdfErrorCorrectionInner on an empty shape with
+// mode INDISCRIMINATE (nothing protected) or EDGE_ONLY (protectAll) and DO_NOT_CHECK_DISTANCE, so the same kernels run it.
+int msdfhip_error_correction_shapeless(int channels, float *pixels, int w, int h, int rowStride, const double *xf, double minDeviationRatio, int protectAll) {
+    if (channels != 3 && channels != 4)
+        return fail(MSDFHIP_ERR_INVALID, "channels %d (must be 3 or 4)", channels);
+    static const int32_t noContours[1] = { 0 };
+    MsdfHipConfig cfg;
+    msdfhip_default_config(&cfg);
+    cfg.overlap_support = 0;
+    cfg.ec_mode = protectAll ? MSDFHIP_EC_EDGE_ONLY : MSDFHIP_EC_INDISCRIMINATE;
+    cfg.ec_distance_check = MSDFHIP_DO_NOT_CHECK_DISTANCE;
+    cfg.min_deviation_ratio = minDeviationRatio;
+    return singleShape(channels, channels, OP_ERROR_CORRECTION, pixels, w, h, rowStride, 0, noContours, 0, NULL, NULL, NULL, xf, &cfg, NULL);
+}
+
 int msdfhip_distance_sign_correction(int channels, float *pixels, int w, int h, int rowStride, int flip, const int32_t *co, int nC, const double *points,
                                      const uint8_t *types, const uint8_t *colors, const double *xf, float zero, int fillRule) {
     if (channels != 1 && channels != 3 && channels != 4)
@@ -2381,20 +2438,33 @@ int msdfhip_shape_distance(int selector, int overlap, const int32_t *co, int nC,
     if (rc != MSDFHIP_OK)
         return rc;
     const int nch = channelsOf(selector);
-    const size_t lds = overlap ? (size_t) b->maxContours*nch*WAVE*sizeof(double) : 0;
-    double *dPts = NULL, *dOut = NULL;
+    size_t lds = overlap ? (size_t) b->maxContours*nch*WAVE*sizeof(double) : 0;
+    double *dPts = NULL, *dOut = NULL, *gres = NULL;
+    size_t gresStride = 0;
+    int chunkPoints = nPoints;
     hipError_t e = hipSuccess;
-    if (lds > (size_t) gLdsLimit.load())
-        rc = fail(MSDFHIP_ERR_TOO_COMPLEX, "%d contours need %zu B of LDS", b->maxContours, lds);
+    if (lds > (size_t) gLdsLimit.load()) {                       // more contours than a CU's LDS holds scratch for: a global workspace slice per workgroup
+        gresStride = lds/sizeof(double);
+        size_t groups = (size_t) (nPoints+WAVE-1)/WAVE;
+        if (groups*lds > ((size_t) 2<<30))                       // bounded workspace: the points go through in several launches
+            groups = ((size_t) 2<<30)/lds > 0 ? ((size_t) 2<<30)/lds : 1;
+        chunkPoints = (int) (groups*WAVE < (size_t) nPoints ? groups*WAVE : (size_t) nPoints);
+        rc = ensureGres(b, groups*lds, &gres);
+        lds = 0;
+    }
     if (rc == MSDFHIP_OK) {
         e = hipMalloc((void **) &dPts, sizeof(double)*2*(size_t) nPoints);
         if (e == hipSuccess) e = hipMalloc((void **) &dOut, sizeof(double)*4*(size_t) nPoints);
         if (e == hipSuccess) e = hipMemcpy(dPts, pts, sizeof(double)*2*(size_t) nPoints, hipMemcpyHostToDevice);
     }
     if (rc == MSDFHIP_OK && e == hipSuccess) {
-        const dim3 grid((nPoints+WAVE-1)/WAVE), block(WAVE);
+        const dim3 block(WAVE);
         const BatchView v = viewOf(b);
-        #define LAUNCH_SD(S, O) do { rc = setLds(k_shape_distance<S, O>, lds); if (rc == MSDFHIP_OK) hipLaunchKernelGGL((k_shape_distance<S, O>), grid, block, lds, 0, v, nPoints, dPts, dOut); } while (0)
+        #define LAUNCH_SD(S, O) do { rc = setLds(k_shape_distance<S, O>, lds); \
+            for (int base = 0; rc == MSDFHIP_OK && base < nPoints; base += chunkPoints) { \
+                const int n = nPoints-base < chunkPoints ? nPoints-base : chunkPoints; \
+                hipLaunchKernelGGL((k_shape_distance<S, O>), dim3((n+WAVE-1)/WAVE), block, lds, 0, v, n, dPts+2*(size_t) base, dOut+4*(size_t) base, gres, gresStride); \
+            } } while (0)
         switch (selector*2+(overlap ? 1 : 0)) {
             case 2: LAUNCH_SD(1, false); break;
             case 3: LAUNCH_SD(1, true); break;

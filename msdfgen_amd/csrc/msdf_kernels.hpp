@@ -1575,11 +1575,59 @@ __global__ void k_sdf_error_sum(const double *lines, int nGlyphs, int height, in
 
 // ------------------------------------------------------------------------------------------------- distance queries
 
+// The form that NEVER refuses a shape (core/msdfgen.cpp:78-106 returns void for any Shape): no survivor lists, no LDS at all. A glyph whose
+// lists would not fit a CU's LDS (> ~40 000 edges or > ~10 000 contours; k_distance's phase 1 needs one list entry per edge) is rendered
+// by walking ALL its edges per tile, straight from the CSR offsets, with the per-texel relevance vote as the only cull and the combiner's
+// per-contour distances in a global workspace slice per workgroup. Persistent: a bounded pool of workgroups (the workspace is
+// contours x 1.5 KB per workgroup) draws tiles from one counter. Orders of magnitude slower per edge than the culled path -- it exists so
+// that a valid input is rendered instead of returning MSDFHIP_ERR_TOO_COMPLEX.
+template <int SEL, bool OVERLAP>
+__global__ void __launch_bounds__(WAVE, 2)
+k_distance_unculled(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const int32_t *__restrict__ contourOffsets, const EdgeRec *__restrict__ recs,
+                    const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, int tilesX, int tilesPerGlyph,
+                    float *__restrict__ dst, int toScratch, double *__restrict__ gres, size_t gresStride, unsigned *__restrict__ counter, unsigned items) {
+    enum { NCH = SelTraits<SEL>::NCH };
+    const int lane = threadIdx.x;
+    for (;;) {
+        unsigned item = 0;
+        if (lane == 0)
+            item = atomicAdd(counter, 1u);
+        item = (unsigned) __builtin_amdgcn_readfirstlane((int) item);
+        if (item >= items)
+            return;
+        const int g = (int) (item/(unsigned) tilesPerGlyph), tile = (int) (item%(unsigned) tilesPerGlyph);
+        const int c0 = glyphContourOffsets[g], C = glyphContourOffsets[g+1]-c0;
+        const int32_t *coff = contourOffsets+c0;
+        const EdgeRec *rec = recs+coff[0];
+        const MsdfHipGlyph gd = glyphs[g];
+        const Xform t = loadXform(gd);
+        const int tx = tile%tilesX, ty = tile/tilesX;
+        const int x = tx*TILE+(lane&(TILE-1)), y = ty*TILE+(lane>>3);
+        if (x >= width || y >= height)
+            continue;
+        const V2 p = unproject(t, mk(x+.5, y+.5));                   // msdfgen.cpp:68
+        EdgesAll edges;
+        edges.coff = coff;
+        double d[NCH];
+        if (OVERLAP)
+            shapeDistanceOverlap<SEL>(rec, edges, windings+c0, C, p, gres+(size_t) blockIdx.x*gresStride+lane, WAVE, d);
+        else
+            shapeDistanceSimple<SEL>(rec, edges, C, p, d);
+        const int yn = gd.flip ? height-1-y : y;
+        float *px = toScratch ? dst+(((size_t) g*height+yn)*width+x)*NCH : dst+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) NCH*x;
+        for (int ch = 0; ch < NCH; ++ch)
+            px[ch] = mapDistance(t, d[ch]);
+    }
+}
+
+// res: the overlapping combiner's per-contour scratch -- LDS (dynamic shared memory sized by the host) or, for shapes with more contours
+// than a CU's LDS holds, a global workspace slice per workgroup (gres != NULL).
 template <int SEL, bool OVERLAP>
 __global__ void __launch_bounds__(WAVE)
-k_shape_distance(BatchView batch, int nPoints, const double *pts, double *out) {
+k_shape_distance(BatchView batch, int nPoints, const double *pts, double *out, double *gres, size_t gresStride) {
     enum { NCH = SelTraits<SEL>::NCH };
-    extern __shared__ double smem[];
+    extern __shared__ double smemSd[];
+    double *smem = gres ? gres+(size_t) blockIdx.x*gresStride : smemSd;
     const int i = blockIdx.x*WAVE+threadIdx.x;
     if (i >= nPoints)
         return;

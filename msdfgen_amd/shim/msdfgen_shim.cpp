@@ -210,6 +210,29 @@ void msdfErrorCorrection(const BitmapSection<float, 4> &sdf, const Shape &shape,
     correct<4>(sdf, shape, SDFTransformation(projection, range), config);
 }
 
+// ---- core/msdf-error-correction.h:21-34: the shapeless passes (findErrors(sdf) + apply, core/msdf-error-correction.cpp:50-59)
+namespace {
+template <int N>
+void correctShapeless(const BitmapSection<float, N> &sdf, const SDFTransformation &transformation, double minDeviationRatio, bool protectAll) {
+    double xf[6];
+    transformationToXf(transformation, xf);
+    check(msdfhip_error_correction_shapeless(N, sdf.pixels, sdf.width, sdf.height, sdf.rowStride, xf, minDeviationRatio, protectAll ? 1 : 0),
+          protectAll ? "msdfFastEdgeErrorCorrection" : "msdfFastDistanceErrorCorrection");
+}
+}
+void msdfFastDistanceErrorCorrection(const BitmapSection<float, 3> &sdf, const SDFTransformation &transformation, double minDeviationRatio) { correctShapeless<3>(sdf, transformation, minDeviationRatio, false); }
+void msdfFastDistanceErrorCorrection(const BitmapSection<float, 4> &sdf, const SDFTransformation &transformation, double minDeviationRatio) { correctShapeless<4>(sdf, transformation, minDeviationRatio, false); }
+void msdfFastDistanceErrorCorrection(const BitmapSection<float, 3> &sdf, const Projection &projection, Range range, double minDeviationRatio) { correctShapeless<3>(sdf, SDFTransformation(projection, range), minDeviationRatio, false); }
+void msdfFastDistanceErrorCorrection(const BitmapSection<float, 4> &sdf, const Projection &projection, Range range, double minDeviationRatio) { correctShapeless<4>(sdf, SDFTransformation(projection, range), minDeviationRatio, false); }
+void msdfFastDistanceErrorCorrection(const BitmapSection<float, 3> &sdf, Range pxRange, double minDeviationRatio) { correctShapeless<3>(sdf, SDFTransformation(Projection(), pxRange), minDeviationRatio, false); }
+void msdfFastDistanceErrorCorrection(const BitmapSection<float, 4> &sdf, Range pxRange, double minDeviationRatio) { correctShapeless<4>(sdf, SDFTransformation(Projection(), pxRange), minDeviationRatio, false); }
+void msdfFastEdgeErrorCorrection(const BitmapSection<float, 3> &sdf, const SDFTransformation &transformation, double minDeviationRatio) { correctShapeless<3>(sdf, transformation, minDeviationRatio, true); }
+void msdfFastEdgeErrorCorrection(const BitmapSection<float, 4> &sdf, const SDFTransformation &transformation, double minDeviationRatio) { correctShapeless<4>(sdf, transformation, minDeviationRatio, true); }
+void msdfFastEdgeErrorCorrection(const BitmapSection<float, 3> &sdf, const Projection &projection, Range range, double minDeviationRatio) { correctShapeless<3>(sdf, SDFTransformation(projection, range), minDeviationRatio, true); }
+void msdfFastEdgeErrorCorrection(const BitmapSection<float, 4> &sdf, const Projection &projection, Range range, double minDeviationRatio) { correctShapeless<4>(sdf, SDFTransformation(projection, range), minDeviationRatio, true); }
+void msdfFastEdgeErrorCorrection(const BitmapSection<float, 3> &sdf, Range pxRange, double minDeviationRatio) { correctShapeless<3>(sdf, SDFTransformation(Projection(), pxRange), minDeviationRatio, true); }
+void msdfFastEdgeErrorCorrection(const BitmapSection<float, 4> &sdf, Range pxRange, double minDeviationRatio) { correctShapeless<4>(sdf, SDFTransformation(Projection(), pxRange), minDeviationRatio, true); }
+
 // ---- core/render-sdf.h:12-22: together these replace the whole of core/render-sdf.cpp
 namespace {
 template <int NO, int NS>

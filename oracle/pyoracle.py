@@ -297,6 +297,8 @@ class Ref:
         L.ref_generate.argtypes = [vp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _bp]
         L.ref_error_correction.argtypes = [vp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _bp]
         L.ref_ec_stages.argtypes = [vp, C.c_int, _fp, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_double, _bp]
+        if hasattr(L, "ref_fast_error_correction"):                 # (a prebuilt _ref from before round 3 lacks it)
+            L.ref_fast_error_correction.argtypes = [C.c_int, _fp, C.c_int, C.c_int, C.c_int, _dp, C.c_double, C.c_int]
         L.ref_signed_distance.argtypes = [C.c_int, _dp, C.c_double, C.c_double, _dp]
         L.ref_solve_cubic.argtypes = [_dp, C.c_double, C.c_double, C.c_double, C.c_double]
         L.ref_solve_quadratic.argtypes = [_dp, C.c_double, C.c_double, C.c_double]
@@ -381,6 +383,14 @@ class Ref:
                                       _p(stencil, _bp) if stencil is not None else None)
         if own:
             self.free(hd)
+        return px
+
+    def fast_error_correction(self, pixels, xf, min_dev=DEFAULT_RATIO, protect_all=False):
+        """msdfFastDistanceErrorCorrection (protect_all False) / msdfFastEdgeErrorCorrection (True), core/msdf-error-correction.h:21-34."""
+        px = np.array(pixels, np.float32, order="C")
+        h, w, n = px.shape
+        xf = _xf(xf)
+        self.lib.ref_fast_error_correction(n, _p(px, _fp), w, h, w*n, _p(xf, _dp), C.c_double(min_dev), int(protect_all))
         return px
 
     def ec_stages(self, shape, pixels, xf, overlap=True, min_dev=DEFAULT_RATIO, min_imp=DEFAULT_RATIO):

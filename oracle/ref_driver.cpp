@@ -165,6 +165,18 @@ void ref_error_correction(void *s, int channels, float *pixels, int w, int h, in
         msdfErrorCorrection(BitmapSection<float, 4>(pixels, w, h, rowStride, yo), *(Shape *) s, t, cfg);
 }
 
+/// msdfFastDistanceErrorCorrection / msdfFastEdgeErrorCorrection (core/msdf-error-correction.h:21-34): the shapeless passes.
+void ref_fast_error_correction(int channels, float *pixels, int w, int h, int rowStride, const double *xf, double minDev, int protectAll) {
+    SDFTransformation t(Projection(Vector2(xf[0], xf[1]), Vector2(xf[2], xf[3])), DistanceMapping(Range(xf[4], xf[5])));
+    if (channels == 3) {
+        BitmapSection<float, 3> sdf(pixels, w, h, rowStride);
+        if (protectAll) msdfFastEdgeErrorCorrection(sdf, t, minDev); else msdfFastDistanceErrorCorrection(sdf, t, minDev);
+    } else {
+        BitmapSection<float, 4> sdf(pixels, w, h, rowStride);
+        if (protectAll) msdfFastEdgeErrorCorrection(sdf, t, minDev); else msdfFastDistanceErrorCorrection(sdf, t, minDev);
+    }
+}
+
 /// Stencil after each stage of the default pipeline (core/msdf-error-correction.cpp:12-48), for stage-by-stage diffs.
 /// stages: w*h bytes each: [0] after protectCorners, [1] after protectEdges, [2] after findErrors(sdf), [3] after protectAll+findErrors(sdf,shape)
 void ref_ec_stages(void *s, int channels, const float *pixels, int w, int h, const double *xf, int overlap, double minDev, double minImp, unsigned char *stages) {

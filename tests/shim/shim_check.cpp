@@ -45,6 +45,17 @@ int main(int argc, char **argv) {
                 default: renderSDF(preview, BitmapConstSection<float, 4>(field.data(), w, h), Range(range), .5f); break;
             }
             simulate8bit(preview);
+        } else if (scanline == 7 || scanline == 8) {                          // the shapeless passes (core/msdf-error-correction.h:21-34) on an uncorrected field
+            MSDFGeneratorConfig gen(true, ErrorCorrectionConfig(ErrorCorrectionConfig::DISABLED));
+            if (mode == 3) {
+                BitmapSection<float, 3> b(px.data(), w, h, yo);
+                generateMSDF(b, shape, t, gen);
+                if (scanline == 7) msdfFastDistanceErrorCorrection(b, t); else msdfFastEdgeErrorCorrection(b, Projection(scale, Vector2(tx, ty)), Range(range), 1.5);
+            } else {
+                BitmapSection<float, 4> b(px.data(), w, h, yo);
+                generateMTSDF(b, shape, t, gen);
+                if (scanline == 7) msdfFastDistanceErrorCorrection(b, Projection(scale, Vector2(tx, ty)), Range(range)); else msdfFastEdgeErrorCorrection(b, t, 1.5);
+            }
         } else if (scanline) {
             const FillRule rule = (FillRule) (scanline-1);
             const Projection proj(scale, Vector2(tx, ty));

@@ -777,3 +777,90 @@ def test_stencil_rows_of_the_batched_paths_for_y_downward_bitmaps(ref):
         hb.close()
         close(hgot, want, "HostBatch.generate_host y=%d" % y)
         assert (hst == want_st).all(), "HostBatch.generate_host: stencil rows, y_orientation %d" % y
+
+
+def test_shapeless_error_correction_entry_points(ref, oracle):
+    """msdfFastDistanceErrorCorrection / msdfFastEdgeErrorCorrection (core/msdf-error-correction.cpp:50-59, 87-113; VERDICT r2 missing #5):
+    findErrors(sdf) + apply without a shape, on pre-correction fields of real glyphs (msdf and mtsdf), several deviation ratios -- bit for
+    bit against the COMPILED REFERENCE's own functions, and against the oracle's general pass on an empty shape (the identity the device
+    path relies on: mode INDISCRIMINATE resp. EDGE_ONLY with DO_NOT_CHECK_DISTANCE)."""
+    z = load_npz("latin.npz")
+    batch = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
+                       z["colors"].astype(np.int32), z["inverse_y"], [str(n) for n in z["names"]])
+    empty = FlatShape.from_contours([])
+    changed = 0
+    for name in ("U+0040", "U+0067", "U+0026", "U+0057"):
+        g = batch.names.index(name)
+        xf = z["xf64"][g]
+        t = M.SDFTransformation.from_xf(xf)
+        for mode, n in ((3, 3), (4, 4)):
+            pre = gen(mode, batch.shape(g), 64, 60, xf, cfg(ec_mode=M.EC_DISABLED))
+            for ratio in (1.11111111111111111, 1.0, 2.5):
+                for protect_all, fn in ((False, M.msdf_fast_distance_error_correction), (True, M.msdf_fast_edge_error_correction)):
+                    want = ref.fast_error_correction(pre, xf, ratio, protect_all)
+                    got = fn(pre.copy(), t, ratio)
+                    assert (bits(got) == bits(want)).all(), (name, mode, ratio, protect_all, int((bits(got) != bits(want)).sum()))
+                    same = oracle.error_correction(empty, pre, xf, overlap=False, ec_mode=M.EC_EDGE_ONLY if protect_all else M.EC_INDISCRIMINATE,
+                                                   ec_dist=M.DO_NOT_CHECK_DISTANCE, min_dev=ratio)
+                    assert (bits(same) == bits(want)).all()
+                    changed += int((bits(got) != bits(pre)).any())
+    assert changed >= 8                                                        # the passes do change these fields
+
+
+def _ring(cx, cy, r, n, phase=0., flip=False, quad_every=3):
+    """Closed polygon ring of n edges around (cx, cy); every quad_every-th edge a quadratic bulge. Colours cycle (corners everywhere)."""
+    ang = phase+np.arange(n+1)*(2*np.pi/n)
+    if flip:
+        ang = ang[::-1]
+    pts = [(cx+r*np.cos(a)*(1+.03*np.sin(7*a)), cy+r*np.sin(a)*(1+.03*np.cos(5*a))) for a in ang[:-1]]
+    edges = []
+    for k in range(n):
+        p0, p1 = pts[k], pts[(k+1) % n]
+        col = (6, 5, 3)[k % 3]
+        if k % quad_every == 0:
+            mx, my = .5*(p0[0]+p1[0]), .5*(p0[1]+p1[1])
+            edges.append((col, p0, (mx+(mx-cx)*.01, my+(my-cy)*.01), p1))
+        else:
+            edges.append((col, p0, p1))
+    return edges
+
+
+def test_shapes_beyond_the_lds_lists_are_rendered_not_refused(oracle):
+    """The reference's generators return void for ANY Shape (core/msdfgen.cpp:78-106); round 2 refused glyphs whose survivor lists exceed a
+    CU's LDS (MSDFHIP_ERR_TOO_COMPLEX beyond ~40 000 edges). They now take the list-free kernel (k_distance_unculled), and beyond ~19 000
+    contours the error-correction pass takes the full per-texel pipeline with its scratch in the global workspace. Against the oracle:
+      * 61 440 edges in 24 nested / overlapping rings, msdf with the default correction and mtsdf (single-shape call);
+      * 12 000 contours (36 000 edges), msdf default correction, inside a BATCH next to an ordinary glyph;
+      * 21 000 contours (63 000 edges): also past the error-correction kernel's per-contour LDS scratch; plus a distance query
+        (msdfhip_shape_distance) on the same shape, whose combiner scratch does not fit LDS either."""
+    big = FlatShape.from_contours([_ring(.5+.01*(c % 5), .5-.008*(c % 7), .46-.017*c, 2560, phase=.1*c, flip=bool(c % 3 == 1)) for c in range(24)])
+    assert big.n_edges == 61440
+    xf = autoframe((0, 0, 1, 1), 40, 36, 4)
+    close(gen(3, big, 40, 36, xf), oracle.generate(big, 3, 40, 36, xf), "61 440 edges msdf")
+    close(gen(4, big, 40, 36, xf, cfg(ec_mode=M.EC_DISABLED)), oracle.generate(big, 4, 40, 36, xf, ec_mode=0), "61 440 edges mtsdf")
+
+    def grid_of_triangles(n, cols):
+        out = []
+        for i in range(n):
+            cx, cy, r = (i % cols+.5)/cols, (i//cols+.5)/cols, .45/cols
+            pts = [(cx+r*np.cos(a+i), cy+r*np.sin(a+i)) for a in (0., 2.1, 4.2)]
+            if i % 4 == 0:
+                pts = pts[::-1]
+            out.append([((6, 5, 3)[k], pts[k], pts[(k+1) % 3]) for k in range(3)])
+        return FlatShape.from_contours(out)
+    many = grid_of_triangles(12000, 110)
+    small = FlatShape.from_contours([_ring(.5, .5, .4, 12), _ring(.5, .5, .2, 9, flip=True)])
+    xf2 = autoframe((0, 0, 1, 1), 24, 24, 2)
+    gb = M.GlyphBatch(ShapeBatch.from_shapes([small, many, small]))
+    got = gb.generate(3, 24, 24, np.stack([xf2]*3)).cpu().numpy()
+    gb.close()
+    close(got[1], oracle.generate(many, 3, 24, 24, xf2), "12 000 contours in a batch")
+    close(got[0], oracle.generate(small, 3, 24, 24, xf2), "ordinary glyph next to it")
+    assert (bits(got[2]) == bits(got[0])).all()
+    huge = grid_of_triangles(21000, 145)
+    xf3 = autoframe((0, 0, 1, 1), 16, 16, 2)
+    close(gen(3, huge, 16, 16, xf3), oracle.generate(huge, 3, 16, 16, xf3), "21 000 contours msdf + correction")
+    pts = np.stack([np.linspace(.1, .9, 64), np.linspace(.9, .2, 64)], 1)
+    got_d = M.shape_distance(huge, 3, True, pts)
+    want_d = oracle.shape_distance(huge, 3, True, pts)
+    assert np.abs(got_d[:, :3]-want_d[:, :3]).max() <= 1e-9

@@ -81,3 +81,25 @@ def test_reference_client_render_sdf_through_cpp_shim(tmp_path, oracle, mode):
     field = oracle.generate(s, mode, w, h, [scale, scale, tx, ty, -.5*rng, .5*rng])
     want = oracle.simulate_8bit(oracle.render_sdf(field, 2*w, 2*h, 1, -.5*rng, .5*rng, .5))
     assert (bits(got) == bits(want)).all()
+
+
+@pytest.mark.parametrize("mode,which", [(3, 7), (4, 7), (3, 8), (4, 8)])
+def test_reference_client_shapeless_error_correction_through_cpp_shim(tmp_path, oracle, ref, mode, which):
+    """msdfgen::msdfFastDistanceErrorCorrection / msdfFastEdgeErrorCorrection (core/msdf-error-correction.h:21-34) through the shim, all three
+    overload families (SDFTransformation; Projection + Range; default and explicit minDeviationRatio) -- against the compiled reference."""
+    if not os.path.exists(BIN):
+        pytest.skip("tests/shim/shim_check not built (needs the msdfgen headers)")
+    z = load_npz("shape_a.npz")
+    s = FlatShape(z["contour_offsets"], z["points"], z["types"], z["colors"])
+    desc = tmp_path/"a.txt"
+    desc.write_text(str(z["desc"]))
+    out = tmp_path/"a.bin"
+    w, h = 40, 32
+    scale, tx, ty, rng = 2.75, .625, .71875, 1.5
+    r = subprocess.run([BIN, str(desc), str(out), str(mode), str(w), str(h), repr(scale), repr(tx), repr(ty), repr(rng), "0", str(which)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(out, np.float32).reshape(h, w, mode)
+    xf = [scale, scale, tx, ty, -.5*rng, .5*rng]
+    pre = oracle.generate(s, mode, w, h, xf, ec_mode=0)
+    want = ref.fast_error_correction(pre, xf, 1.11111111111111111 if which == 7 else 1.5, which == 8)
+    assert (bits(got) == bits(want)).all()
