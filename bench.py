@@ -75,12 +75,11 @@ def global_list(batch, xfs, glyphs_per_gpu, world):
 
 
 def rank_shard(batch, xfs, glyphs_per_gpu, world, rank, w, h):
-    """(sub-batch, xfs, (lo, hi), bounds) of `rank`: contiguous cut of the global list balanced by W*H*E (msdfgen_amd.shard)."""
-    from msdfgen_amd.shard import partition_contiguous
+    """(sub-batch, xfs, (lo, hi), bounds) of `rank`: contiguous cut of the global list into ranges of equal modelled cost (msdfgen_amd.shard:
+    per-class cost model fitted to measured kernel times, profiles/r03_cost_model.json)."""
+    from msdfgen_amd.shard import partition_contiguous, glyph_costs
     idx = global_list(batch, xfs, glyphs_per_gpu, world)
-    gco, co = batch.glyph_contour_offsets, batch.contour_offsets
-    edges = (co[gco[1:]]-co[gco[:-1]]).astype(np.float64)[idx]
-    bounds = partition_contiguous(float(w*h)*(edges+1.), world)
+    bounds = partition_contiguous(glyph_costs(batch, w, h)[idx], world)
     lo, hi = int(bounds[rank]), int(bounds[rank+1])
     return batch.select(idx[lo:hi]), xfs[idx[lo:hi]], (lo, hi), bounds
 
@@ -139,9 +138,10 @@ def cpu_baseline(batch, xfs, w, h, budget_s=15.):
 
 
 def profile_counters(args, w, h):
-    """Counters of the dominant pass from the separate rocprofv3 --pmc passes of this very command (tools/pmc_traffic.py writes
-    profiles/pmc_traffic.json; counters cannot be collected from inside the timed process). Only used when the committed profile is of
-    this exact workload; the entry says at which commit it was measured."""
+    """Counters of the dominant pass from the separate rocprofv3 --pmc passes of this very command (tools/profile_round.sh; counters cannot be
+    collected from inside the timed process): profiles/pmc_traffic.json = HBM bytes (FETCH_SIZE / WRITE_SIZE) and the calibrated VALU busy
+    fraction of the distance kernels (tools/pmc_report.py: per-class instruction counts x measured cycles per class). Only used when the
+    committed profile is of this exact workload; the entry says at which commit it was measured."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         t = json.load(open(path))
@@ -217,6 +217,48 @@ def end_to_end(M, batch, xfs, w, h, reps=3):
     return res
 
 
+def inprocess(args):
+    """ONE process driving N GPUs: msdfhip_generate_sharded over devices 0..N-1 (one host thread + two streams per device, every device
+    copying its rectangles straight into the caller's pinned buffer) on the same weak-scaling list as the multi-process
+    bench. End to end by construction: host CSR arrays in, host tiles out. N = 1 is the single-GPU end_to_end figure."""
+    import torch
+    import msdfgen_amd as M
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    devices = [0]*args.gpus if args.same_device else list(range(args.gpus))
+    if not args.same_device and have < args.gpus:
+        raise SystemExit("bench.py --gpus %d --inprocess: only %d GPU(s) visible" % (args.gpus, have))
+    M.init(0)
+    w = h = args.size
+    dejavu, xf64, bounds = load_dejavu()
+    idx = global_list(dejavu, xf64, args.glyphs, args.gpus)
+    batch, xfs = dejavu.select(idx), xf64[idx]
+    n = batch.n_glyphs
+    tiles = M.host_alloc((n, h, w, 3))
+    cols = 128
+    atlas = M.host_alloc((((n+cols-1)//cols)*h, cols*w, 3), np.uint8)
+    offs = np.array([((g//cols)*h*cols*w+(g % cols)*w)*3 for g in range(n)], np.int64)
+    t_float, t_bytes = [], []
+    for rep in range(args.warmup+args.steps):
+        t0 = time.perf_counter()
+        M.generate_sharded(devices, batch, M.MODE_MSDF, w, h, xfs, out=tiles)
+        t1 = time.perf_counter()
+        M.generate_sharded(devices, batch, M.MODE_MSDF, w, h, xfs, atlas=atlas, out_offsets=offs, row_stride=cols*w*3)
+        t2 = time.perf_counter()
+        if rep >= args.warmup:
+            t_float.append(t1-t0), t_bytes.append(t2-t1)
+    f, b = float(np.median(t_float)), float(np.median(t_bytes))
+    print(json.dumps({"metric": "MSDF glyphs/sec (64x64, fp32), end to end, one process driving the GPUs", "value": n/f, "unit": "glyphs/s", "n_gpus": args.gpus,
+                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3*f, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                      "data": "synthetic",
+                      "config": {"workload": "msdfhip_generate_sharded: %d x %d distinct DejaVu glyphs msdf %dx%d, library-default config; host CSR arrays -> per-device "
+                                             "upload + digest + kernels + copy back into ONE pinned host buffer" % (args.gpus, args.glyphs, w, h),
+                                 "devices": devices, "parallelism": "one process, one host thread + two streams per device, contiguous ranges of equal modelled cost, no exchange"},
+                      "uint8_atlas": {"glyphs_per_s": n/b, "ms_per_step": 1e3*b},
+                      "note": "median of %d runs after %d warm-up runs%s" % (args.steps, args.warmup, "; REHEARSAL: every 'device' is GPU 0" if args.same_device else "")}))
+    M.host_free(tiles)
+    M.host_free(atlas)
+
+
 def spawn(args):
     """`python bench.py --gpus N` outside torchrun: re-launch under torch.distributed.run, one rank per GPU."""
     if not args.mock and not args.same_device:
@@ -271,8 +313,11 @@ def main():
     ap.add_argument("--mock", action="store_true", help="CPU rehearsal of the multi-rank control path (gloo, no kernels); used by the tests")
     ap.add_argument("--same-device", action="store_true", help="rehearsal of the N > 1 path on a ONE-GPU box: every rank uses cuda:0 and the process "
                                                                 "group is gloo (RCCL refuses two ranks on one device); the number is not a scaling result")
+    ap.add_argument("--inprocess", action="store_true", help="one process drives all --gpus devices through msdfhip_generate_sharded (end to end; prints its own JSON line)")
     args = ap.parse_args()
 
+    if args.inprocess:
+        return inprocess(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -340,7 +385,7 @@ def main():
                                    "step = digest + distance field + error correction, inputs/outputs resident in HBM" % (
                                        w, h, args.glyphs, batch.n_edges/batch.n_glyphs, batch.n_contours/batch.n_glyphs),
                        "glyphs_per_gpu": args.glyphs, "tile": [w, h], "mode": "msdf",
-                       "parallelism": "glyph-sharded x%d by W*H*E (msdfgen_amd.shard), no collective; rank 0 owns glyphs [%d, %d) of %d%s" % (
+                       "parallelism": "glyph-sharded x%d into ranges of equal modelled cost (msdfgen_amd.shard), no collective; rank 0 owns glyphs [%d, %d) of %d%s" % (
                            world, lo, hi, world*args.glyphs, " -- REHEARSAL: all ranks on one GPU, gloo" if args.same_device else "")},
             "roofline": {"bound": "hbm", "kernel": "k_distance<3,...> distance pass (msdf; three launches: 1-contour glyphs / combiner scratch in LDS / in the global workspace)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS,
@@ -351,8 +396,9 @@ def main():
                          "note": "arithmetic intensity ~400 fp64 flop/B: the pass is fp64-VALU bound, not HBM bound (SURVEY.md 8d); "
                                  "the HBM fraction is reported as the contract asks, the binding resource is in `valu_fp64`"},
             "valu_fp64": {"achieved": gflops, "peak": FP64_VECTOR_PEAK_GFLOPS, "unit": "GFLOP/s (algorithmic estimate, SURVEY.md 8d)", "frac": gflops/FP64_VECTOR_PEAK_GFLOPS,
-                          "valu_issue_frac_pmc": prof.get("valu_issue_frac") if prof else None,
-                          "valu_issue_frac_pmc_note": prof.get("valu_issue_note") if prof else None},
+                          "valu_issue_frac_pmc": prof.get("valu_busy_frac_calibrated") if prof else None,
+                          "valu_issue_frac_pmc_per_kernel": prof.get("valu_busy_per_kernel") if prof else None,
+                          "valu_issue_frac_pmc_note": prof.get("valu_busy_note") if prof else None},
             "kernel_ms": {"distance": dist_ms, "error_correction": ec_ms},
         }
         if not args.no_extras:
@@ -362,6 +408,24 @@ def main():
                               "mean": float(err.mean()), "max": float(err.max())}
     gb.close()
     del out
+    if world > 1 and not args.no_extras:
+        # every rank runs the host-output pipeline of ITS shard at the same time (host CSR -> H2D -> kernels -> D2H into pinned memory): the
+        # contention for PCIe / host memory that the resident number cannot show. Aggregate = all glyphs / slowest rank.
+        dist.barrier()
+        mine = end_to_end(M, batch, xfs, w, h, reps=2)
+        vec = torch.tensor([batch.n_glyphs, mine["float_tiles"]["ms_upload_and_digest"]+mine["float_tiles"]["ms_generate_and_copy_back"],
+                            mine["float_tiles"]["ms_upload_and_digest"]+mine["uint8_atlas"]["ms_generate_convert_and_copy_back"]], dtype=torch.float64,
+                           device="cpu" if args.same_device else dev)
+        parts = [torch.zeros_like(vec) for _ in range(world)]
+        dist.all_gather(parts, vec)
+        if rank == 0:
+            rows = [[float(v) for v in p.cpu()] for p in parts]
+            total = sum(r[0] for r in rows)
+            res["end_to_end"] = {"float_tiles": {"glyphs_per_s": total/(max(r[1] for r in rows)*1e-3), "ms_per_rank": [round(r[1], 3) for r in rows]},
+                                 "uint8_atlas": {"glyphs_per_s": total/(max(r[2] for r in rows)*1e-3), "ms_per_rank": [round(r[2], 3) for r in rows]},
+                                 "note": "all %d ranks run msdfhip_batch_create + msdfhip_batch_generate_host / _bytes_host on their shards SIMULTANEOUSLY "
+                                         "(barrier, then each rank its own median of 2 runs); aggregate = all glyphs / slowest rank" % world,
+                                 "rank0": mine}
     if rank == 0 and world == 1 and not args.no_extras:
         res["end_to_end"] = end_to_end(M, batch, xfs, w, h)
         latin, lxf = load_latin()

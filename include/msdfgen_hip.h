@@ -304,6 +304,11 @@ int msdfhip_kernel_timing(double *avg_ms_distance, double *avg_ms_correction, in
  * not in use right now. The pools grow to the peak number of concurrent calls and are otherwise kept for the life of the process. */
 int msdfhip_trim(void);
 
+/* MSDFHIP_DEVICES = "all" | "0,1,...": the devices over which the host-pointer single-shape entry points (msdfhip_generate* etc., and with them
+ * the C++ shim) spread their micro-batched groups, round robin; unset = the default device (msdfhip_init). Returns how many are configured
+ * and writes up to `cap` of them to `out`. */
+int msdfhip_front_door_devices(int *out, int cap);
+
 /* The library reads its MSDFHIP_* environment knobs ("environment") once, at first use. Tests and A/B scripts that change
  * the environment of a running process call this to have them read again. Not meant for production code. */
 int msdfhip_reload_tuning(void);

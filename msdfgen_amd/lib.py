@@ -99,6 +99,7 @@ _PROTOS = {
     "msdfhip_error_correction_shapeless": (C.c_int, [C.c_int, _fp, C.c_int, C.c_int, C.c_int, _dp, C.c_double, C.c_int]),
     "msdfhip_reload_tuning": (C.c_int, []),
     "msdfhip_trim": (C.c_int, []),
+    "msdfhip_front_door_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "msdfhip_debug_wait_profile": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
 }
 

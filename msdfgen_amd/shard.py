@@ -1,7 +1,7 @@
 """Glyph-sharded multi-GPU execution: one process per GPU, a static contiguous split of the glyph list, no data-path collective.
 
 Glyphs are independent units, so rank r simply renders glyphs [bounds[r], bounds[r+1]) on its own GPU.  The split is
-balanced by the per-glyph cost W*H*E (edge counts are heavy-tailed).  Outputs are byte-identical for any world size because no
+balanced by a per-glyph cost model fitted to measured kernel times (COST_MODEL below).  Outputs are byte-identical for any world size because no
 arithmetic crosses glyphs.  The only optional exchange is assembling the final atlas (`gather_tiles`, one all_gather over RCCL/xGMI).
 """
 from typing import Sequence
@@ -11,10 +11,29 @@ import numpy as np
 from .shape import ShapeBatch
 
 
+# Microseconds per glyph at 64x64 (msdf, library-default config) = a + b*E + c*C + d*E*C with one coefficient set per KERNEL CLASS of the glyph
+# (E edges, C contours; classes as msdf_capi.hip: ensureBuckets sorts them): least squares over (contours, edges) bins of the 8 192 distinct
+# DejaVu glyphs, each bin timed on an MI355X -- tools/fit_cost_model.py, profiles/r03_cost_model.json (rms error of the fit: 5 percent).
+# Round 2 balanced by W*H*(E+1); the measured cost is far from linear in E alone (0.22 us for a one-contour glyph, 0.66 us in the LDS
+# class, 3.5 us in the global-workspace class). The same numbers live in msdf_capi.hip: glyphCost.
+COST_MODEL = {
+    "one_contour": [0.2768, 0.01348, 0.0, 0.0],      # <= 1 contour: simple-combiner kernel
+    "lds": [0.44322, 0.00935, -0.01895, 0.0042],     # 2..7 contours and <= 128 edges: per-contour distances in LDS
+    "global": [2.33907, 0.02717, -0.18818, 0.00156],  # the rest: per-contour distances in the global workspace
+}
+
+
+def glyph_class(contours, edges):
+    return np.where(contours <= 1, 0, np.where((contours <= 7) & (edges <= 128), 1, 2))
+
+
 def glyph_costs(batch: ShapeBatch, width: int, height: int) -> np.ndarray:
     gco, co = batch.glyph_contour_offsets, batch.contour_offsets
     edges = (co[gco[1:]]-co[gco[:-1]]).astype(np.float64)
-    return float(width*height)*(edges+1.)  # +1: fixed per-texel work even for an empty shape
+    contours = (gco[1:]-gco[:-1]).astype(np.float64)
+    coef = np.array([COST_MODEL["one_contour"], COST_MODEL["lds"], COST_MODEL["global"]])[glyph_class(contours, edges)]
+    per_glyph = coef[:, 0]+coef[:, 1]*edges+coef[:, 2]*contours+coef[:, 3]*edges*contours
+    return float(width*height)/4096.*np.maximum(per_glyph, 1e-3)
 
 
 def partition_contiguous(costs: Sequence[float], parts: int) -> np.ndarray:
