@@ -39,6 +39,15 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), in order WITHIN a queue: the host-output
+// pipeline's three chunk streams (plus the caller's own streams) then alias, and a chunk's kernels wait for another chunk's 100 MB copy
+// (measured with MSDFHIP_PIPELINE_TRACE: 12.0 -> 10.2 ms per 8 192 glyphs with 8 queues). The variable is read when the runtime initialises,
+// so this library asks for 8 when it is LOADED -- unless the environment already says something, and without effect if the host
+// initialised HIP earlier. INTEGRATION.md, "environment".
+__attribute__((constructor)) static void msdfhipAskForHardwareQueues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
+static long long nowNsEarly() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // Measurement / experiment knobs from the environment, read ONCE (first use, or msdfhip_reload_tuning() -- tests and A/B scripts flip them
 // between calls); the launch paths never touch getenv.
 struct Tuning {
@@ -51,6 +60,8 @@ struct Tuning {
     float qpWideLoad;
     size_t signCap;                  // MSDFHIP_SIGN_CAP            row-list capacity of the sign pass
     bool pipelineUniform;            // MSDFHIP_PIPELINE_UNIFORM    equal pipeline chunks (no half chunks at the ends)
+    char pipelineLengths[128];       // MSDFHIP_PIPELINE_LENGTHS    experiment: explicit chunk lengths "512,1024,..." (the last one repeats)
+    bool pipelineTrace;              // MSDFHIP_PIPELINE_TRACE      host-output pipeline prints per chunk when its kernels / its copy back finished (stderr)
     int microbatch;                  // MSDFHIP_MICROBATCH          0 / 1 disables the grouping of concurrent single-shape calls; N caps the group
     char devices[256];               // MSDFHIP_DEVICES             "all" | "0,1,..." devices the single-shape front door spreads over
 };
@@ -72,6 +83,10 @@ void readTuning() {
         sscanf(env, "%d,%d,%d,%d,%f", &t.qpEdgeCost, &t.qpMaxEdges, &t.qpMinCount, &t.qpWideMaxEdges, &t.qpWideLoad);
     t.signCap = (env = getenv("MSDFHIP_SIGN_CAP")) ? (size_t) atol(env) : (size_t) 192;
     t.pipelineUniform = getenv("MSDFHIP_PIPELINE_UNIFORM") != NULL;
+    t.pipelineTrace = getenv("MSDFHIP_PIPELINE_TRACE") != NULL;
+    t.pipelineLengths[0] = 0;
+    if ((env = getenv("MSDFHIP_PIPELINE_LENGTHS")))
+        snprintf(t.pipelineLengths, sizeof(t.pipelineLengths), "%s", env);
     t.microbatch = (env = getenv("MSDFHIP_MICROBATCH")) ? atoi(env) : 256;
     if (t.microbatch < 1)
         t.microbatch = 1;
@@ -213,12 +228,15 @@ struct MsdfHipBatch {
     mutable bool bucketExternal;      // dBucket / hBucket belong to someone else (the single-shape calls carve them from their arena)
     mutable bool bucketUploaded;
     mutable int nOne, nSmall, smallMaxC, smallMaxE, oneMaxE;
+    bool serialClasses;               // launch the glyph classes one after the other on the caller's stream (host-output pipeline: its chunks overlap instead)
+    unsigned *overflowOut;            // single-shape host calls: where k_ec_query mirrors the candidate-overflow count (then no k_ec_slow launch)
+    mutable bool overflowMirrored;    // set by the correction launch when it did so
     int glyphCap;                     // per-glyph work buffers are sized for max(nGlyphs, glyphCap) glyphs (views of the host-output pipeline)
     mutable hipStream_t sideStream[2];   // the three glyph classes of the distance pass run concurrently: two of them on these (fork / join by events)
     mutable hipEvent_t forkEvent, joinEvent[2];
     MsdfHipBatch() : device(0), nGlyphs(0), nContours(0), nEdges(0), maxContours(0), maxEdges(0), ownsInputs(false), dGlyphContourOffsets(NULL),
                      dContourOffsets(NULL), dPoints(NULL), dTypes(NULL), dColors(NULL), dRecs(NULL), dWindings(NULL), dScratch(NULL), scratchFloats(0),
-                     dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
+                     dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0), serialClasses(false), overflowOut(NULL), overflowMirrored(false),
                      smallMaxC(0), smallMaxE(0), oneMaxE(0), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
 };
 
@@ -387,6 +405,17 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
     return MSDFHIP_OK;
 }
 
+// Upload of a few KB from pinned host memory by a kernel instead of an SDMA copy (see k_upload_words). bytes must be a multiple of 4.
+int uploadSmall(void *dst, const void *srcPinned, size_t bytes, hipStream_t stream) {
+    if (bytes == 0)
+        return MSDFHIP_OK;
+    const size_t words = bytes/4;
+    const unsigned blocks = (unsigned) ((words+255)/256 < 64 ? (words+255)/256 : 64);
+    hipLaunchKernelGGL(k_upload_words, dim3(blocks ? blocks : 1), dim3(256), 0, stream, reinterpret_cast<uint32_t *>(dst), reinterpret_cast<const uint32_t *>(srcPinned), words);
+    HIPCHK(hipGetLastError());
+    return MSDFHIP_OK;
+}
+
 // Glyph indices sorted into three classes of the overlapping combiner; cached per limit:
 //   one    <= 1 contour: the combiner reduces to the simple one (contour-combiners.cpp:104-133 with a single selector) -- these run the
 //          simple-combiner kernel, which needs 95 VGPRs instead of ~150 and therefore runs 5 instead of 3 wavefronts per SIMD;
@@ -432,7 +461,11 @@ int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
     for (int g = 0; g < b->nGlyphs; ++g)
         if (b->hContours[g] > 1 && !(b->hContours[g] <= limit && b->hEdges[g] <= SMALL_MAX_EDGES))
             order[at++] = g;
-    HIPCHK(hipMemcpyAsync(b->dBucket, b->hBucket, sizeof(int)*(size_t) b->nGlyphs, hipMemcpyHostToDevice, stream));
+    {
+        const int rcUp = uploadSmall(b->dBucket, b->hBucket, sizeof(int)*(size_t) b->nGlyphs, stream);   // (hBucket is pinned)
+        if (rcUp != MSDFHIP_OK)
+            return rcUp;
+    }
     b->bucketUploaded = true;
     b->bucketLimit = limit, b->nOne = nOne, b->nSmall = nSmall, b->smallMaxC = smallMaxC, b->smallMaxE = smallMaxE, b->oneMaxE = oneMaxE;
     return MSDFHIP_OK;
@@ -552,7 +585,7 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     // two on the batch's side streams, forked and joined by events), so that the tail of one fills with the wavefronts of the others --
     // two processes sharing the GPU had measured 12 % more throughput than one.
     const int classes = (b->nOne > 0)+(b->nSmall > 0)+(nRest > 0);
-    const bool concurrent = classes > 1 && !tuning().serialClasses;
+    const bool concurrent = classes > 1 && !tuning().serialClasses && !b->serialClasses;
     hipStream_t sOne = stream, sRest = stream;
     if (concurrent) {
         rc = ensureSideStreams(b);
@@ -729,9 +762,12 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     hipLaunchKernelGGL(k_ec_scan, dim3(1), dim3(1024), 0, stream, viewOf(b), reinterpret_cast<const unsigned *>(deferred), seg, offsets, lpcMaxContours);
     hipLaunchKernelGGL((k_ec_query<N, OVERLAP>), dim3(queryBlocks), dim3(WAVE), queryLds, stream, b->nGlyphs, b->dGlyphContourOffsets, b->dContourOffsets,
                        (const EdgeRec *) viewOf(b).recs, viewOf(b).windings, dGlyphs, w, h, src, out, stencil, cfg,
-                       (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, offsets, slotCap, slotOffset, lpcMaxContours);
-    hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowGrid), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
-                       (const EcCandidate *) deferred, seg, 1, gres, gresStride);
+                       (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, offsets, slotCap, slotOffset, lpcMaxContours, b->overflowOut);
+    if (b->overflowOut)
+        b->overflowMirrored = true;                              // the caller looks at the count after its copy back and reruns with the pass below if needed
+    else
+        hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowGrid), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
+                           (const EcCandidate *) deferred, seg, 1, gres, gresStride);
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
 }
@@ -1394,9 +1430,11 @@ int msdfhip_simulate_8bit(float *dPixels, size_t n, void *streamPtr) {
 // of chunk k+1 overlap the device-to-host copy of chunk k. A chunk is a non-owning view of the batch (the CSR arrays are global:
 // a glyph range is the same arrays with shifted glyph offsets).
 
+enum { PIPE_SLOTS = 3 };
 struct PipeSlot {
-    hipStream_t stream;
+    hipStream_t stream;               // kernels and copy back of the slot's chunk
     hipEvent_t done;                  // the slot's last device-to-host copy has finished
+    hipEvent_t kernelsDone;           // the kernels (and the small uploads before them) of the slot's last chunk have finished
     bool busy;
     char *dev;                        // [descriptors | float tiles | stencil | byte tiles]
     size_t devCap;
@@ -1409,12 +1447,13 @@ struct PipeSlot {
     MsdfHipBatch view;                // glyph range of the parent batch + this slot's own work buffers
 };
 
-// The two slots of a pipeline in flight. Pipelines live in a process-wide pool per device (like the arenas of the single-shape calls):
+// The slots of a pipeline in flight. Pipelines live in a process-wide pool per device (like the arenas of the single-shape calls):
 // a host-output call takes one and returns it, so that a caller that builds a fresh batch per atlas does not pay for 100+ MB of
 // device / pinned allocations every time; the pool is bounded by the peak number of concurrent host-output calls.
 struct Pipe {
     int device;
-    PipeSlot slot[2];
+    hipStream_t compute;              // (unused: one stream for all chunks' kernels was measured slower, see runPipeline)
+    PipeSlot slot[PIPE_SLOTS];
 };
 
 static std::mutex gPipeMutex;
@@ -1429,7 +1468,9 @@ struct PipeLease {
         if (p) {
             // Whatever exit the call took (an error return may leave copies into caller memory / kernels in flight on the slots' streams):
             // nothing of this call is pending when the next caller takes the pipe. Idle streams answer at once.
-            for (int k = 0; k < 2; ++k)
+            if (p->compute)
+                (void) hipStreamSynchronize(p->compute);
+            for (int k = 0; k < PIPE_SLOTS; ++k)
                 if (p->slot[k].stream)
                     (void) hipStreamSynchronize(p->slot[k].stream);
             (void) hipGetLastError();
@@ -1449,15 +1490,20 @@ struct PipeLease {
         }
         Pipe *fresh = new Pipe();
         fresh->device = device;
-        for (int k = 0; k < 2; ++k) {
+        fresh->compute = NULL;
+        for (int k = 0; k < PIPE_SLOTS; ++k) {
             PipeSlot &s = fresh->slot[k];
-            s.stream = NULL, s.done = NULL, s.busy = false, s.dev = NULL, s.devCap = 0, s.pinnedGlyphs = NULL, s.pinnedGlyphCap = 0, s.viewCap = 0;
+            s.stream = NULL, s.done = NULL, s.kernelsDone = NULL, s.busy = false, s.dev = NULL, s.devCap = 0, s.pinnedGlyphs = NULL, s.pinnedGlyphCap = 0, s.viewCap = 0;
             s.pinnedTiles = NULL, s.pinnedTilesCap = 0, s.pendingFirst = 0, s.pendingCount = 0;
         }
-        for (int k = 0; k < 2; ++k) {                            // a half-built pipe never reaches the pool
-            hipError_t e = hipStreamCreateWithFlags(&fresh->slot[k].stream, hipStreamNonBlocking);
+        for (int k = 0; k < PIPE_SLOTS; ++k) {                   // a half-built pipe never reaches the pool
+            hipError_t e = k == 0 ? hipStreamCreateWithFlags(&fresh->compute, hipStreamNonBlocking) : hipSuccess;
+            if (e == hipSuccess)
+                e = hipStreamCreateWithFlags(&fresh->slot[k].stream, hipStreamNonBlocking);
             if (e == hipSuccess)
                 e = hipEventCreateWithFlags(&fresh->slot[k].done, hipEventDisableTiming);
+            if (e == hipSuccess)
+                e = hipEventCreateWithFlags(&fresh->slot[k].kernelsDone, hipEventDisableTiming);
             if (e != hipSuccess) {
                 (void) hipGetLastError();
                 destroyPipe(fresh);
@@ -1486,6 +1532,7 @@ static void sliceBatch(const MsdfHipBatch *b, MsdfHipBatch &v, int g0, int n) {
     }
     v.maxContours = maxC, v.maxEdges = maxE;
     v.bucketLimit = -1;                                          // the class lists are per glyph range
+    v.serialClasses = true;                                      // pipeline chunks overlap each other; side streams per chunk only alias the few hardware queues
 }
 
 static int fetchGlyphCounts(const MsdfHipBatch *b) {             // device-array batches: the per-glyph counts are read back once
@@ -1563,8 +1610,9 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
     const size_t offGlyphs = 0, offTiles = (2*(size_t) chunk*sizeof(MsdfHipGlyph)+255)/256*256, tilesBytes = ((size_t) chunk*tile*sizeof(float)+255)/256*256;
     const size_t offStencil = offTiles+tilesBytes, stencilBytes = wantStencil ? ((size_t) chunk*texels+255)/256*256 : 0;
     const size_t offBytes = offStencil+stencilBytes, devBytes = offBytes+(atlas ? (size_t) chunk*tile : 0)+256;
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < PIPE_SLOTS; ++k) {
         PipeSlot &p = pipe[k];
+        p.view.bucketUploaded = false;                           // (the previous call drained every stream of this pipe before it returned it)
         if (p.devCap < devBytes) {
             HIPCHK(hipStreamSynchronize(p.stream));
             if (p.dev)
@@ -1609,17 +1657,51 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
         if (rem > 0)
             lengths.push_back(rem);
     }
+    if (tuning().pipelineLengths[0]) {                           // experiment knob: explicit schedule, capped by the slots' capacity
+        lengths.clear();
+        int rem = nG, last = chunk;
+        for (const char *q = tuning().pipelineLengths; rem > 0; ) {
+            char *end = NULL;
+            const long v = *q ? strtol(q, &end, 10) : 0;
+            if (end && end != q)
+                last = (int) (v < 64 ? 64 : v > chunk ? chunk : v), q = *end == ',' ? end+1 : end;
+            const int take = last < rem ? last : rem;
+            lengths.push_back(take);
+            rem -= take;
+        }
+    }
+    // MSDFHIP_PIPELINE_TRACE: timed events per chunk (kernels enqueued / finished, copy finished) relative to the first enqueue
+    struct TraceEvents { hipEvent_t start, kernels, copied; long long hostEnqueued; };
+    std::vector<TraceEvents> trace;
+    const bool tracing = tuning().pipelineTrace;
+    const long long traceT0 = nowNsEarly();
+    // Schedule: chunk k runs -- kernels, then its copy back -- on the stream of slot k % PIPE_SLOTS, so the copy of one chunk overlaps the
+    // kernels of the next ones, and the kernels of two consecutive chunks overlap each other (a 2 048-glyph step alone leaves the device
+    // half empty in its tails: serialising the chunks' kernels on one stream was measured, 17 instead of 12 ms). THREE slots: with two, the
+    // device idled 0.8 ms per chunk while a copy held the slot the next chunk needed (MSDFHIP_PIPELINE_TRACE, profiles/r03_ab_notes.md).
     int slot = 0, g0 = 0;
-    for (size_t ci = 0; ci < lengths.size() && rc == MSDFHIP_OK; g0 += lengths[ci], ++ci, slot ^= 1) {
+    for (size_t ci = 0; ci < lengths.size() && rc == MSDFHIP_OK; g0 += lengths[ci], ++ci, slot = (slot+1)%PIPE_SLOTS) {
         const int n = lengths[ci];
         PipeSlot &p = pipe[slot];
+        hipStream_t compute = p.stream;
+        if (ci >= 2)                                             // at most two chunks' kernels at a time, in order: chunk k starts when chunk k-2's KERNELS are done
+            HIPCHK(hipStreamWaitEvent(compute, pipe[(slot+PIPE_SLOTS-2)%PIPE_SLOTS].kernelsDone, 0));
         if (p.busy) {                                            // the slot's previous copy must have left its buffers
             HIPCHK(hipEventSynchronize(p.done));
             p.busy = false;
+            p.view.bucketUploaded = false;
             if (p.pendingCount)
                 scatterPending(p, glyphs, dstBytes, elem, w, h, N);
+            p.pendingCount = 0;
         }
         sliceBatch(b, p.view, g0, n);
+        if (tracing) {
+            TraceEvents te;
+            hipEventCreate(&te.start), hipEventCreate(&te.kernels), hipEventCreate(&te.copied);
+            te.hostEnqueued = nowNsEarly()-traceT0;
+            hipEventRecord(te.start, compute);
+            trace.push_back(te);
+        }
         MsdfHipGlyph *dGlyphs = reinterpret_cast<MsdfHipGlyph *>(p.dev+offGlyphs);
         float *dTiles = reinterpret_cast<float *>(p.dev+offTiles);
         uint8_t *dStencil = wantStencil ? reinterpret_cast<uint8_t *>(p.dev+offStencil) : NULL;
@@ -1669,8 +1751,10 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
             else
                 p.pinnedGlyphs[g].out_offset = (int64_t) ((size_t) g*tile), p.pinnedGlyphs[g].row_stride = w*N;
         }
-        HIPCHK(hipMemcpyAsync(dGlyphs, p.pinnedGlyphs, sizeof(MsdfHipGlyph)*(size_t) n, hipMemcpyHostToDevice, p.stream));
-        rc = msdfhip_batch_generate(&p.view, mode, w, h, dGlyphs, dTiles, dStencil, NULL, cfg, p.stream);
+        rc = uploadSmall(dGlyphs, p.pinnedGlyphs, sizeof(MsdfHipGlyph)*(size_t) n, compute);
+        if (rc != MSDFHIP_OK)
+            break;
+        rc = msdfhip_batch_generate(&p.view, mode, w, h, dGlyphs, dTiles, dStencil, NULL, cfg, compute);
         if (rc != MSDFHIP_OK)
             break;
         const char *dResult = reinterpret_cast<const char *>(dTiles);
@@ -1683,12 +1767,17 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
                 else
                     hBlit[g].out_offset = (int64_t) ((size_t) g*tile), hBlit[g].row_stride = w*N;
             }
-            HIPCHK(hipMemcpyAsync(dBlit, hBlit, sizeof(MsdfHipGlyph)*(size_t) n, hipMemcpyHostToDevice, p.stream));
-            rc = msdfhip_tiles_to_bytes(dTiles, n, w, h, N, dBlit, dBytes, p.stream);
+            rc = uploadSmall(dBlit, hBlit, sizeof(MsdfHipGlyph)*(size_t) n, compute);
+            if (rc != MSDFHIP_OK)
+                break;
+            rc = msdfhip_tiles_to_bytes(dTiles, n, w, h, N, dBlit, dBytes, compute);
             if (rc != MSDFHIP_OK)
                 break;
             dResult = reinterpret_cast<const char *>(dBytes);
         }
+        if (tracing)
+            hipEventRecord(trace.back().kernels, compute);
+        HIPCHK(hipEventRecord(p.kernelsDone, compute));
         if (dense)
             HIPCHK(hipMemcpyAsync(dstBytes+(size_t) spanLo*elem, dResult, (size_t) n*tile*elem, hipMemcpyDeviceToHost, p.stream));
         else {
@@ -1705,9 +1794,11 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
         if (wantStencil)
             HIPCHK(hipMemcpyAsync(stencil+(size_t) g0*texels, dStencil, (size_t) n*texels, hipMemcpyDeviceToHost, p.stream));
         HIPCHK(hipEventRecord(p.done, p.stream));
+        if (tracing)
+            hipEventRecord(trace.back().copied, p.stream);
         p.busy = true;
     }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < PIPE_SLOTS; ++k) {
         PipeSlot &p = pipe[k];
         hipError_t e = hipStreamSynchronize(p.stream);
         p.busy = false;
@@ -1716,6 +1807,20 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
         if (rc == MSDFHIP_OK && p.pendingCount)
             scatterPending(p, glyphs, dstBytes, elem, w, h, N);
         p.pendingCount = 0;
+    }
+    if (tracing && !trace.empty()) {
+        fprintf(stderr, "{\"pipeline_trace\": \"%s\", \"glyphs\": %d, \"host_total_ms\": %.3f, \"chunks\": [", out ? "float" : "uint8", nG, (nowNsEarly()-traceT0)/1e6);
+        for (size_t i = 0; i < trace.size(); ++i) {
+            float a = 0, k = 0, c = 0;
+            hipEventElapsedTime(&a, trace[0].start, trace[i].start);
+            hipEventElapsedTime(&k, trace[0].start, trace[i].kernels);
+            hipEventElapsedTime(&c, trace[0].start, trace[i].copied);
+            fprintf(stderr, "%s{\"glyphs\": %d, \"host_enqueue_ms\": %.3f, \"stream_start_ms\": %.3f, \"kernels_done_ms\": %.3f, \"copy_done_ms\": %.3f}", i ? ", " : "",
+                    lengths[i], trace[i].hostEnqueued/1e6, a, k, c);
+        }
+        fprintf(stderr, "]}\n");
+        for (size_t i = 0; i < trace.size(); ++i)
+            hipEventDestroy(trace[i].start), hipEventDestroy(trace[i].kernels), hipEventDestroy(trace[i].copied);
     }
     return rc;
 }
@@ -1922,7 +2027,9 @@ static int arenaReserve(ThreadArena &a, size_t devBytes, size_t pinnedBytes) {
 
 static void destroyPipe(Pipe *p) {
     (void) hipSetDevice(p->device);
-    for (int k = 0; k < 2; ++k) {
+    if (p->compute)
+        (void) hipStreamSynchronize(p->compute);
+    for (int k = 0; k < PIPE_SLOTS; ++k) {
         PipeSlot &s = p->slot[k];
         if (s.stream)
             (void) hipStreamSynchronize(s.stream);
@@ -1937,9 +2044,13 @@ static void destroyPipe(Pipe *p) {
             pinnedFree(s.pinnedTiles);
         if (s.done)
             hipEventDestroy(s.done);
+        if (s.kernelsDone)
+            hipEventDestroy(s.kernelsDone);
         if (s.stream)
             hipStreamDestroy(s.stream);
     }
+    if (p->compute)
+        hipStreamDestroy(p->compute);
     (void) hipGetLastError();
     delete p;
 }
@@ -1980,6 +2091,19 @@ static long long nowNs() { return std::chrono::duration_cast<std::chrono::nanose
 // Runs n compatible calls as ONE device batch on the calling thread's arena: stage all inputs -> one H2D copy -> digest + kernels ->
 // one D2H copy -> scatter the tiles into the callers' bitmaps. n == 1 is the plain single-shape call.
 static std::atomic<int> gMaxGroup(-1), gMaxLeaders(2);
+
+// End of a latency-bound call: poll the stream for a bounded time before handing the thread to the blocking wait (whose wake-up alone
+// costs 10-20 us, a sixth of a single-shape call).
+static hipError_t waitStream(hipStream_t stream) {
+    const long long deadline = nowNs()+400000;                   // 0.4 ms of polling at most
+    for (;;) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e != hipErrorNotReady)
+            return e;
+        if (nowNs() > deadline)
+            return hipStreamSynchronize(stream);
+    }
+}
 
 // MSDFHIP_DEVICES = "all" | "0,1,...": the devices the front door (single-shape host-pointer calls, i.e. every unmodified caller of the C++
 // shim) spreads its groups over, round robin -- an 8-GPU node serves msdf-atlas-gen's worker pool without a line changed in the caller
@@ -2051,6 +2175,7 @@ static int runGroup(ShapeCall *const *calls, int n) {
     const size_t hSrc = bitmapIsInput ? hc.take(n*tileBytes) : hc.off;
     const size_t inputBytes = hc.off;
     const size_t hBucketOff = hc.take(n*sizeof(int));           // class lists of the overlapping combiner (uploaded on the stream by the launch code)
+    const size_t hStatus = hc.take(256);                         // [0]: candidate-overflow count of the correction pass, copied back with the results
     const size_t hOut = hc.take(n*tileBytes), hStencil = hc.take(n*texels);
     const size_t resultBytes = hc.off-hOut;
     // device layout: mirror of the staging area, then device-only work buffers
@@ -2100,7 +2225,12 @@ static int runGroup(ShapeCall *const *calls, int n) {
     }
     gco[n] = (int32_t) cAt;
     const long long t1 = nowNs();
-    HIPCHK(hipMemcpyAsync(a.dev, a.pinned, inputBytes, hipMemcpyHostToDevice, a.stream));
+    if (inputBytes <= ((size_t) 1<<20)) {                        // a few KB: read from the pinned staging by a kernel -- no SDMA submission on the latency path
+        rc = uploadSmall(a.dev, a.pinned, inputBytes, a.stream);
+        if (rc != MSDFHIP_OK)
+            return rc;
+    } else
+        HIPCHK(hipMemcpyAsync(a.dev, a.pinned, inputBytes, hipMemcpyHostToDevice, a.stream));
 
     MsdfHipBatch b;                                              // non-owning view into the arena
     b.device = a.device;
@@ -2132,9 +2262,11 @@ static int runGroup(ShapeCall *const *calls, int n) {
     const MsdfHipGlyph *dGlyph = reinterpret_cast<const MsdfHipGlyph *>(a.dev+hGlyph);
     float *dOut = reinterpret_cast<float *>(a.dev+hOut);
     uint8_t *dStencil = anyStencil ? reinterpret_cast<uint8_t *>(a.dev+hStencil) : NULL;
+    b.overflowOut = reinterpret_cast<unsigned *>(a.dev+hStatus);
 
     rc = digest(&b, a.stream);
-    if (rc == MSDFHIP_OK) {
+    for (int attempt = 0; rc == MSDFHIP_OK && attempt < 2; ++attempt) {
+        b.overflowMirrored = false;
         if (op == OP_ERROR_CORRECTION)
             rc = runCorrection(&b, channels, w, h, dGlyph, reinterpret_cast<const float *>(a.dev+hSrc), dOut, dStencil, *cfg, a.stream);
         else if (op == OP_SIGN_CORRECTION)
@@ -2143,13 +2275,29 @@ static int runGroup(ShapeCall *const *calls, int n) {
             rc = runSignCorrection(&b, 1, w, h, dGlyph, NULL, dOut, 0, 0.f, cfg->fill_rule, a.stream);
         else
             rc = msdfhip_batch_generate(&b, mode, w, h, dGlyph, dOut, dStencil, stages ? reinterpret_cast<float *>(a.dev+dScratch) : NULL, cfg, a.stream);
+        if (rc != MSDFHIP_OK)
+            break;
+        HIPCHK(hipMemcpyAsync(a.pinned+hStatus, a.dev+hStatus, 256+(anyStencil ? resultBytes : n*tileBytes), hipMemcpyDeviceToHost, a.stream));
+        HIPCHK(waitStream(a.stream));
+        if (!(b.overflowMirrored && *reinterpret_cast<const unsigned *>(a.pinned+hStatus) != 0))
+            break;
+        // a glyph's candidate segment overflowed (more than 1/16 of its texels needed a distance check): once more, with the per-texel
+        // overflow pass in the launch sequence. Pathological inputs only.
+        b.overflowOut = NULL;
+        if (bitmapIsInput)
+            break;                                               // (in-place correction of a caller bitmap: the input copy on the device is intact, rerun below)
+    }
+    if (rc == MSDFHIP_OK && b.overflowOut == NULL && bitmapIsInput) {
+        rc = runCorrection(&b, channels, w, h, dGlyph, reinterpret_cast<const float *>(a.dev+hSrc), dOut, dStencil, *cfg, a.stream);
+        if (rc == MSDFHIP_OK) {
+            HIPCHK(hipMemcpyAsync(a.pinned+hStatus, a.dev+hStatus, 256+(anyStencil ? resultBytes : n*tileBytes), hipMemcpyDeviceToHost, a.stream));
+            HIPCHK(waitStream(a.stream));
+        }
     }
     if (rc != MSDFHIP_OK) {
         hipStreamSynchronize(a.stream);
         return rc;
     }
-    HIPCHK(hipMemcpyAsync(a.pinned+hOut, a.dev+hOut, anyStencil ? resultBytes : n*tileBytes, hipMemcpyDeviceToHost, a.stream));
-    HIPCHK(hipStreamSynchronize(a.stream));
     const long long t2 = nowNs();
     for (int g = 0; g < n; ++g) {
         const ShapeCall &c = *calls[g];

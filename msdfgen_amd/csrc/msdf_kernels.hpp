@@ -69,6 +69,14 @@ __global__ void k_prep_records(EdgeRec *recs, int nEdges, int nContours, const i
     prepRecord(recs, slot, lo, contourOffsets, points, types, colors);
 }
 
+// Small host-to-device uploads from PINNED host memory as a kernel (the device reads the pinned source over PCIe): descriptors and class
+// lists of a pipeline chunk. As hipMemcpyAsync they go to an SDMA engine and queue up BEHIND the 100 MB device-to-host copy of the previous
+// chunk -- the next chunk's kernels then start only when that copy is done (MSDFHIP_PIPELINE_TRACE showed exactly that).
+__global__ void k_upload_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ srcPinned, size_t nWords) {
+    for (size_t i = (size_t) blockIdx.x*blockDim.x+threadIdx.x; i < nWords; i += (size_t) gridDim.x*blockDim.x)
+        dst[i] = srcPinned[i];
+}
+
 // ---------------------------------------------------------------------------------------------------------- helpers
 
 struct GlyphWork {
@@ -1118,7 +1126,11 @@ __global__ void __launch_bounds__(WAVE, 2)
 k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const int32_t *__restrict__ contourOffsets, const EdgeRec *__restrict__ recs,
            const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, const float *__restrict__ src, float *__restrict__ out,
            uint8_t *__restrict__ stencilOut, MsdfHipConfig cfg, const EcGlyphParams *__restrict__ glyphParams, const EcCandidate *__restrict__ cands, unsigned seg,
-           int *__restrict__ offsets, int slotCap, int slotOffset, EcQueryPolicy lpcMaxContours) {
+           int *__restrict__ offsets, int slotCap, int slotOffset, EcQueryPolicy lpcMaxContours, unsigned *__restrict__ overflowOut) {
+    // overflowOut (single-shape host calls): the candidate-overflow count is mirrored next to the results, so that the host sees it with the
+    // copy back instead of a k_ec_slow launch that does nothing in all but pathological cases (one launch less on a latency-bound path)
+    if (overflowOut && blockIdx.x == 0 && threadIdx.x == 0)
+        *overflowOut = reinterpret_cast<const unsigned *>(cands)[0];
     // (__restrict__ throughout, as in k_distance: the lane-per-candidate walk reads the records with scalar loads only if the kernel's
     // own stores -- corrected texels, stencil bytes, the work counter -- provably do not touch them)
     BatchView batch;
