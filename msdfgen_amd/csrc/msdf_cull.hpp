@@ -26,13 +26,13 @@ namespace msdfhip {
 MSDF_HD double cullUpperDistance(const EdgeRec &e, V2 c) {
     const V2 a = c-ld(e.p0), b = c-ld(e.pe), m = c-ld(e.mid);
     const double da = dot(a, a), db = dot(b, b), dm = dot(m, m);
-    return sqrt(dmin(dmin(da, db), dm));
+    return sqrt(cmin(cmin(da, db), dm));
 }
 
 // Lower bound of the distance from c to edge e: distance to the control-point bounding box (a Bezier lies in its control hull).
 MSDF_HD double cullLowerDistance(const EdgeRec &e, V2 c) {
-    const double dx = dmax(dmax(e.lo[0]-c.x, c.x-e.hi[0]), 0.);
-    const double dy = dmax(dmax(e.lo[1]-c.y, c.y-e.hi[1]), 0.);
+    const double dx = cmax(cmax(e.lo[0]-c.x, c.x-e.hi[0]), 0.);
+    const double dy = cmax(cmax(e.lo[1]-c.y, c.y-e.hi[1]), 0.);
     return sqrt(dx*dx+dy*dy);
 }
 
@@ -62,7 +62,7 @@ MSDF_HD bool cullEdgeSurvives(const EdgeRec &e, V2 c, double r, double Umax) {
 // by the edge's position within its group of 16 (keys are then unique within a group: a plain rank is a permutation).
 MSDF_HD unsigned cullOrderKey(const EdgeRec &e, V2 c, int slot) {
     const V2 a = c-ld(e.p0), b = c-ld(e.pe), m = c-ld(e.mid);
-    const float d2 = (float) dmin(dmin(dot(a, a), dot(b, b)), dot(m, m));
+    const float d2 = (float) cmin(cmin(dot(a, a), dot(b, b)), dot(m, m));
     unsigned bits;
     memcpy(&bits, &d2, sizeof(bits));
     if (!(bits < 0x7f800000u))

@@ -147,6 +147,16 @@ MSDF_HD V2 mixv(V2 a, V2 b, double w) { return (1.-w)*a+w*b; }               // 
 MSDF_HD double nonZeroSign(double n) { return n > 0 ? 1. : -1.; }            // arithmetics.hpp:59-61 (int 2*(n>0)-1, exact in double)
 MSDF_HD double dmin(double a, double b) { return b < a ? b : a; }
 MSDF_HD double dmax(double a, double b) { return a < b ? b : a; }
+// For the CONSERVATIVE tests only (tile cull, per-texel relevance: they decide what is evaluated, never a value): the hardware's
+// v_max_f64 / v_min_f64 -- one instruction where the reference-exact dmax / dmin (b < a ? b : a, whose NaN and signed-zero behaviour
+// differs from IEEE maxNum) costs a compare and two selects.
+#if defined(MSDF_EXACT_MINMAX_EVERYWHERE)
+MSDF_HD double cmax(double a, double b) { return dmax(a, b); }
+MSDF_HD double cmin(double a, double b) { return dmin(a, b); }
+#else
+MSDF_HD double cmax(double a, double b) { return __builtin_fmax(a, b); }
+MSDF_HD double cmin(double a, double b) { return __builtin_fmin(a, b); }
+#endif
 MSDF_HD double median(double a, double b, double c) { return dmax(dmin(a, b), dmin(dmax(a, b), c)); }
 MSDF_HD float fmin_(float a, float b) { return b < a ? b : a; }
 MSDF_HD float fmax_(float a, float b) { return a < b ? b : a; }
@@ -715,11 +725,11 @@ MSDF_HD bool selEdgeRelevant(const Selector<SEL> &s, const Rec &e, V2 o) {
         bound2 = 0;
         for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
             if (mask&(1<<i))
-                bound2 = dmax(bound2, s.c[i].td*s.c[i].td);
+                bound2 = cmax(bound2, s.c[i].td*s.c[i].td);
     }
     bound2 *= 1+1e-9;                                // (-DBL_MAX)^2 = inf: nothing is skipped until a channel has a candidate
-    const double dx = dmax(dmax(e.Lo().x-o.x, o.x-e.Hi().x), 0.);
-    const double dy = dmax(dmax(e.Lo().y-o.y, o.y-e.Hi().y), 0.);
+    const double dx = cmax(cmax(e.Lo().x-o.x, o.x-e.Hi().x), 0.);
+    const double dy = cmax(cmax(e.Lo().y-o.y, o.y-e.Hi().y), 0.);
     if (!(dx*dx+dy*dy > bound2))
         return true;
     if (SEL >= 2) {

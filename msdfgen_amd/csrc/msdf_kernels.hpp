@@ -278,14 +278,13 @@ struct EdgesCulledPacked {              // survivors of the per-tile cull as pac
     const int *cstart;                  // C+1 compacted offsets
     const int *list;                    // packed entries (LDS)
     int total;                          // cstart[C]
-    int cstartLane;                     // lane c holds cstart[c] (c <= C) when the glyph has fewer than 64 contours, see inLanes
-    bool inLanes;
 #if defined(MSDF_PROFILE_WAITS)
     mutable unsigned long long prof[16]; // [8] contour walks of pass 0 [9] per-contour bookkeeping after a walk [10] second walks [11] combiner epilogue [12] tile prologue [13] tile stores | [0] batch cycles [1] batches [2] E batch cycles [3] E batches [4] eval cycles [5] evals [6] relevance cycles [7] slow batches (>1000) | (>3000)<<32
 #endif
-    // (a cross-lane read instead of an LDS round trip per contour and tile)
-    __device__ int begin(int c) const { return inLanes ? __builtin_amdgcn_readlane(cstartLane, c) : MSDF_UNIFORM(cstart[c]); }
-    __device__ int end(int c) const { return inLanes ? __builtin_amdgcn_readlane(cstartLane, c+1) : MSDF_UNIFORM(cstart[c+1]); }
+    // (holding the offsets in lanes 0..C and fetching them with readlane -- no LDS round trip per contour -- was measured: no gain, and
+    // one more VGPR in kernels that sit at their register cap)
+    __device__ int begin(int c) const { return MSDF_UNIFORM(cstart[c]); }
+    __device__ int end(int c) const { return MSDF_UNIFORM(cstart[c+1]); }
 };
 
 #if defined(MSDF_PROFILE_WAITS)
@@ -514,16 +513,15 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
 #endif
                 }
             }
-            // key = (contour segment within the 16-lane row | distance | slot): contours stay grouped, nearest first inside each.
-            // The segment is the number of contour CHANGES up to this lane within its row (at most 15) -- not the difference of contour
-            // indices, which empty contours (valid input: they own no edge) can push past 15.
-            const int cPrev = __shfl(i < nE ? c : -1, lane > 0 ? lane-1 : 0);
-            const unsigned long long changes = __ballot((lane&15) != 0 && i < nE && c != cPrev);
-            const int segment = __popcll((changes>>(lane&~15))&((2ull<<(lane&15))-1ull));
+            // key = (contour segment within the 16-lane row | distance | slot): contours stay grouped, nearest first inside each. The
+            // segment is the contour's offset from the row's first contour -- below 16 unless EMPTY contours (valid input: they own no edge)
+            // sit between the row's edges; such a row keeps plain lane order (which is contour order) instead of nearest-first.
+            const int segment = c-__shfl(c, lane&~15);
+            const bool wideRow = ((__ballot(i < nE && segment > 15)>>(lane&~15))&0xffffull) != 0;
             unsigned key = MSDF_CULL_KEY_DROPPED_SEGMENTED|(unsigned) (col&15);
             if (keep) {
                 const unsigned d = (cullOrderKey(rec[i], tc, 0)>>3)&0x0ffffff0u;
-                key = ((unsigned) segment<<28)|(d < 0x0ffffff0u ? d : 0x0fffffe0u)|(unsigned) (col&15);
+                key = wideRow ? (unsigned) (col&15) : ((unsigned) segment<<28)|(d < 0x0ffffff0u ? d : 0x0fffffe0u)|(unsigned) (col&15);
             }
             const int rank = rowRank(key);
             const unsigned long long ballot = __ballot(keep);
@@ -559,9 +557,6 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             break;
         const int tx = tile%tilesX, ty = tile/tilesX;
         const int x = tx*TILE+(lane&(TILE-1)), y = ty*TILE+(lane>>3);
-        // (read by every lane BEFORE texels outside the bitmap drop out: the walk fetches its contour offsets from lanes 0..C with readlane)
-        int cstartLane = cstarts[(size_t) q*(C+1)+(lane < C ? lane : C)];
-        asm volatile("" : "+v"(cstartLane));                        // pins the load HERE: sunk below the branch, inactive lanes would never load
         if (x >= width || y >= height)
             continue;
         const V2 p = fastXf ? mk(divExact(x+.5, t.sx, rsx)-t.tx, divExact(y+.5, t.sy, rsy)-t.ty)
@@ -570,9 +565,7 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
         EdgesCulled edges;
 #else
         EdgesCulledPacked edges;
-        edges.inLanes = C < WAVE;
-        edges.cstartLane = cstartLane;
-        edges.total = edges.inLanes ? __builtin_amdgcn_readlane(edges.cstartLane, C) : MSDF_UNIFORM(cstarts[(size_t) q*(C+1)+C]);
+        edges.total = MSDF_UNIFORM(cstarts[(size_t) q*(C+1)+C]);
 #if defined(MSDF_PROFILE_WAITS)
         for (int i = 0; i < 16; ++i)
             edges.prof[i] = 0;
