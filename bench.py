@@ -210,8 +210,14 @@ def end_to_end(M, batch, xfs, w, h, reps=3):
                           "h2d_bytes": h2d, "d2h_bytes": int(tiles.nbytes), "d2h_gb_per_s_incl_kernels": tiles.nbytes/f/1e9}
     res["uint8_atlas"] = {"glyphs_per_s": n/(c+b), "glyphs_per_s_excluding_upload": n/b, "ms_generate_convert_and_copy_back": 1e3*b,
                           "h2d_bytes": h2d, "d2h_bytes": int(atlas.nbytes), "atlas": [int(atlas.shape[1]), int(atlas.shape[0])]}
+    fl = flatten_ms(batch)
+    if fl:
+        best = min(fl.values())
+        res["ms_flatten"] = {"per_pass_over_all_glyphs": fl, "note": "const msdfgen::Shape & -> CSR (the C++ shim's per-call flatten) over the same %d glyphs, real "
+                             "msdfgen::Shape objects; NOT inside the two figures above (they start from CSR arrays) -- with it: float tiles %.0f, 8-bit atlas %.0f glyphs/s" % (
+                                 n, n/(c+f+best*1e-3), n/(c+b+best*1e-3))}
     res["note"] = ("host CSR arrays in pageable memory, outputs in pinned memory (msdfhip_host_alloc), %d glyphs, median of %d runs; chunks of the glyph "
-                   "list alternate between two streams so that kernels overlap the copy back" % (n, reps))
+                   "list rotate through three streams (two chunks' kernels at a time) so that kernels overlap the copies back" % (n, reps))
     M.host_free(tiles)
     M.host_free(atlas)
     return res
@@ -257,6 +263,33 @@ def inprocess(args):
                       "note": "median of %d runs after %d warm-up runs%s" % (args.steps, args.warmup, "; REHEARSAL: every 'device' is GPU 0" if args.same_device else "")}))
     M.host_free(tiles)
     M.host_free(atlas)
+
+
+def flatten_ms(batch):
+    """SURVEY 8(d) counts the HOST FLATTEN in the end-to-end metric: const msdfgen::Shape & -> CSR edge buffer, what the C++ shim does per call
+    (msdfgen_shim.cpp: flatten). Measured by the shim's own client (tests/shim/shim_check, built against the msdfgen headers in the authoring
+    container; it travels to the GPU box): real msdfgen::Shape objects built from this workload, flattened on 1 and on all usable threads."""
+    import tempfile
+    exe = os.path.join(ROOT, "tests", "shim", "shim_check")
+    if not os.path.exists(exe):
+        return None
+    gco, co = batch.glyph_contour_offsets.astype(np.int32), batch.contour_offsets.astype(np.int32)
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        np.array([len(gco)-1, len(co)-1, int(co[-1])], np.int32).tofile(f)
+        gco.tofile(f), co.tofile(f), np.ascontiguousarray(batch.points, np.float64).tofile(f)
+        np.ascontiguousarray(batch.types, np.uint8).tofile(f), np.ascontiguousarray(batch.colors, np.uint8).tofile(f)
+        path = f.name
+    out = {}
+    try:
+        for threads in (1, available_cores()):
+            r = subprocess.run([exe, "flatten", path, str(threads), "7"], capture_output=True, text=True, timeout=120)
+            if r.returncode == 0:
+                out["threads_%d" % threads] = json.loads(r.stdout.strip().splitlines()[-1])["ms_flatten"]
+    except (OSError, ValueError, subprocess.SubprocessError):
+        return None
+    finally:
+        os.unlink(path)
+    return out or None
 
 
 def spawn(args):

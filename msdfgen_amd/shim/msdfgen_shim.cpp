@@ -9,10 +9,13 @@
 //
 // Differences from the reference that a caller can observe: none in the texels (see tests); the functions can now fail (no
 // device, HIP error) and there is deliberately NO CPU fallback -- failures throw std::runtime_error with the library's message.
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "msdfgen.h"
@@ -295,6 +298,37 @@ void distanceSignCorrection(const BitmapSection<float, 4> &sdf, const Shape &sha
     signCorrect<4>(sdf, shape, Projection(scale, translate), .5f, fillRule);
 }
 
+}
+
+// ---- measurement hook (not part of msdfgen's API): what the shim does to a Shape before the C ABI sees it -----------------------------
+// Flattens the n shapes (const Shape & -> CSR edge buffer, flatten() above) on `threads` host threads, `reps` times; returns the median
+// milliseconds of one pass over all n. bench.py reports it as end_to_end.ms_flatten (SURVEY 8d counts the host flatten in the metric).
+extern "C" double msdfgen_hip_shim_flatten_ms(const msdfgen::Shape *const *shapes, int n, int threads, int reps, long long *edges_out) {
+    std::vector<double> ms;
+    std::atomic<long long> edges(0);
+    for (int r = 0; r < reps; ++r) {
+        edges.store(0);
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t)
+            pool.push_back(std::thread([&, t]() {
+                long long mine = 0;
+                msdfgen::FlatShape flat;
+                for (int g = t; g < n; g += threads) {
+                    flat.contourOffsets.clear(), flat.points.clear(), flat.types.clear(), flat.colors.clear();
+                    msdfgen::flatten(*shapes[g], flat);
+                    mine += (long long) flat.contourOffsets.back();
+                }
+                edges += mine;
+            }));
+        for (size_t t = 0; t < pool.size(); ++t)
+            pool[t].join();
+        ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now()-t0).count());
+    }
+    std::sort(ms.begin(), ms.end());
+    if (edges_out)
+        *edges_out = edges.load();
+    return ms.empty() ? 0. : ms[ms.size()/2];
 }
 
 // ---- failure reporting of the shim (not part of msdfgen's API) -----------------------------------------------------------------

@@ -7,12 +7,60 @@
 // combiner; distanceSignCorrection; msdfErrorCorrection with DO_NOT_CHECK_DISTANCE.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <cstdint>
 #include <vector>
 #include "msdfgen.h"
 
 using namespace msdfgen;
 
+extern "C" double msdfgen_hip_shim_flatten_ms(const msdfgen::Shape *const *shapes, int n, int threads, int reps, long long *edges_out);
+
+// shim_check flatten <csr.bin> <threads> <reps>: builds msdfgen::Shape objects from a flat CSR dump (int32 nGlyphs, nContours, nEdges;
+// gco[nGlyphs+1]; co[nContours+1]; f64 points[nEdges][8]; u8 types[nEdges]; u8 colors[nEdges]) the way a font loader would (heap-allocated
+// edge segments behind EdgeHolders), then times the shim's Shape -> CSR flattening over all of them. Prints one JSON line.
+static int flattenBench(const char *path, int threads, int reps) {
+    FILE *f = fopen(path, "rb");
+    if (!f)
+        return 3;
+    int32_t hdr[3];
+    if (fread(hdr, sizeof(int32_t), 3, f) != 3)
+        return 3;
+    const int nG = hdr[0], nC = hdr[1], nE = hdr[2];
+    std::vector<int32_t> gco((size_t) nG+1), co((size_t) nC+1);
+    std::vector<double> pts((size_t) nE*8);
+    std::vector<unsigned char> types((size_t) nE), colors((size_t) nE);
+    if (fread(gco.data(), 4, gco.size(), f) != gco.size() || fread(co.data(), 4, co.size(), f) != co.size() || fread(pts.data(), 8, pts.size(), f) != pts.size() ||
+        fread(types.data(), 1, types.size(), f) != types.size() || fread(colors.data(), 1, colors.size(), f) != colors.size())
+        return 3;
+    fclose(f);
+    std::vector<Shape> shapes((size_t) nG);
+    for (int g = 0; g < nG; ++g)
+        for (int c = gco[g]; c < gco[g+1]; ++c) {
+            Contour &contour = shapes[g].addContour();
+            for (int e = co[c]; e < co[c+1]; ++e) {
+                const double *p = &pts[(size_t) e*8];
+                const EdgeColor col = (EdgeColor) colors[e];
+                if (types[e] == 1)
+                    contour.addEdge(EdgeHolder(Point2(p[0], p[1]), Point2(p[2], p[3]), col));
+                else if (types[e] == 2)
+                    contour.addEdge(EdgeHolder(Point2(p[0], p[1]), Point2(p[2], p[3]), Point2(p[4], p[5]), col));
+                else
+                    contour.addEdge(EdgeHolder(Point2(p[0], p[1]), Point2(p[2], p[3]), Point2(p[4], p[5]), Point2(p[6], p[7]), col));
+            }
+        }
+    std::vector<const Shape *> ptrs((size_t) nG);
+    for (int g = 0; g < nG; ++g)
+        ptrs[g] = &shapes[g];
+    long long edges = 0;
+    const double ms = msdfgen_hip_shim_flatten_ms(ptrs.data(), nG, threads, reps, &edges);
+    printf("{\"ms_flatten\": %.4f, \"shapes\": %d, \"edges\": %lld, \"threads\": %d, \"reps\": %d}\n", ms, nG, edges, threads, reps);
+    return edges == nE ? 0 : 5;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 5 && !strcmp(argv[1], "flatten"))
+        return flattenBench(argv[2], atoi(argv[3]), atoi(argv[4]));
     if (argc < 10)
         return 2;
     FILE *f = fopen(argv[1], "r");

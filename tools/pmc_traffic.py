@@ -1,16 +1,16 @@
-"""Turns the rocprofv3 passes of `bench.py` (tools/profile_round.sh) into profiles/pmc_traffic.json, the counters bench.py quotes for the
-dominant pass (the distance field = every k_distance<...> launch of a step: up to three instantiations, the global-scratch one chunked):
+"""Turns the rocprofv3 passes of `bench.py` (tools/profile_round.sh) into profiles/pmc_traffic.json -- what bench.py quotes for the dominant
+pass (the distance field = every k_distance<...> launch of a step; up to three instantiations running concurrently):
 
-  * HBM bytes per step from the separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, corrected as /opt/skills/guides/MI355X_MICROARCH.md
-    (HBM section) prescribes: both counters are in units of 1024 B, and on gfx950 FETCH_SIZE reports half of the bytes of a wide
-    coalesced read (so the read side is doubled; WRITE_SIZE is uncalibrated, taken as is);
-  * the pass's duration = union of the launches' intervals in the --kernel-trace --stats pass (the classes run concurrently);
-  * VALU issue utilisation of the pass from the SQ pass: SQ_INSTS_VALU wave-instructions x 4 cycles (a wave64 instruction occupies the
-    16-lane SIMD for at least 4 cycles; fp64 ops take longer, so this is a LOWER bound of the busy fraction) over 1024 SIMDs x the pass's
-    duration (--kernel-trace --stats pass) at the 2.4 GHz peak engine clock; SQ_WAIT_ANY / SQ_WAVE_CYCLES = share of a wavefront's
-    life spent parked in s_waitcnt.
+  * HBM bytes per step from the separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes. Units and corrections as CALIBRATED on this device
+    (tools/valu_calib.hip --fetch, profiles/r03_valu_calibration.json): both counters count KiB; WRITE_SIZE is exact for all three store
+    patterns of this library; FETCH_SIZE tallies vector loads at HALF and wave-uniform scalar loads at 1.13x of the bytes moved. k_distance
+    reads through both (gathers in phase 1, s_load in phase 2), so the read side is reported as a RANGE [x1, x2] and `hbm_bytes_per_launch`
+    takes the x2 end (the guide's rule for wide loads; an upper bound here);
+  * the pass's duration = union of the launches' intervals in the --kernel-trace --stats pass;
+  * the VALU busy fraction of the distance kernels from tools/pmc_report.py (profiles/<tag>_pmc_bench.json: per-class instruction counts x
+    measured cycles per class, shader clock from GRBM_GUI_ACTIVE), weighted by each kernel's own time.
 
-    python tools/pmc_traffic.py <tag> <commit>        (reads gpurun_out/<tag>_{stats,fetch,write,sq}/**/*.db)
+    python tools/pmc_traffic.py <tag> <commit>
 """
 import glob
 import json
@@ -19,8 +19,6 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLOCK_HZ = 2.4e9
-SIMDS = 256*4
 
 
 def db(tag, kind):
@@ -41,13 +39,9 @@ def main():
     like = "k_distance"
     fetch, steps = counter_per_step(db(tag, "fetch"), "FETCH_SIZE", like)
     write, _ = counter_per_step(db(tag, "write"), "WRITE_SIZE", like)
-    sq = db(tag, "sq")
-    c = {name: counter_per_step(sq, name, like)[0] for name in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "SQ_WAVES",
-                                                                 "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")}
     st = db(tag, "stats")
     rows = st.execute("select name, sum(end-start), count(*) from kernels group by name").fetchall()
     nsteps = max(n for name, _, n in rows if "k_ec_fast" in name)
-    # the glyph classes' launches run concurrently (side streams): the pass lasts as long as the UNION of their intervals
     spans = sorted(st.execute("select start, end from kernels where name like ?", ("%"+like+"%",)).fetchall())
     busy, (lo, hi) = 0, spans[0]
     for a, b in spans[1:]:
@@ -56,25 +50,27 @@ def main():
         else:
             hi = max(hi, b)
     dist_ns = (busy+hi-lo)/nsteps
-    dist_sum_ns = sum(t for name, t, _ in rows if like in name)/nsteps
     per_kernel = {name.split("(")[0].replace("void msdfhip::", ""): round(t/nsteps/1e6, 4) for name, t, _ in rows if t/nsteps > 2000}
-    cycles = dist_ns*1e-9*CLOCK_HZ*SIMDS
+    rep = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_bench.json" % tag)))["kernels"]
+    dk = {k: v for k, v in rep.items() if like in k}
+    total_ms = sum(v["ms_alone"] for v in dk.values())
+    busy_w = sum(v["valu_busy_frac_calibrated"]*v["ms_alone"] for v in dk.values())/total_ms
     out = {"workload": "dejavu8192", "glyphs_per_gpu": 8192, "tile": [64, 64], "commit": commit, "steps_profiled": steps,
            "kernels": "every k_distance<...> launch of a step (1-contour / LDS-scratch / global-scratch classes)",
-           "distance_pass_ms": round(dist_ns/1e6, 4), "distance_kernels_sum_ms": round(dist_sum_ns/1e6, 4), "kernel_ms_per_step": per_kernel,
-           "FETCH_SIZE_raw": fetch, "WRITE_SIZE_raw": write, "hbm_read_bytes": 2*fetch*1024, "hbm_write_bytes": write*1024,
+           "distance_pass_ms": round(dist_ns/1e6, 4), "kernel_ms_per_step_concurrent": per_kernel,
+           "FETCH_SIZE_raw_KiB": fetch, "WRITE_SIZE_raw_KiB": write,
+           "hbm_read_bytes_range": [fetch*1024, 2*fetch*1024], "hbm_write_bytes": write*1024,
            "hbm_bytes_per_launch": 2*fetch*1024+write*1024,
-           "correction": "x1024 B per counter unit; FETCH_SIZE x2 (gfx950 half-count of wide coalesced reads, MI355X_MICROARCH.md)",
-           "valu_issue_frac": round(4*c["SQ_INSTS_VALU"]/cycles, 4),
-           "valu_issue_note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x distance-pass duration x 2.4 GHz), separate rocprofv3 --pmc pass at commit %s; "
-                              "fp64 instructions occupy the SIMD longer than 4 cycles, so this is a lower bound of the busy fraction" % commit,
-           "valu_active_frac": round(4*c["SQ_ACTIVE_INST_VALU"]/cycles, 4),
-           "wait_any_over_wave_cycles": round(c["SQ_WAIT_ANY"]/c["SQ_WAVE_CYCLES"], 4),
-           "wait_inst_any_over_wave_cycles": round(c["SQ_WAIT_INST_ANY"]/c["SQ_WAVE_CYCLES"], 4),
-           "lds_bank_conflict_over_idx_active": round(c["SQ_LDS_BANK_CONFLICT"]/max(c["SQ_LDS_IDX_ACTIVE"], 1), 5),
-           "sq_counters_per_step": {k: round(v) for k, v in c.items()}}
+           "correction": "counters in KiB (calibrated: profiles/r03_valu_calibration.json); WRITE_SIZE exact; FETCH_SIZE x2 for vector loads, x0.88 for scalar loads -- "
+                         "the kernel mixes both, the x2 end is used",
+           "valu_busy_frac_calibrated": round(busy_w, 4),
+           "valu_busy_per_kernel": {k: {"ms_alone": v["ms_alone"], "busy": v["valu_busy_frac_calibrated"], "wait_any": v["wait_any_over_wave_cycles"],
+                                        "scalar_cache_miss_rate": v["scalar_cache_miss_rate"], "shader_clock_ghz": v["shader_clock_ghz"]} for k, v in dk.items()},
+           "valu_busy_note": "sum over instruction classes of (PMC count x cycles per wave64 instruction measured with tools/valu_calib.hip) / (1024 SIMDs x kernel time x "
+                             "shader clock from GRBM_GUI_ACTIVE); each kernel alone on the device (rocprofv3 serialises kernels under --pmc), time-weighted over the "
+                             "three class kernels; commit %s. Replaces round 2's flat 4 cycles per instruction at 2.4 GHz." % commit}
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
-    print(json.dumps(out))
+    print(json.dumps(out)[:1500])
 
 
 if __name__ == "__main__":
