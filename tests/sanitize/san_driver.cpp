@@ -178,6 +178,59 @@ int main(int argc, char **argv) {
         }
     }
 
+    // 4b. round 3: the front door spread over "devices" (MSDFHIP_DEVICES, device 0 listed three times -> six leaders), the shapeless
+    // correction passes, overlapping rectangles in the pipeline (staging path), msdfhip_trim between bursts
+    {
+        setenv("MSDFHIP_DEVICES", "0,0,0", 1);
+        EXPECT(msdfhip_reload_tuning() == MSDFHIP_OK);
+        int devs[4] = { -1, -1, -1, -1 };
+        EXPECT(msdfhip_front_door_devices(devs, 4) == 3 && devs[2] == 0);
+        std::atomic<int> mismatches(0), errors(0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < 10; ++t)
+            pool.emplace_back([&, t]() {
+                std::vector<float> px(tile);
+                std::vector<int32_t> local;
+                for (int i = 0; i < 20; ++i) {
+                    const int g = (t*13+i*7)%G, c0 = s.gco[g], nC = s.gco[g+1]-c0, e0 = s.co[c0];
+                    local.assign(nC+1, 0);
+                    for (int k = 0; k <= nC; ++k)
+                        local[k] = s.co[c0+k]-e0;
+                    const int rc = msdfhip_generate(MSDFHIP_MODE_MSDF, px.data(), W, W, W*N, 0, local.data(), nC, &s.points[8*(size_t) e0], &s.types[e0], &s.colors[e0],
+                                                    &s.xf[6*(size_t) g], &cfg, NULL);
+                    if (rc != MSDFHIP_OK)
+                        ++errors;
+                    else if (memcmp(px.data(), want.data()+g*tile, sizeof(float)*tile) != 0)
+                        ++mismatches;
+                    if (i%5 == 0) {                                          // a shapeless pass on the fresh tile: must not fail, must stay finite
+                        if (msdfhip_error_correction_shapeless(N, px.data(), W, W, W*N, &s.xf[6*(size_t) g], 1.11111111111111111, i&1) != MSDFHIP_OK)
+                            ++errors;
+                    }
+                }
+            });
+        for (auto &th : pool)
+            th.join();
+        EXPECT(errors.load() == 0);
+        EXPECT(mismatches.load() == 0);
+        unsetenv("MSDFHIP_DEVICES");
+        EXPECT(msdfhip_reload_tuning() == MSDFHIP_OK);
+        EXPECT(msdfhip_front_door_devices(NULL, 0) == 0);
+        EXPECT(msdfhip_trim() == MSDFHIP_OK);                                // pools empty now; the next calls rebuild them
+        MsdfHipBatch *b2 = NULL;
+        EXPECT(msdfhip_batch_create(&b2, G, s.gco.data(), s.co.data(), s.points.data(), s.types.data(), s.colors.data()) == MSDFHIP_OK);
+        std::vector<MsdfHipGlyph> od(gd);
+        od[5].out_offset = od[4].out_offset;                                 // two glyphs on one tile, tile 5 free: not an exact tiling -> staging + scatter
+        std::fill(got.begin(), got.end(), -9.f);
+        EXPECT(msdfhip_batch_generate_host(b2, MSDFHIP_MODE_MSDF, W, W, od.data(), got.data(), got.size(), NULL, &cfg) == MSDFHIP_OK);
+        size_t freeCellTouched = 0;
+        for (size_t i = 5*tile; i < 6*tile; ++i)
+            freeCellTouched += got[i] != -9.f;
+        EXPECT(freeCellTouched == 0);
+        EXPECT(memcmp(got.data()+6*tile, want.data()+6*tile, sizeof(float)*(G-6)*tile) == 0);
+        msdfhip_batch_destroy(b2);
+        EXPECT(msdfhip_trim() == MSDFHIP_OK);
+    }
+
     // 5. argument validation never reads past what it was given
     {
         MsdfHipBatch *bad = NULL;
