@@ -236,8 +236,8 @@ struct MsdfHipBatch {
     mutable hipEvent_t forkEvent, joinEvent[2];
     MsdfHipBatch() : device(0), nGlyphs(0), nContours(0), nEdges(0), maxContours(0), maxEdges(0), ownsInputs(false), dGlyphContourOffsets(NULL),
                      dContourOffsets(NULL), dPoints(NULL), dTypes(NULL), dColors(NULL), dRecs(NULL), dWindings(NULL), dScratch(NULL), scratchFloats(0),
-                     dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0), serialClasses(false), overflowOut(NULL), overflowMirrored(false),
-                     smallMaxC(0), smallMaxE(0), oneMaxE(0), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
+                     dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
+                     smallMaxC(0), smallMaxE(0), oneMaxE(0), serialClasses(false), overflowOut(NULL), overflowMirrored(false), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
 };
 
 namespace {

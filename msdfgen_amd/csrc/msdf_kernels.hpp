@@ -322,7 +322,14 @@ __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, con
         // 6.28 ms per step; a batch lands in 380 cycles on average, 4 % of a wavefront's life. It also cannot be made safe in C++: the
         // dummy destination of an unwaited s_load may be copied or spilled by the register allocator and its register reused while the
         // load is still in flight. Gone.)
+#if defined(MSDF_ONE_STAGE_RELEVANCE)                               // A/B only
         const bool relevant = MSDF_WAVE_ANY(selEdgeRelevant(sel, r, o));
+#else
+        double bound2;
+        bool relevant = MSDF_WAVE_ANY(selEdgeRelevantBox(sel, r, o, bound2));      // some lane within reach of the control box: evaluate, whatever the wedges say
+        if (SEL >= 2 && !relevant)
+            relevant = MSDF_WAVE_ANY(selEdgeRelevantWedges<SEL>(r, o, bound2));
+#endif
 #if defined(MSDF_PROFILE_WAITS)
         MSDF_STAMP(t2);
         edges.prof[6] += t2-t1;
@@ -466,14 +473,15 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
         }
         for (int base = 0; base < nE; base += ROW) {
             const int i = base+col;
-            double ub = 0;
+            float sample2 = 0;
             int mask = 0;
             if (i < nE && tileValid) {
                 mask = cullMask<SEL>(rec[i]);
                 if (mask || !OVERLAP)
-                    ub = cullUpperDistance(rec[i], tc);
+                    sample2 = cullNearestSample2(rec[i], tc);
+                list[i] = __float_as_int(sample2);                  // pass B's walk-order key; survivors only ever land at or below their own index
             }
-            const float ubf = floatAbove(ub);
+            const float ubf = cullUpperFromSample2(sample2);
             if (OVERLAP) {
                 if (mask) {
                     unsigned *mine = bounds+(size_t) (rec[i].contour-c0)*3;
@@ -498,7 +506,10 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             const int i = base+col;
             bool keep = false;
             int c = 0;
+            float sample2 = 0;
             if (i < nE) {
+                if (tileValid)
+                    sample2 = __int_as_float(list[i]);              // read before this round's survivors are written (same wavefront: LDS operations stay in order)
                 c = rec[i].contour-c0;
                 const int mask = cullMask<SEL>(rec[i]);
                 if (mask && tileValid) {
@@ -520,7 +531,7 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             const bool wideRow = ((__ballot(i < nE && segment > 15)>>(lane&~15))&0xffffull) != 0;
             unsigned key = MSDF_CULL_KEY_DROPPED_SEGMENTED|(unsigned) (col&15);
             if (keep) {
-                const unsigned d = (cullOrderKey(rec[i], tc, 0)>>3)&0x0ffffff0u;
+                const unsigned d = (cullOrderKeyOfSample2(sample2, 0)>>3)&0x0ffffff0u;
                 key = wideRow ? (unsigned) (col&15) : ((unsigned) segment<<28)|(d < 0x0ffffff0u ? d : 0x0fffffe0u)|(unsigned) (col&15);
             }
             const int rank = rowRank(key);

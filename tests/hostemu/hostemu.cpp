@@ -86,7 +86,7 @@ TileCull cullTile(const Digest &d, const int32_t *co, int nC, bool overlap, cons
     std::vector<float> U((size_t) (nC > 0 ? nC : 1)*3, INFINITY);
     for (int i = 0; i < nE; ++i) {
         const int mask = cullMask<SEL>(d.recs[i]);
-        const float ub = floatAboveHost(cullUpperDistance(d.recs[i], tc));
+        const float ub = cullUpperFromSample2(cullNearestSample2(d.recs[i], tc));        // as the kernel: fp32, rounded up
         float *mine = &U[(size_t) (overlap ? contourOf[i] : 0)*3];
         for (int ch = 0; ch < 3; ++ch)
             if ((mask>>ch)&1)
