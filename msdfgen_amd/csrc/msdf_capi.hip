@@ -63,6 +63,7 @@ struct Tuning {
     char pipelineLengths[128];       // MSDFHIP_PIPELINE_LENGTHS    experiment: explicit chunk lengths "512,1024,..." (the last one repeats)
     bool pipelineTrace;              // MSDFHIP_PIPELINE_TRACE      host-output pipeline prints per chunk when its kernels / its copy back finished (stderr)
     int microbatch;                  // MSDFHIP_MICROBATCH          0 / 1 disables the grouping of concurrent single-shape calls; N caps the group
+    int queryBatch;                  // MSDFHIP_QUERY_BATCH         cooperative distance checks a wavefront of k_ec_query takes per ticket (default 1: more only lengthens the tail)
     char devices[256];               // MSDFHIP_DEVICES             "all" | "0,1,..." devices the single-shape front door spreads over
 };
 Tuning gTuning;
@@ -91,6 +92,7 @@ void readTuning() {
     if (t.microbatch < 1)
         t.microbatch = 1;
     t.devices[0] = 0;
+    t.queryBatch = (env = getenv("MSDFHIP_QUERY_BATCH")) && atoi(env) > 0 ? atoi(env) : 1;
     if ((env = getenv("MSDFHIP_DEVICES")))
         snprintf(t.devices, sizeof(t.devices), "%s", env);
     gTuning = t;
@@ -762,7 +764,8 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     hipLaunchKernelGGL(k_ec_scan, dim3(1), dim3(1024), 0, stream, viewOf(b), reinterpret_cast<const unsigned *>(deferred), seg, offsets, lpcMaxContours);
     hipLaunchKernelGGL((k_ec_query<N, OVERLAP>), dim3(queryBlocks), dim3(WAVE), queryLds, stream, b->nGlyphs, b->dGlyphContourOffsets, b->dContourOffsets,
                        (const EdgeRec *) viewOf(b).recs, viewOf(b).windings, dGlyphs, w, h, src, out, stencil, cfg,
-                       (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, offsets, slotCap, slotOffset, lpcMaxContours, b->overflowOut);
+                       (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, (const int *) offsets, offsets+2*(size_t) b->nGlyphs+2, tuning().queryBatch, slotCap, slotOffset, lpcMaxContours,
+                       b->overflowOut);
     if (b->overflowOut)
         b->overflowMirrored = true;                              // the caller looks at the count after its copy back and reruns with the pass below if needed
     else
@@ -2783,6 +2786,22 @@ extern "C" int msdfhip_debug_wait_profile(unsigned long long *out24, int reset) 
         HIPCHK(hipMemcpyFromSymbol(out24, HIP_SYMBOL(msdfhip::gWaitProfile), sizeof(zero)));
     if (reset)
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(msdfhip::gWaitProfile), zero, sizeof(zero)));
+    return MSDFHIP_OK;
+#elif defined(MSDF_PROFILE_QUERY)                                    // (-DMSDF_PROFILE_QUERY, tools/profile_query.py: the table of k_ec_query instead)
+    unsigned long long zero[24] = { 0 };
+    zero[3] = ~0ull;                                                // first start: an atomic minimum
+    if (out24) {
+        unsigned long long detail[16];
+        HIPCHK(hipMemcpyFromSymbol(out24, HIP_SYMBOL(msdfhip::gQueryProfile), sizeof(zero)));
+        HIPCHK(hipMemcpyFromSymbol(detail, HIP_SYMBOL(msdfhip::gQueryDetail), sizeof(detail)));
+        if (reset == 2)                                             // second page: the cooperative query in detail (tools/profile_query.py)
+            memcpy(out24, detail, sizeof(detail));
+    }
+    if (reset == 1) {
+        unsigned long long zero16[16] = { 0 };
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(msdfhip::gQueryProfile), zero, sizeof(zero)));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(msdfhip::gQueryDetail), zero16, sizeof(zero16)));
+    }
     return MSDFHIP_OK;
 #else
     if (out24)

@@ -253,6 +253,18 @@ struct EdgeRegs {
 };
 static_assert(REC_A_ZERO == 1 && REC_B_ZERO == 2 && REC_NORMED == 4 && REC_FASTDIV == 16, "packEntry / EdgeRegs::Flags");
 
+// The same register image of a record for a lane that evaluates ITS OWN edge (k_ec_query: lanes = edges): the five blocks and the packed
+// type / colour / flags arrive with 21 independent 16-byte loads -- one round trip. Evaluated straight from memory (selAddEdge on an
+// EdgeRec &), every field is loaded where it is first used: ~80 DEPENDENT vector-load round trips per edge, which is what a distance
+// check cost (profiles/r03_profile_query.jsonl: 300 k cycles per round of 64 edges, 60 times an evaluation of k_distance).
+__device__ inline EdgeRegs loadEdgeRegs(const EdgeRec *rp, int i) {
+    const d8 *blocks = reinterpret_cast<const d8 *>(rp);
+    EdgeRegs r;
+    r.r0 = blocks[0], r.r1 = blocks[1], r.e0 = blocks[2], r.e1 = blocks[3], r.e2 = blocks[4];
+    r.meta = packEntry(i, *rp);
+    return r;
+}
+
 #if defined(MSDF_PROFILE_WAITS)
 // Measurement build only (tools/profile_waits.sh): where a k_distance wavefront's cycles go. s_memtime stamps inside the hand-placed load
 // batches; per-wave sums are added to this table by lane 0 when the wavefront ends. [0] waves [1] wave cycles [2] phase 1 [3] cycles in
@@ -353,6 +365,39 @@ __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, con
 #endif
         }
         cur = next;
+    }
+}
+
+// Every edge of a glyph for a per-lane query point (k_ec_query, lane-per-candidate chunks), the records fetched like the survivor walk
+// above: ONE batch of scalar loads per edge (R + E0 + the type / colour / flags words of block T) instead of a dependent scalar-cache
+// round trip per field group -- a chunk of a 44-edge glyph was the ~0.2 ms critical path of the whole launch.
+typedef int i4 __attribute__((ext_vector_type(4)));
+struct EdgesAllBatched {
+    const int32_t *coff;
+    __device__ int begin(int c) const { return coff[c]-coff[0]; }
+    __device__ int end(int c) const { return coff[c+1]-coff[0]; }
+};
+
+template <int SEL>
+__device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, const EdgesAllBatched &edges, int c, V2 o) {
+    const int e = MSDF_UNIFORM(edges.end(c));
+    MSDF_NOUNROLL
+    for (int i = MSDF_UNIFORM(edges.begin(c)); i < e; ++i) {
+        const EdgeRec *rp = rec+i;
+        EdgeRegs r;
+        i4 words;                                                    // type, color, flags, contour
+        asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx4 %3, %4, 0x160\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(r.r0), "=&s"(r.r1), "=&s"(r.e0), "=&s"(words) : "s"(rp));
+        r.meta = (unsigned) i|(unsigned) words[0]<<20|(unsigned) (words[1]&7)<<22|(unsigned) (words[2]&7)<<25|(unsigned) ((words[2]>>4)&1)<<28;   // packEntry
+        double bound2;
+        bool relevant = MSDF_WAVE_ANY(selEdgeRelevantBox(sel, r, o, bound2));
+        if (SEL >= 2 && !relevant)
+            relevant = MSDF_WAVE_ANY(selEdgeRelevantWedges<SEL>(r, o, bound2));
+        if (relevant) {
+            if (r.Type() >= 2)
+                asm volatile("s_load_dwordx16 %0, %2, 0xc0\n\ts_load_dwordx16 %1, %2, 0x100\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r.e1), "=&s"(r.e2) : "s"(rp));
+            selAddEdge(sel, r, i, o);
+        }
     }
 }
 
@@ -631,16 +676,18 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
 
 // --------------------------------------------------------------------------------------------------- error correction
 
-template <bool OVERLAP>
+// Wind: Contour::winding per contour -- the int8 array in memory, or (k_ec_query) WindingMasks: the combiner reads it up to four times per
+// contour and query, and a wave-uniform byte load from global memory is a ~1.5 us round trip each (they were most of a work item's 90 us).
+template <bool OVERLAP, class Wind = const int8_t *, class Edges = EdgesAll>
 struct PsdfQuery {                                                  // ShapeDistanceFinder<CC<PerpendicularDistanceSelector>>, MSDFErrorCorrection.cpp:97
     const EdgeRec *rec;
     const int32_t *coff;
-    const int8_t *windings;
+    Wind windings;
     int C;
     double *res;
     __device__ double operator()(V2 q) const {
         double out[1];
-        EdgesAll edges;
+        Edges edges;
         edges.coff = coff;
         if (OVERLAP)
             shapeDistanceOverlap<2>(rec, edges, windings, C, q, res, WAVE, out);
@@ -662,9 +709,23 @@ struct EdgesCooperative {
     PBSlot *slots;                      // LDS: one slot per edge of the glyph, or NULL (glyph too large: per-contour lane merge instead)
     PBSlot *merged;                     // LDS: one slot per contour (the contour's edges merged in visit order), valid with slots
     int nE, C;
+#if defined(MSDF_PROFILE_QUERY)
+    mutable unsigned long long prof[16]; // [8] contour walks of pass 0 [9] bookkeeping [10] second walks [11] epilogue | [0] all-edge evaluation [1] per-contour slot merges
+#endif
     MSDF_HD int begin(int c) const { return coff[c]-coff[0]; }
     MSDF_HD int end(int c) const { return coff[c+1]-coff[0]; }
 };
+#if defined(MSDF_PROFILE_QUERY)
+__device__ inline unsigned long long qNow() {
+#if MSDF_PROFILE_QUERY >= 2
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    return __builtin_readcyclecounter();
+}
+__device__ inline void profAdd(const EdgesCooperative &edges, int i, unsigned long long dt) { edges.prof[i] += dt; }
+__device__ inline unsigned long long profNow(const EdgesCooperative &) { return qNow(); }
+__device__ unsigned long long gQueryDetail[16];
+#endif
 
 __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const EdgesCooperative &edges, int c, V2 o) {
     if (edges.slots) {
@@ -672,16 +733,24 @@ __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const
         // own slots in visit order -- a handful of uniform LDS reads per edge instead of a cross-lane reduction per contour.
         // (Slots are filled when contour 0 is walked: the first walk of every query starts there, later walks reuse them.)
         if (c == 0) {
+#if defined(MSDF_PROFILE_QUERY)
+            const unsigned long long qa = qNow();
+#endif
             for (int base = 0; base < edges.nE; base += WAVE) {
                 const int i = base+edges.lane;
                 if (i < edges.nE) {
                     Selector<2> mine;
                     selInit(mine);
-                    selAddEdge(mine, rec[i], i, o);
+                    const EdgeRegs r = loadEdgeRegs(rec+i, i);
+                    selAddEdge(mine, r, i, o);
                     edges.slots[i] = mine.c[0];
                 }
             }
             waveSync();
+#if defined(MSDF_PROFILE_QUERY)
+            const unsigned long long qb = qNow();
+            edges.prof[0] += qb-qa;
+#endif
             // lanes = contours: each merges ITS contour's slots in visit order (the serial part is the longest contour, not the glyph)
             for (int cc = edges.lane; cc < edges.C; cc += WAVE) {
                 PB acc;
@@ -694,6 +763,9 @@ __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const
                 edges.merged[cc] = acc;
             }
             waveSync();
+#if defined(MSDF_PROFILE_QUERY)
+            edges.prof[1] += qNow()-qb;
+#endif
         }
         // merge(sel, merge(...merge(initial, e_first)..., e_last)) == the sequential merges: the earlier state survives ties either way
         const PBSlot whole = edges.merged[c];
@@ -705,8 +777,10 @@ __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const
         Selector<2> mine;
         selInit(mine);
         const int i = base+edges.lane;
-        if (i < e)
-            selAddEdge(mine, rec[i], i, o);
+        if (i < e) {
+            const EdgeRegs r = loadEdgeRegs(rec+i, i);
+            selAddEdge(mine, r, i, o);
+        }
         PB &m = mine.c[0];
         MSDF_UNROLL
         for (int off = 1; off < WAVE; off <<= 1) {                  // lane l <- merge(l, l+off): the lower lane is the earlier edge
@@ -722,11 +796,11 @@ __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const
     }
 }
 
-template <bool OVERLAP>
+template <bool OVERLAP, class Wind = const int8_t *>
 struct PsdfQueryCooperative {                                       // same query, all 64 lanes working on ONE point
     const EdgeRec *rec;
     const int32_t *coff;
-    const int8_t *windings;
+    Wind windings;
     int C, lane;
     double *res;
     PBSlot *slots, *merged;
@@ -734,12 +808,25 @@ struct PsdfQueryCooperative {                                       // same quer
         double out[1];
         EdgesCooperative edges;
         edges.coff = coff, edges.lane = lane, edges.slots = slots, edges.merged = merged, edges.nE = coff[C]-coff[0], edges.C = C;
+#if defined(MSDF_PROFILE_QUERY)
+        for (int i = 0; i < 16; ++i)
+            edges.prof[i] = 0;
+        const unsigned long long qq0 = qNow();
+#endif
         if (slots)
             waveSync();                                             // the previous query's slot reads are done
         if (OVERLAP)
             shapeDistanceOverlap<2>(rec, edges, windings, C, q, res, 1, out);   // wave-uniform point: every lane holds the same values, one slot per contour
         else
             shapeDistanceSimple<2>(rec, edges, C, q, out);
+#if defined(MSDF_PROFILE_QUERY)
+        if (lane == 0) {
+            atomicAdd(&gQueryDetail[0], 1ull), atomicAdd(&gQueryDetail[1], qNow()-qq0);
+            atomicAdd(&gQueryDetail[2], edges.prof[0]), atomicAdd(&gQueryDetail[3], edges.prof[1]), atomicAdd(&gQueryDetail[4], edges.prof[8]);
+            atomicAdd(&gQueryDetail[5], edges.prof[9]), atomicAdd(&gQueryDetail[6], edges.prof[10]), atomicAdd(&gQueryDetail[7], edges.prof[11]);
+            atomicAdd(&gQueryDetail[8], (unsigned long long) C), atomicAdd(&gQueryDetail[9], (unsigned long long) (slots ? 1 : 0));
+        }
+#endif
         return out[0];
     }
 };
@@ -1125,12 +1212,30 @@ k_ec_scan(BatchView batch, const unsigned *header, unsigned seg, int *offsets, E
 // combiner scratch is one double per contour) or a chunk of 64 candidates of one glyph (lane per candidate, scratch [contour][lane]).
 // A candidate that turns out to be an artifact flags its texel: rgb := median (apply, MSDFErrorCorrection.cpp:459-479),
 // stencil |= ERROR. Several candidates of one texel write identical values.
+#ifndef MSDF_EC_QUERY_WAVES_PER_SIMD
+#define MSDF_EC_QUERY_WAVES_PER_SIMD 3   // 168 VGPRs (13 spilled) with the record images of the cooperative path; 2 -> CJK-like set 2.90 ms, 3 -> 2.61, 4 (119 spilled) -> 2.94
+#endif
+#if defined(MSDF_PROFILE_QUERY)
+// Measurement build (tools/profile_query.py): where a wavefront of k_ec_query spends its cycles. [0] waves [1] wave cycles [2] waves with work
+// [3] first start [4] last end (atomic min / max) | chunk items: [5] count [6] cycles | cooperative items: [7] count [8] cycles |
+// [9] ticket wait [10] lookup [11] glyph state [12] evaluation (candidate load, interpolation, distance query, comparison) [13] store + barrier
+// [14] longest item [15] cooperative rounds (64 edges each) [16] end of the last wavefront that still found work
+__device__ unsigned long long gQueryProfile[24];
+// -DMSDF_PROFILE_QUERY=2: every stamp waits for all outstanding memory operations first (attributes the time to the segments, slows the
+// kernel); =1: plain s_memtime stamps -- per-item totals, the longest item and a histogram stay meaningful, the kernel runs at its own pace.
+#if MSDF_PROFILE_QUERY >= 2
+#define MSDF_QSTAMP(x) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long x = __builtin_readcyclecounter()
+#else
+#define MSDF_QSTAMP(x) const unsigned long long x = __builtin_readcyclecounter()
+#endif
+#endif
 template <int N, bool OVERLAP>
-__global__ void __launch_bounds__(WAVE, 2)
+__global__ void __launch_bounds__(WAVE, MSDF_EC_QUERY_WAVES_PER_SIMD)
 k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const int32_t *__restrict__ contourOffsets, const EdgeRec *__restrict__ recs,
            const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, const float *__restrict__ src, float *__restrict__ out,
            uint8_t *__restrict__ stencilOut, MsdfHipConfig cfg, const EcGlyphParams *__restrict__ glyphParams, const EcCandidate *__restrict__ cands, unsigned seg,
-           int *__restrict__ offsets, int slotCap, int slotOffset, EcQueryPolicy lpcMaxContours, unsigned *__restrict__ overflowOut) {
+           const int *__restrict__ offsets, int *__restrict__ counter, int itemsPerTicket, int slotCap, int slotOffset, EcQueryPolicy lpcMaxContours,
+           unsigned *__restrict__ overflowOut) {
     // overflowOut (single-shape host calls): the candidate-overflow count is mirrored next to the results, so that the host sees it with the
     // copy back instead of a k_ec_slow launch that does nothing in all but pathological cases (one launch less on a latency-bound path)
     if (overflowOut && blockIdx.x == 0 && threadIdx.x == 0)
@@ -1143,28 +1248,54 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
     PBSlot *slotBuf = reinterpret_cast<PBSlot *>(smemLds+slotOffset);
     const unsigned *header = reinterpret_cast<const unsigned *>(cands);
     const size_t texelsPerGlyph = (size_t) width*height;
-    const int chunks = offsets[batch.nGlyphs], total = chunks+offsets[2*batch.nGlyphs+1];
+    // offsets[] is read-only here and the work counter (k_ec_scan keeps it in the same array) arrives as a pointer of its own: the glyph
+    // lookup below is then 13 SCALAR loads instead of 13 vector-load round trips to L2 -- together with the atomic they were half of the
+    // ~27 us an item took (55 k items of the DejaVu set over 3 072 resident wavefronts in 0.48 ms: the kernel is this latency chain).
+    const int chunks = offsets[batch.nGlyphs], coopItems = offsets[2*batch.nGlyphs+1];
+    const int tickets = chunks+(coopItems+itemsPerTicket-1)/itemsPerTicket;   // a ticket = one chunk, or itemsPerTicket consecutive cooperative items
     lpcMaxContours.lpcMaxEdges = offsets[2*batch.nGlyphs+3];        // as k_ec_scan decided for this launch
-    int *counter = offsets+2*batch.nGlyphs+2;
+#if defined(MSDF_PROFILE_QUERY)
+    MSDF_QSTAMP(qStart);
+    unsigned long long qAcc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, qItems[4] = { 0, 0, 0, 0 }, qLongest = 0, qLastWork = 0, qLongestWho = 0;
+#endif
     for (;;) {
-        int i = 0;
+#if defined(MSDF_PROFILE_QUERY)
+        MSDF_QSTAMP(q0);
+#endif
+        int ticket = 0;
         if (threadIdx.x == 0)
-            i = atomicAdd(counter, 1);
-        i = __builtin_amdgcn_readfirstlane(i);
-        if (i >= total)
+            ticket = atomicAdd(counter, 1);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket >= tickets)
             break;
-        const int *part = i < chunks ? offsets : offsets+batch.nGlyphs+1;   // heavy first: the lane-per-candidate chunks, then the cooperative items
-        if (i >= chunks)
-            i -= chunks;
-        int lo = 0, hi = batch.nGlyphs-1;                           // the glyph g with part[g] <= i < part[g+1]
+#if defined(MSDF_PROFILE_QUERY)
+        MSDF_QSTAMP(q1);
+        qAcc[0] += q1-q0;
+#endif
+        const int *part = ticket < chunks ? offsets : offsets+batch.nGlyphs+1;   // heavy first: the lane-per-candidate chunks, then the cooperative items
+        const int first = ticket < chunks ? ticket : (ticket-chunks)*itemsPerTicket;
+        const int last = ticket < chunks ? first+1 : (first+itemsPerTicket < coopItems ? first+itemsPerTicket : coopItems);
+        int lo = 0, hi = batch.nGlyphs-1;                           // the glyph g with part[g] <= first < part[g+1]
         while (lo < hi) {
             const int mid = (lo+hi)>>1;
-            if (part[mid+1] > i)
+            if (part[mid+1] > first)
                 hi = mid;
             else
                 lo = mid+1;
         }
-        const int g = lo, item = i-part[g];
+        int g = lo;
+        MSDF_NOUNROLL
+        for (int i = first; i < last; ++i) {
+#if defined(MSDF_PROFILE_QUERY)
+        MSDF_QSTAMP(q2a);
+#endif
+        while (part[g+1] <= i)                                      // consecutive items: the same glyph or one of the next few
+            ++g;
+        const int item = i-part[g];
+#if defined(MSDF_PROFILE_QUERY)
+        MSDF_QSTAMP(q2);
+        qAcc[1] += q2-(i == first ? q1 : q2a);
+#endif
         const unsigned count = header[1+g];
         const EcCandidate *segment = cands+ecHeaderRecords(batch.nGlyphs)+(size_t) g*seg;
         const int c0 = batch.glyphContourOffsets[g], C = batch.glyphContourOffsets[g+1]-c0;
@@ -1182,9 +1313,22 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
         sdf.px = src+(size_t) g*texelsPerGlyph*N;
         sdf.w = width, sdf.h = height, sdf.N = N, sdf.flip = gd.flip;
         const int nE = coff[C]-coff[0];
+        WindingMasks wind;                                          // one vector load + two ballots per item instead of up to 4 C dependent byte loads
+        wind.mem = batch.windings+c0;
+        wind.pos = wind.neg = 0;
+        if (OVERLAP) {
+            const int w = (int) threadIdx.x < C ? (int) wind.mem[threadIdx.x] : 0;
+            wind.pos = __ballot(w > 0), wind.neg = __ballot(w < 0);
+        }
+#if defined(MSDF_PROFILE_QUERY)
+        MSDF_QSTAMP(q3);
+        qAcc[2] += q3-q2;
+        unsigned long long q4 = q3;
+        const bool qChunk = ecQueryLanePerCandidate(count, nE, C, lpcMaxContours);
+#endif
         if (ecQueryLanePerCandidate(count, nE, C, lpcMaxContours)) {
-            PsdfQuery<OVERLAP> query;
-            query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.res = smemLds+threadIdx.x;
+            PsdfQuery<OVERLAP, WindingMasks, EdgesAllBatched> query;
+            query.rec = batch.recs+coff[0], query.coff = coff, query.windings = wind, query.C = C, query.res = smemLds+threadIdx.x;
             const unsigned k = (unsigned) item*WAVE+threadIdx.x;
             if (k < count) {
                 const EcCandidate cand = segment[k];
@@ -1192,7 +1336,8 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
                 const int rem = (int) (texel-(size_t) g*texelsPerGlyph);
                 const int yn = rem/width, x = rem%width;
                 const int ys = gd.flip ? height-1-yn : yn;
-                if (ecEvaluateCandidate(sdf, p, x, ys, cand.t, (cand.dir&3)-1, ((cand.dir>>2)&3)-1, query)) {
+                const bool artifact = ecEvaluateCandidate(sdf, p, x, ys, cand.t, (cand.dir&3)-1, ((cand.dir>>2)&3)-1, query);
+                if (artifact) {
                     const float *in = sdf.native(x, yn);
                     const float m = medianf(in[0], in[1], in[2]);
                     float *px = out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
@@ -1203,8 +1348,8 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             }
         } else {
             const EcCandidate cand = segment[item];
-            PsdfQueryCooperative<OVERLAP> query;
-            query.rec = batch.recs+coff[0], query.coff = coff, query.windings = batch.windings+c0, query.C = C, query.lane = threadIdx.x;
+            PsdfQueryCooperative<OVERLAP, WindingMasks> query;
+            query.rec = batch.recs+coff[0], query.coff = coff, query.windings = wind, query.C = C, query.lane = threadIdx.x;
             query.res = smemLds;
             // larger glyphs: per-contour cross-lane merge instead of the slots. `merged` holds min(maxContours, slotCap) states: a glyph of
             // <= slotCap edges normally has no more contours than that, but EMPTY contours (valid input) do not count as edges -- such a
@@ -1215,7 +1360,14 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             const int rem = (int) (texel-(size_t) g*texelsPerGlyph);
             const int yn = rem/width, x = rem%width;
             const int ys = gd.flip ? height-1-yn : yn;
-            if (ecEvaluateCandidate(sdf, p, x, ys, cand.t, (cand.dir&3)-1, ((cand.dir>>2)&3)-1, query) && threadIdx.x == 0) {
+            const bool artifact = ecEvaluateCandidate(sdf, p, x, ys, cand.t, (cand.dir&3)-1, ((cand.dir>>2)&3)-1, query);
+#if defined(MSDF_PROFILE_QUERY)
+            {
+                MSDF_QSTAMP(q4c);
+                q4 = q4c;
+            }
+#endif
+            if (artifact && threadIdx.x == 0) {
                 const float *in = sdf.native(x, yn);
                 const float m = medianf(in[0], in[1], in[2]);
                 float *px = out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
@@ -1225,7 +1377,44 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             }
         }
         waveSync();                                                 // the next item rewrites the LDS scratch
+#if defined(MSDF_PROFILE_QUERY)
+        {
+            MSDF_QSTAMP(q5);
+            if (qChunk)
+                q4 = q5;                                            // (chunk: evaluation and stores are not told apart)
+            qAcc[3] += q4-q3, qAcc[4] += q5-q4;
+            qItems[qChunk ? 0 : 2] += 1, qItems[qChunk ? 1 : 3] += q5-q2a;
+            qItems[2] += 0;
+            if (!qChunk)
+                qAcc[5] += (unsigned long long) ((nE+WAVE-1)/WAVE);
+            if (q5-q2a > qLongest)
+                qLongest = q5-q2a, qLongestWho = (unsigned long long) g<<1|(qChunk ? 1ull : 0ull);
+            qLastWork = q5;
+            if (threadIdx.x == 0) {                                 // histogram of item durations: < 16 k cycles, < 32 k, ... >= 512 k
+                int bucket = 0;
+                for (unsigned long long d = (q5-q2a)>>14; d && bucket < 6; d >>= 1)
+                    ++bucket;
+                atomicAdd(&gQueryDetail[10+(bucket > 5 ? 5 : bucket)], 1ull);
+            }
+        }
+#endif
+        }
     }
+#if defined(MSDF_PROFILE_QUERY)
+    {
+        MSDF_QSTAMP(qEnd);
+        if (threadIdx.x == 0) {
+            atomicAdd(&gQueryProfile[0], 1ull), atomicAdd(&gQueryProfile[1], qEnd-qStart);
+            if (qLastWork)
+                atomicAdd(&gQueryProfile[2], 1ull), atomicMax(&gQueryProfile[16], qLastWork);
+            atomicMin(&gQueryProfile[3], qStart), atomicMax(&gQueryProfile[4], qEnd);
+            atomicAdd(&gQueryProfile[5], qItems[0]), atomicAdd(&gQueryProfile[6], qItems[1]), atomicAdd(&gQueryProfile[7], qItems[2]), atomicAdd(&gQueryProfile[8], qItems[3]);
+            atomicAdd(&gQueryProfile[9], qAcc[0]), atomicAdd(&gQueryProfile[10], qAcc[1]), atomicAdd(&gQueryProfile[11], qAcc[2]), atomicAdd(&gQueryProfile[12], qAcc[3]);
+            atomicAdd(&gQueryProfile[13], qAcc[4]), atomicMax(&gQueryProfile[14], qLongest), atomicAdd(&gQueryProfile[15], qAcc[5]);
+            atomicMax(&gQueryProfile[17], (qLongest>>8)<<24|qLongestWho);   // longest item: cycles/256 | glyph<<1 | chunk
+        }
+    }
+#endif
 }
 
 // Full per-texel pipeline incl. the exact shape-distance check (msdf_ec.hpp) for EVERY texel of the batch: used for the stage
