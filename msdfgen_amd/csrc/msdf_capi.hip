@@ -55,6 +55,7 @@ struct Tuning {
     long persistentRounds;           // MSDFHIP_PERSISTENT_ROUNDS   global-scratch launches of at least this many rounds run persistent; 0 = never
     bool serialClasses;              // MSDFHIP_SERIAL_CLASSES      glyph classes one after the other instead of on side streams
     int querySlotCap, queryLpcContours;   // MSDFHIP_QUERY_LDS      "slotCap,lpcMaxContours"
+    bool hasQueryLds;
     bool hasQueryPolicy;             // MSDFHIP_QUERY_POLICY        "edgeCost,maxEdges,minCount,wideMaxEdges,wideLoad"
     int qpEdgeCost, qpMaxEdges, qpMinCount, qpWideMaxEdges;
     float qpWideLoad;
@@ -76,7 +77,8 @@ void readTuning() {
     t.persistentRounds = (env = getenv("MSDFHIP_PERSISTENT_ROUNDS")) ? atol(env) : 8;
     t.serialClasses = getenv("MSDFHIP_SERIAL_CLASSES") != NULL;
     t.querySlotCap = 160, t.queryLpcContours = 24;
-    if ((env = getenv("MSDFHIP_QUERY_LDS")))
+    t.hasQueryLds = (env = getenv("MSDFHIP_QUERY_LDS")) != NULL;
+    if (env)
         sscanf(env, "%d,%d", &t.querySlotCap, &t.queryLpcContours);
     t.qpEdgeCost = 340, t.qpMaxEdges = 48, t.qpMinCount = 0x7fffffff, t.qpWideMaxEdges = 128, t.qpWideLoad = 4e8f;
     t.hasQueryPolicy = (env = getenv("MSDFHIP_QUERY_POLICY")) != NULL;
@@ -715,7 +717,15 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     // (both bounded so that the kernel's LDS does not cap its occupancy -- one 543-edge symbol in the batch had cost every wavefront
     // 22 KB; measured: 2.67 -> 2.60 ms of correction on the distinct-glyph set)
     const int slotCapWanted = tuning().querySlotCap, lpcContoursWanted = tuning().queryLpcContours;   // 160, 24 (MSDFHIP_QUERY_LDS)
-    const int slotCap = b->maxEdges < slotCapWanted ? (b->maxEdges > 0 ? b->maxEdges : 1) : slotCapWanted;
+    int slotCap = b->maxEdges < slotCapWanted ? (b->maxEdges > 0 ? b->maxEdges : 1) : slotCapWanted;
+    // A launch of few glyphs is a latency chain of its largest one (the 926-edge logo: one distance check per wavefront, 40 contours walked one
+    // after the other without the slots: correction 0.61 ms, with them 0.39): slots for up to 1024 edges there, LDS permitting.
+    if (b->nGlyphs < 256 && !tuning().hasQueryLds) {
+        const int wide = b->maxEdges < 1024 ? (b->maxEdges > 0 ? b->maxEdges : 1) : 1024;
+        const int wideMerged = b->maxContours < wide ? (b->maxContours > 0 ? b->maxContours : 1) : wide;
+        if ((size_t) b->maxContours*sizeof(double)+(size_t) (wide+wideMerged)*sizeof(PBSlot) <= (size_t) 64*1024 && wide > slotCap)
+            slotCap = wide;
+    }
     // LDS of a query wavefront: the lane-per-candidate scratch [maxContours][64], or (cooperative) [maxContours] + the slots -- one or the other
     EcQueryPolicy lpcMaxContours;
     lpcMaxContours.lpcMaxContours = b->maxContours < lpcContoursWanted ? b->maxContours : lpcContoursWanted;     // beyond: cooperative only (one double per contour)
