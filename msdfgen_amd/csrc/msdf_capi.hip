@@ -80,7 +80,7 @@ void readTuning() {
     t.hasQueryLds = (env = getenv("MSDFHIP_QUERY_LDS")) != NULL;
     if (env)
         sscanf(env, "%d,%d", &t.querySlotCap, &t.queryLpcContours);
-    t.qpEdgeCost = 340, t.qpMaxEdges = 48, t.qpMinCount = 0x7fffffff, t.qpWideMaxEdges = 128, t.qpWideLoad = 4e8f;
+    t.qpEdgeCost = 150, t.qpMaxEdges = 48, t.qpMinCount = 0x7fffffff, t.qpWideMaxEdges = 128, t.qpWideLoad = 4e8f;
     t.hasQueryPolicy = (env = getenv("MSDFHIP_QUERY_POLICY")) != NULL;
     if (env)
         sscanf(env, "%d,%d,%d,%d,%f", &t.qpEdgeCost, &t.qpMaxEdges, &t.qpMinCount, &t.qpWideMaxEdges, &t.qpWideLoad);
@@ -736,7 +736,10 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     // Round 2, after the records of the lane-per-candidate walk became scalar loads and the work list heavy-first: with the bound at 128
     // edges for every launch the CJK-like set gains (4.42 -> 2.82) and the DejaVu set loses (2.33 -> 2.73: 55 k candidates are a latency
     // chain, not a load) -- k_ec_scan therefore widens the bound only for launches whose cooperative cost exceeds wideLoad instructions.
-    lpcMaxContours.lpcEdgeCost = tuning().qpEdgeCost, lpcMaxContours.lpcMaxEdges = tuning().qpMaxEdges, lpcMaxContours.lpcMinCount = tuning().qpMinCount;   // 340, 48, never
+    // Round 3, after the chunk walk got batched scalar loads and the cooperative path its register records: the cost of an edge in a chunk
+    // relative to a cooperative round re-swept (340 / 200 / 120 / 60): 1.80 / 1.78 / 1.79 / 1.78 ms on the DejaVu set, 1.57 / 1.51 / 1.50 / 1.52 on
+    // Basic-Latin -- 150 (profiles/r03_ab_notes.md).
+    lpcMaxContours.lpcEdgeCost = tuning().qpEdgeCost, lpcMaxContours.lpcMaxEdges = tuning().qpMaxEdges, lpcMaxContours.lpcMinCount = tuning().qpMinCount;   // 150, 48, never
     lpcMaxContours.wideMaxEdges = tuning().qpWideMaxEdges, lpcMaxContours.wideLoad = tuning().qpWideLoad;                                                   // 128, 4e8 (MSDFHIP_QUERY_POLICY)
     const size_t resLanes = OVERLAP ? (size_t) (lpcMaxContours.lpcMaxContours > 0 ? lpcMaxContours.lpcMaxContours : 1)*WAVE*sizeof(double) : 0;
     const int slotOffset = OVERLAP ? (b->maxContours > 0 ? b->maxContours : 1) : 0;
