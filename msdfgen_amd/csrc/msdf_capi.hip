@@ -465,6 +465,15 @@ int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
     for (int g = 0; g < b->nGlyphs; ++g)
         if (b->hContours[g] > 1 && !(b->hContours[g] <= limit && b->hEdges[g] <= SMALL_MAX_EDGES))
             order[at++] = g;
+    // Heaviest glyphs first inside each class (longest-processing-time order: a launch is ~26 rounds of workgroups, its tail is the last round's
+    // heaviest glyph; the output does not depend on the order -- a glyph writes its own tiles).
+    if (!getenv("MSDFHIP_NO_CLASS_SORT")) {
+        const int *hE = b->hEdges.data(), *hC = b->hContours.data();
+        auto heavier = [hE, hC](int x, int y) { return (long long) hE[x]*(hC[x] > 1 ? hC[x] : 1) > (long long) hE[y]*(hC[y] > 1 ? hC[y] : 1); };
+        std::stable_sort(order, order+nOne, heavier);
+        std::stable_sort(order+nOne, order+nOne+nSmall, heavier);
+        std::stable_sort(order+nOne+nSmall, order+at, heavier);
+    }
     {
         const int rcUp = uploadSmall(b->dBucket, b->hBucket, sizeof(int)*(size_t) b->nGlyphs, stream);   // (hBucket is pinned)
         if (rcUp != MSDFHIP_OK)
