@@ -26,3 +26,4 @@ if [ -n "$WITH_CONFIGS" ]; then python tools/pmc_report.py $TAG cfg4 k_distance 
 python tools/pmc_traffic.py $TAG $COMMIT
 cat gpurun_out/${TAG}_pmc_bench.txt | head -30
 find gpurun_out -name "*.db" -path "*${TAG}_*" -size +8M -delete
+mkdir -p gpurun_out/${TAG}_profiles_out; cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc_*.json profiles/pmc_traffic.json gpurun_out/${TAG}_profiles_out/ 2>/dev/null   # (only gpurun_out/ travels back)
