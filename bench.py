@@ -181,7 +181,7 @@ def timed_steps(M, torch, dist, lib, gb, desc, out, cfg, w, h, steps, warmup, wo
     return elapsed, kd.value, kc.value, kn.value
 
 
-def end_to_end(M, batch, xfs, w, h, reps=3):
+def end_to_end(M, batch, xfs, w, h, reps=5):
     """The reference's contract (caller-owned host bitmaps): HOST CSR arrays -> msdfhip_batch_create (H2D + digestion) ->
     msdfhip_batch_generate_host (chunked two-stream pipeline: kernels incl. error correction overlapped with the D2H of the previous
     chunk) into PINNED host tiles; and the 8-bit atlas variant (float tiles stay on the device, 1/4 of the D2H bytes)."""
