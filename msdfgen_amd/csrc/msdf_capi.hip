@@ -64,6 +64,7 @@ struct Tuning {
     char pipelineLengths[128];       // MSDFHIP_PIPELINE_LENGTHS    experiment: explicit chunk lengths "512,1024,..." (the last one repeats)
     bool pipelineTrace;              // MSDFHIP_PIPELINE_TRACE      host-output pipeline prints per chunk when its kernels / its copy back finished (stderr)
     int microbatch;                  // MSDFHIP_MICROBATCH          0 / 1 disables the grouping of concurrent single-shape calls; N caps the group
+    bool noClassSort;                // MSDFHIP_NO_CLASS_SORT       glyph classes in batch order instead of heaviest first (A/B)
     int queryBatch;                  // MSDFHIP_QUERY_BATCH         cooperative distance checks a wavefront of k_ec_query takes per ticket (default 1: more only lengthens the tail)
     char devices[256];               // MSDFHIP_DEVICES             "all" | "0,1,..." devices the single-shape front door spreads over
 };
@@ -94,6 +95,7 @@ void readTuning() {
     if (t.microbatch < 1)
         t.microbatch = 1;
     t.devices[0] = 0;
+    t.noClassSort = getenv("MSDFHIP_NO_CLASS_SORT") != NULL;
     t.queryBatch = (env = getenv("MSDFHIP_QUERY_BATCH")) && atoi(env) > 0 ? atoi(env) : 1;
     if ((env = getenv("MSDFHIP_DEVICES")))
         snprintf(t.devices, sizeof(t.devices), "%s", env);
@@ -467,7 +469,7 @@ int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
             order[at++] = g;
     // Heaviest glyphs first inside each class (longest-processing-time order: a launch is ~26 rounds of workgroups, its tail is the last round's
     // heaviest glyph; the output does not depend on the order -- a glyph writes its own tiles).
-    if (!getenv("MSDFHIP_NO_CLASS_SORT")) {
+    if (!tuning().noClassSort) {
         const int *hE = b->hEdges.data(), *hC = b->hContours.data();
         auto heavier = [hE, hC](int x, int y) { return (long long) hE[x]*(hC[x] > 1 ? hC[x] : 1) > (long long) hE[y]*(hC[y] > 1 ? hC[y] : 1); };
         std::stable_sort(order, order+nOne, heavier);

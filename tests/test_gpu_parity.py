@@ -292,6 +292,41 @@ def test_config4_full_size_atlas_8192_glyphs_48(oracle):
     print("config 4: 24 sampled tiles, %d texels differing bitwise" % worst)
 
 
+def test_scheduling_knobs_do_not_change_a_byte():
+    """Round 3 changed WHEN work runs, never what it computes: glyph classes heaviest first (MSDFHIP_NO_CLASS_SORT), distance checks per ticket
+    (MSDFHIP_QUERY_BATCH), which glyphs take the lane-per-candidate chunks / how many edges get LDS slots (MSDFHIP_QUERY_POLICY,
+    MSDFHIP_QUERY_LDS -- i.e. k_ec_query's cooperative path with register records vs its chunk walk with batched scalar loads on the SAME
+    candidates). 1 024 distinct DejaVu glyphs incl. the 543-edge symbol, msdf with the default correction and mtsdf with ALWAYS_CHECK."""
+    import os
+    z = load_npz("dejavu8192.npz")
+    full = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
+                      z["colors"].astype(np.int32), np.zeros(len(z["names"]), bool), [str(n) for n in z["names"]])
+    n_e = full.contour_offsets[full.glyph_contour_offsets[1:]]-full.contour_offsets[full.glyph_contour_offsets[:-1]]
+    idx = sorted(set(int(i) for i in np.argsort(-n_e)[:64]) | set(range(0, 8192, 8)))[:1024]
+    batch, xfs = full.select(idx), z["xf64"][idx]
+    always = M.MSDFGeneratorConfig(True, M.ErrorCorrectionConfig(M.EC_EDGE_PRIORITY, M.ALWAYS_CHECK_DISTANCE))
+
+    def render():
+        gb = M.GlyphBatch(batch)
+        a = gb.generate(3, 64, 64, xfs).cpu().numpy()
+        b = gb.generate(4, 40, 40, xfs, config=always).cpu().numpy()
+        gb.close()
+        return a, b
+    want = render()
+    knobs = [{"MSDFHIP_NO_CLASS_SORT": "1"}, {"MSDFHIP_QUERY_BATCH": "5"}, {"MSDFHIP_QUERY_POLICY": "150,0,2147483647,0,4e8"},
+             {"MSDFHIP_QUERY_POLICY": "1,128,0,128,0"}, {"MSDFHIP_QUERY_LDS": "700,30"}, {"MSDFHIP_QUERY_LDS": "16,2"}, {"MSDFHIP_SERIAL_CLASSES": "1"}]
+    for env in knobs:
+        os.environ.update(env)
+        M.load().msdfhip_reload_tuning()
+        try:
+            got = render()
+        finally:
+            for k in env:
+                del os.environ[k]
+            M.load().msdfhip_reload_tuning()
+        assert (bits(got[0]) == bits(want[0])).all() and (bits(got[1]) == bits(want[1])).all(), env
+
+
 def test_very_many_contours_use_the_global_combiner_scratch(oracle):
     """Maximum-size edge case: 260 overlapping contours. The overlapping combiner's per-contour scratch (260*3*512 B) exceeds the CU's
     LDS, so k_distance / k_ec_query keep it in a global workspace; results must not change."""
