@@ -223,7 +223,7 @@ typedef double d8 __attribute__((ext_vector_type(8)));
 
 enum { ENTRY_INDEX_BITS = 20, ENTRY_INDEX_MASK = (1<<ENTRY_INDEX_BITS)-1 };   // 1 M edges per glyph (the LDS lists hold far fewer)
 __device__ inline unsigned packEntry(int i, const EdgeRec &e) {
-    return (unsigned) i|(unsigned) e.type<<20|(unsigned) (e.color&7)<<22|(unsigned) (e.flags&7)<<25|(unsigned) ((e.flags>>4)&1)<<28;
+    return (unsigned) (i&ENTRY_INDEX_MASK)|(unsigned) e.type<<20|(unsigned) (e.color&7)<<22|(unsigned) (e.flags&7)<<25|(unsigned) ((e.flags>>4)&1)<<28;   // (index bits: k_distance's lists only; k_ec_query passes the index separately)
 }
 
 struct EdgeRegs {
@@ -388,7 +388,7 @@ __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, con
         i4 words;                                                    // type, color, flags, contour
         asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx4 %3, %4, 0x160\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(r.r0), "=&s"(r.r1), "=&s"(r.e0), "=&s"(words) : "s"(rp));
-        r.meta = (unsigned) i|(unsigned) words[0]<<20|(unsigned) (words[1]&7)<<22|(unsigned) (words[2]&7)<<25|(unsigned) ((words[2]>>4)&1)<<28;   // packEntry
+        r.meta = (unsigned) (i&ENTRY_INDEX_MASK)|(unsigned) words[0]<<20|(unsigned) (words[1]&7)<<22|(unsigned) (words[2]&7)<<25|(unsigned) ((words[2]>>4)&1)<<28;   // packEntry
         double bound2;
         bool relevant = MSDF_WAVE_ANY(selEdgeRelevantBox(sel, r, o, bound2));
         if (SEL >= 2 && !relevant)
