@@ -237,13 +237,15 @@ struct MsdfHipBatch {
     bool serialClasses;               // launch the glyph classes one after the other on the caller's stream (host-output pipeline: its chunks overlap instead)
     unsigned *overflowOut;            // single-shape host calls: where k_ec_query mirrors the candidate-overflow count (then no k_ec_slow launch)
     mutable bool overflowMirrored;    // set by the correction launch when it did so
+    mutable int *dEcOrder;            // glyph indices heaviest first (k_ec_scan / k_ec_query), built on first use; NULL: batch order
+    mutable bool ecOrderTried;
     int glyphCap;                     // per-glyph work buffers are sized for max(nGlyphs, glyphCap) glyphs (views of the host-output pipeline)
     mutable hipStream_t sideStream[2];   // the three glyph classes of the distance pass run concurrently: two of them on these (fork / join by events)
     mutable hipEvent_t forkEvent, joinEvent[2];
     MsdfHipBatch() : device(0), nGlyphs(0), nContours(0), nEdges(0), maxContours(0), maxEdges(0), ownsInputs(false), dGlyphContourOffsets(NULL),
                      dContourOffsets(NULL), dPoints(NULL), dTypes(NULL), dColors(NULL), dRecs(NULL), dWindings(NULL), dScratch(NULL), scratchFloats(0),
                      dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
-                     smallMaxC(0), smallMaxE(0), oneMaxE(0), serialClasses(false), overflowOut(NULL), overflowMirrored(false), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
+                     smallMaxC(0), smallMaxE(0), oneMaxE(0), serialClasses(false), overflowOut(NULL), overflowMirrored(false), dEcOrder(NULL), ecOrderTried(false), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
 };
 
 namespace {
@@ -483,6 +485,28 @@ int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
     }
     b->bucketUploaded = true;
     b->bucketLimit = limit, b->nOne = nOne, b->nSmall = nSmall, b->smallMaxC = smallMaxC, b->smallMaxE = smallMaxE, b->oneMaxE = oneMaxE;
+    return MSDFHIP_OK;
+}
+
+// The work list of the distance checks in heaviest-first order (edges x contours, like the glyph classes above): whole batches of at least
+// 256 glyphs whose per-glyph counts are on the host; views of the host-output pipeline and the single-shape groups keep batch order.
+int ensureEcOrder(const MsdfHipBatch *b, const int **order) {
+    std::lock_guard<std::mutex> lock(b->scratchMutex);
+    *order = b->dEcOrder;
+    if (b->ecOrderTried)
+        return MSDFHIP_OK;
+    b->ecOrderTried = true;
+    if (tuning().noClassSort || b->serialClasses || b->bucketExternal || b->nGlyphs < 256 || b->hEdges.size() != (size_t) b->nGlyphs ||
+        b->hContours.size() != (size_t) b->nGlyphs)
+        return MSDFHIP_OK;
+    std::vector<int> host((size_t) b->nGlyphs);
+    for (int g = 0; g < b->nGlyphs; ++g)
+        host[g] = g;
+    const int *hE = b->hEdges.data(), *hC = b->hContours.data();
+    std::stable_sort(host.begin(), host.end(), [hE, hC](int x, int y) { return (long long) hE[x]*(hC[x] > 1 ? hC[x] : 1) > (long long) hE[y]*(hC[y] > 1 ? hC[y] : 1); });
+    HIPCHK(hipMalloc((void **) &b->dEcOrder, sizeof(int)*host.size()));
+    HIPCHK(hipMemcpy(b->dEcOrder, host.data(), sizeof(int)*host.size(), hipMemcpyHostToDevice));   // once per batch; blocks the host, not a stream
+    *order = b->dEcOrder;
     return MSDFHIP_OK;
 }
 
@@ -782,14 +806,18 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     const size_t wanted = allTexels/512;
     const unsigned queryBlocks = (unsigned) (wanted < 64 ? 64 : wanted > 8192 ? 8192 : wanted);
     hipLaunchKernelGGL(k_ec_params, dim3((unsigned) b->nGlyphs), dim3(WAVE), 0, stream, b->dEcParams, viewOf(b), dGlyphs, cfg,
-                       reinterpret_cast<unsigned *>(deferred), corners);   // also zeroes the candidate header
+                       reinterpret_cast<unsigned *>(deferred), corners, offsets+ecSizesAt(b->nGlyphs));   // also zeroes the candidate header
+    const int *ecOrder = NULL;                                   // glyphs heaviest first for the distance checks' work list (NULL: batch order)
+    rc = ensureEcOrder(b, &ecOrder);
+    if (rc != MSDFHIP_OK)
+        return rc;
     hipLaunchKernelGGL((k_ec_fast<N>), dim3(blocks), dim3(WAVE), fastLds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, src, out, stencil, cfg,
                        (const EcGlyphParams *) b->dEcParams, deferred, seg, b->maxEdges, (const int *) corners);
-    hipLaunchKernelGGL(k_ec_scan, dim3(1), dim3(1024), 0, stream, viewOf(b), reinterpret_cast<const unsigned *>(deferred), seg, offsets, lpcMaxContours);
+    hipLaunchKernelGGL(k_ec_scan, dim3(1), dim3(1024), 0, stream, b->nGlyphs, reinterpret_cast<const unsigned *>(deferred), seg, offsets, lpcMaxContours, ecOrder);
     hipLaunchKernelGGL((k_ec_query<N, OVERLAP>), dim3(queryBlocks), dim3(WAVE), queryLds, stream, b->nGlyphs, b->dGlyphContourOffsets, b->dContourOffsets,
                        (const EdgeRec *) viewOf(b).recs, viewOf(b).windings, dGlyphs, w, h, src, out, stencil, cfg,
                        (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, (const int *) offsets, offsets+2*(size_t) b->nGlyphs+2, tuning().queryBatch, slotCap, slotOffset, lpcMaxContours,
-                       b->overflowOut);
+                       b->overflowOut, ecOrder);
     if (b->overflowOut)
         b->overflowMirrored = true;                              // the caller looks at the count after its copy back and reruns with the pass below if needed
     else
@@ -1262,6 +1290,7 @@ void msdfhip_batch_destroy(MsdfHipBatch *b) {
     hipFree(b->dScratch);
     hipFree(b->dDeferred);
     hipFree(b->dEcParams);
+    hipFree(b->dEcOrder);
     hipFree(b->dGres);
     if (!b->bucketExternal) {
         hipFree(b->dBucket);

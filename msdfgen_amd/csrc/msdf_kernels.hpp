@@ -884,7 +884,7 @@ static_assert(sizeof(EcGlyphParams) == 64, "EcGlyphParams layout");
 // call's transform, appended at corners[2*(e0+slot)]). k_ec_fast then needs ONE dependent load per tile (params -> its corner list)
 // instead of walking glyphContourOffsets -> contourOffsets -> the records' flags in each of the glyph's tiles.
 __global__ void __launch_bounds__(WAVE)
-k_ec_params(EcGlyphParams *out, BatchView batch, const MsdfHipGlyph *glyphs, MsdfHipConfig cfg, unsigned *candidateHeader, int *corners) {
+k_ec_params(EcGlyphParams *out, BatchView batch, const MsdfHipGlyph *glyphs, MsdfHipConfig cfg, unsigned *candidateHeader, int *corners, int *sizes) {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (candidateHeader && lane == 0) {                             // zero the candidate counters for k_ec_fast (saves a memset launch)
         candidateHeader[1+g] = 0;
@@ -919,6 +919,8 @@ k_ec_params(EcGlyphParams *out, BatchView batch, const MsdfHipGlyph *glyphs, Msd
         o.hSpan = p.hSpan, o.vSpan = p.vSpan, o.dSpan = p.dSpan, o.texelX = p.texelX, o.texelY = p.texelY;
         o.radiusH = p.radiusH, o.radiusV = p.radiusV, o.radiusD = p.radiusD, o.cornerBegin = e0, o.nCorners = nCorners, o.pad = 0;
         out[g] = o;
+        if (sizes)
+            sizes[2*g] = nE, sizes[2*g+1] = C;
     }
 }
 
@@ -1150,21 +1152,34 @@ MSDF_HD int ecQueryItems(unsigned count, unsigned seg, int nE, int C, EcQueryPol
 // serial walk of all the glyph's edges by one wavefront. With little work (55 k candidates of the DejaVu set: the kernel is a latency
 // chain) only small glyphs (<= lpcMaxEdges) use it; when the cooperative form of everything would cost more than wideLoad instructions
 // (440 k candidates of the CJK-like set: throughput bound) glyphs up to wideMaxEdges do. offsets[2G+3] = the bound in force.
-MSDF_HD size_t ecOffsetInts(int nGlyphs) { return 2*((size_t) nGlyphs+1)+2; }
+// ... followed by (edges, contours) per glyph, written by k_ec_params (k_ec_scan then reads two ints instead of walking two offset arrays).
+MSDF_HD size_t ecOffsetInts(int nGlyphs) { return 2*((size_t) nGlyphs+1)+2+2*(size_t) nGlyphs; }
+MSDF_HD size_t ecSizesAt(int nGlyphs) { return 2*((size_t) nGlyphs+1)+2; }
 
+// Positions, not glyphs: `order` (or NULL = identity) lists the glyphs HEAVIEST FIRST (edges x contours, sorted once per batch by the host),
+// offsets[] is indexed by position and k_ec_query maps a position back through the same array -- the launch is as long as the work it
+// starts last, like the distance pass (msdf_capi.hip: ensureBuckets).
 __global__ void __launch_bounds__(1024)
-k_ec_scan(BatchView batch, const unsigned *header, unsigned seg, int *offsets, EcQueryPolicy lpcMaxContours) {
+k_ec_scan(int nGlyphs, const unsigned *__restrict__ header, unsigned seg, int *__restrict__ offsets, EcQueryPolicy lpcMaxContours, const int *__restrict__ order) {
     __shared__ int partial[2][1024];
-    const int nGlyphs = batch.nGlyphs;
-    const int t = threadIdx.x, per = (nGlyphs+1023)/1024;
-    const int lo = t*per < nGlyphs ? t*per : nGlyphs, hi = lo+per < nGlyphs ? lo+per : nGlyphs;
+    enum { PER = 8 };                                               // positions per thread and round: their loads are issued together
+    const int t = threadIdx.x;
+    const int *sizes = offsets+ecSizesAt(nGlyphs);
     __shared__ float load[1024];
     float mine = 0;
-    for (int g = lo; g < hi; ++g) {
-        const int nE = batch.contourOffsets[batch.glyphContourOffsets[g+1]]-batch.contourOffsets[batch.glyphContourOffsets[g]];
-        const unsigned count = header[1+g];
-        if (count <= seg)
-            mine += (float) count*(340.f*((nE+WAVE-1)/WAVE)+10.f*nE+1000.f);
+    for (int base = 0; base < nGlyphs; base += 1024*PER) {
+        unsigned count[PER];
+        int nE[PER];
+        MSDF_UNROLL
+        for (int k = 0; k < PER; ++k) {
+            const int p = base+t*PER+k;
+            const int g = p < nGlyphs ? (order ? order[p] : p) : -1;
+            count[k] = g >= 0 ? header[1+g] : 0u, nE[k] = g >= 0 ? sizes[2*g] : 0;
+        }
+        MSDF_UNROLL
+        for (int k = 0; k < PER; ++k)
+            if (count[k] <= seg)
+                mine += (float) count[k]*(340.f*((nE[k]+WAVE-1)/WAVE)+10.f*nE[k]+1000.f);
     }
     load[t] = mine;
     __syncthreads();
@@ -1175,31 +1190,45 @@ k_ec_scan(BatchView batch, const unsigned *header, unsigned seg, int *offsets, E
     }
     if (load[0] > lpcMaxContours.wideLoad && lpcMaxContours.wideMaxEdges > lpcMaxContours.lpcMaxEdges)
         lpcMaxContours.lpcMaxEdges = lpcMaxContours.wideMaxEdges;
-    int sum[2] = { 0, 0 };
-    for (int g = lo; g < hi; ++g) {
-        const int C = batch.glyphContourOffsets[g+1]-batch.glyphContourOffsets[g];
-        const int nE = batch.contourOffsets[batch.glyphContourOffsets[g+1]]-batch.contourOffsets[batch.glyphContourOffsets[g]];
-        sum[ecQueryLanePerCandidate(header[1+g], nE, C, lpcMaxContours) ? 0 : 1] += ecQueryItems(header[1+g], seg, nE, C, lpcMaxContours);
-    }
-    partial[0][t] = sum[0], partial[1][t] = sum[1];
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {                      // inclusive scans of the 1024 partial sums
-        const int v0 = t >= off ? partial[0][t-off] : 0, v1 = t >= off ? partial[1][t-off] : 0;
-        __syncthreads();
-        partial[0][t] += v0, partial[1][t] += v1;
-        __syncthreads();
-    }
-    int at[2] = { partial[0][t]-sum[0], partial[1][t]-sum[1] };
     int *coop = offsets+nGlyphs+1;
-    for (int g = lo; g < hi; ++g) {
-        offsets[g] = at[0], coop[g] = at[1];
-        const int C = batch.glyphContourOffsets[g+1]-batch.glyphContourOffsets[g];
-        const int nE = batch.contourOffsets[batch.glyphContourOffsets[g+1]]-batch.contourOffsets[batch.glyphContourOffsets[g]];
-        at[ecQueryLanePerCandidate(header[1+g], nE, C, lpcMaxContours) ? 0 : 1] += ecQueryItems(header[1+g], seg, nE, C, lpcMaxContours);
+    int carry[2] = { 0, 0 };                                        // items of the earlier rounds (batches of more than 8 192 glyphs)
+    for (int base = 0; base < nGlyphs; base += 1024*PER) {
+        int items[PER];
+        bool chunky[PER];
+        int sum[2] = { 0, 0 };
+        MSDF_UNROLL
+        for (int k = 0; k < PER; ++k) {
+            const int p = base+t*PER+k;
+            const int g = p < nGlyphs ? (order ? order[p] : p) : -1;
+            const unsigned count = g >= 0 ? header[1+g] : 0u;
+            const int nE = g >= 0 ? sizes[2*g] : 0, C = g >= 0 ? sizes[2*g+1] : 0;
+            chunky[k] = g >= 0 && ecQueryLanePerCandidate(count, nE, C, lpcMaxContours);
+            items[k] = g >= 0 ? ecQueryItems(count, seg, nE, C, lpcMaxContours) : 0;
+            sum[chunky[k] ? 0 : 1] += items[k];
+        }
+        partial[0][t] = sum[0], partial[1][t] = sum[1];
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {                  // inclusive scans of the 1024 partial sums
+            const int v0 = t >= off ? partial[0][t-off] : 0, v1 = t >= off ? partial[1][t-off] : 0;
+            __syncthreads();
+            partial[0][t] += v0, partial[1][t] += v1;
+            __syncthreads();
+        }
+        int at[2] = { carry[0]+partial[0][t]-sum[0], carry[1]+partial[1][t]-sum[1] };
+        MSDF_UNROLL
+        for (int k = 0; k < PER; ++k) {
+            const int p = base+t*PER+k;
+            if (p < nGlyphs) {
+                offsets[p] = at[0], coop[p] = at[1];
+                at[chunky[k] ? 0 : 1] += items[k];
+            }
+        }
+        carry[0] += partial[0][1023], carry[1] += partial[1][1023];
+        __syncthreads();
     }
     if (t == 1023) {
-        offsets[nGlyphs] = partial[0][1023];
-        coop[nGlyphs] = partial[1][1023];
+        offsets[nGlyphs] = carry[0];
+        coop[nGlyphs] = carry[1];
         coop[nGlyphs+1] = 0;
         coop[nGlyphs+2] = lpcMaxContours.lpcMaxEdges;
     }
@@ -1235,7 +1264,7 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
            const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, const float *__restrict__ src, float *__restrict__ out,
            uint8_t *__restrict__ stencilOut, MsdfHipConfig cfg, const EcGlyphParams *__restrict__ glyphParams, const EcCandidate *__restrict__ cands, unsigned seg,
            const int *__restrict__ offsets, int *__restrict__ counter, int itemsPerTicket, int slotCap, int slotOffset, EcQueryPolicy lpcMaxContours,
-           unsigned *__restrict__ overflowOut) {
+           unsigned *__restrict__ overflowOut, const int *__restrict__ order) {
     // overflowOut (single-shape host calls): the candidate-overflow count is mirrored next to the results, so that the host sees it with the
     // copy back instead of a k_ec_slow launch that does nothing in all but pathological cases (one launch less on a latency-bound path)
     if (overflowOut && blockIdx.x == 0 && threadIdx.x == 0)
@@ -1283,15 +1312,16 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             else
                 lo = mid+1;
         }
-        int g = lo;
+        int pos = lo;
         MSDF_NOUNROLL
         for (int i = first; i < last; ++i) {
 #if defined(MSDF_PROFILE_QUERY)
         MSDF_QSTAMP(q2a);
 #endif
-        while (part[g+1] <= i)                                      // consecutive items: the same glyph or one of the next few
-            ++g;
-        const int item = i-part[g];
+        while (part[pos+1] <= i)                                    // consecutive items: the same position or one of the next few
+            ++pos;
+        const int item = i-part[pos];
+        const int g = order ? order[pos] : pos;                     // positions list the glyphs heaviest first (k_ec_scan)
 #if defined(MSDF_PROFILE_QUERY)
         MSDF_QSTAMP(q2);
         qAcc[1] += q2-(i == first ? q1 : q2a);
