@@ -64,6 +64,7 @@ struct Tuning {
     char pipelineLengths[128];       // MSDFHIP_PIPELINE_LENGTHS    experiment: explicit chunk lengths "512,1024,..." (the last one repeats)
     bool pipelineTrace;              // MSDFHIP_PIPELINE_TRACE      host-output pipeline prints per chunk when its kernels / its copy back finished (stderr)
     int microbatch;                  // MSDFHIP_MICROBATCH          0 / 1 disables the grouping of concurrent single-shape calls; N caps the group
+    int sidePriority;                // MSDFHIP_SIDE_PRIORITY       queue priority of the side-class streams: low (-1, default) / none (0) / high (+1) / one (-2) / rest (-3)
     bool noClassSort;                // MSDFHIP_NO_CLASS_SORT       glyph classes in batch order instead of heaviest first (A/B)
     int queryBatch;                  // MSDFHIP_QUERY_BATCH         cooperative distance checks a wavefront of k_ec_query takes per ticket (default 1: more only lengthens the tail)
     char devices[256];               // MSDFHIP_DEVICES             "all" | "0,1,..." devices the single-shape front door spreads over
@@ -95,6 +96,7 @@ void readTuning() {
     if (t.microbatch < 1)
         t.microbatch = 1;
     t.devices[0] = 0;
+    t.sidePriority = (env = getenv("MSDFHIP_SIDE_PRIORITY")) ? (env[0] == 'l' ? -1 : env[0] == 'h' ? 1 : env[0] == 'o' ? -2 : env[0] == 'r' ? -3 : 0) : -1;
     t.noClassSort = getenv("MSDFHIP_NO_CLASS_SORT") != NULL;
     t.queryBatch = (env = getenv("MSDFHIP_QUERY_BATCH")) && atoi(env) > 0 ? atoi(env) : 1;
     if ((env = getenv("MSDFHIP_DEVICES")))
@@ -513,8 +515,17 @@ int ensureEcOrder(const MsdfHipBatch *b, const int **order) {
 int ensureSideStreams(const MsdfHipBatch *b) {
     if (b->forkEvent)
         return MSDFHIP_OK;
+    int least = 0, greatest = 0;
+    (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
     for (int k = 0; k < 2; ++k) {
-        HIPCHK(hipStreamCreateWithFlags(&b->sideStream[k], hipStreamNonBlocking));
+        // The two side classes run at LOW queue priority: the long LDS-class launch on the caller's stream gets the slots first and the side
+        // classes fill what it leaves, its tail included (distance pass 3.93 -> 3.80-3.88 ms; high: 4.01). MSDFHIP_SIDE_PRIORITY=none|low|high|one|rest.
+        const int which = tuning().sidePriority;                    // -1 both low, +1 both high, -2 only the one-contour class low, -3 only the global-scratch class low
+        const int prio = (which == -1 || (which == -2 && k == 1) || (which == -3 && k == 0)) ? least : which > 0 ? greatest : 0;
+        if (prio != 0)
+            HIPCHK(hipStreamCreateWithPriority(&b->sideStream[k], hipStreamNonBlocking, prio));
+        else
+            HIPCHK(hipStreamCreateWithFlags(&b->sideStream[k], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&b->joinEvent[k], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&b->forkEvent, hipEventDisableTiming));

@@ -293,7 +293,8 @@ def test_config4_full_size_atlas_8192_glyphs_48(oracle):
 
 
 def test_scheduling_knobs_do_not_change_a_byte():
-    """Round 3 changed WHEN work runs, never what it computes: glyph classes heaviest first (MSDFHIP_NO_CLASS_SORT), distance checks per ticket
+    """Round 3 changed WHEN work runs, never what it computes: glyph classes heaviest first (MSDFHIP_NO_CLASS_SORT), side classes at low queue
+    priority (MSDFHIP_SIDE_PRIORITY), distance checks per ticket
     (MSDFHIP_QUERY_BATCH), which glyphs take the lane-per-candidate chunks / how many edges get LDS slots (MSDFHIP_QUERY_POLICY,
     MSDFHIP_QUERY_LDS -- i.e. k_ec_query's cooperative path with register records vs its chunk walk with batched scalar loads on the SAME
     candidates). 1 024 distinct DejaVu glyphs incl. the 543-edge symbol, msdf with the default correction and mtsdf with ALWAYS_CHECK."""
@@ -314,7 +315,8 @@ def test_scheduling_knobs_do_not_change_a_byte():
         return a, b
     want = render()
     knobs = [{"MSDFHIP_NO_CLASS_SORT": "1"}, {"MSDFHIP_QUERY_BATCH": "5"}, {"MSDFHIP_QUERY_POLICY": "150,0,2147483647,0,4e8"},
-             {"MSDFHIP_QUERY_POLICY": "1,128,0,128,0"}, {"MSDFHIP_QUERY_LDS": "700,30"}, {"MSDFHIP_QUERY_LDS": "16,2"}, {"MSDFHIP_SERIAL_CLASSES": "1"}]
+             {"MSDFHIP_QUERY_POLICY": "1,128,0,128,0"}, {"MSDFHIP_QUERY_LDS": "700,30"}, {"MSDFHIP_QUERY_LDS": "16,2"}, {"MSDFHIP_SERIAL_CLASSES": "1"}, {"MSDFHIP_SIDE_PRIORITY": "none"},
+             {"MSDFHIP_SIDE_PRIORITY": "high"}]
     for env in knobs:
         os.environ.update(env)
         M.load().msdfhip_reload_tuning()
