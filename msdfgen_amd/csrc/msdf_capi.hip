@@ -239,6 +239,8 @@ struct MsdfHipBatch {
     bool serialClasses;               // launch the glyph classes one after the other on the caller's stream (host-output pipeline: its chunks overlap instead)
     unsigned *overflowOut;            // single-shape host calls: where k_ec_query mirrors the candidate-overflow count (then no k_ec_slow launch)
     mutable bool overflowMirrored;    // set by the correction launch when it did so
+    mutable int *hEcOrder;            // (pinned host copy the list below is uploaded from)
+    mutable hipEvent_t ecOrderReady;  // (recorded behind that upload)
     mutable int *dEcOrder;            // glyph indices heaviest first (k_ec_scan / k_ec_query), built on first use; NULL: batch order
     mutable bool ecOrderTried;
     int glyphCap;                     // per-glyph work buffers are sized for max(nGlyphs, glyphCap) glyphs (views of the host-output pipeline)
@@ -247,7 +249,7 @@ struct MsdfHipBatch {
     MsdfHipBatch() : device(0), nGlyphs(0), nContours(0), nEdges(0), maxContours(0), maxEdges(0), ownsInputs(false), dGlyphContourOffsets(NULL),
                      dContourOffsets(NULL), dPoints(NULL), dTypes(NULL), dColors(NULL), dRecs(NULL), dWindings(NULL), dScratch(NULL), scratchFloats(0),
                      dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
-                     smallMaxC(0), smallMaxE(0), oneMaxE(0), serialClasses(false), overflowOut(NULL), overflowMirrored(false), dEcOrder(NULL), ecOrderTried(false), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
+                     smallMaxC(0), smallMaxE(0), oneMaxE(0), serialClasses(false), overflowOut(NULL), overflowMirrored(false), hEcOrder(NULL), ecOrderReady(NULL), dEcOrder(NULL), ecOrderTried(false), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
 };
 
 namespace {
@@ -492,22 +494,31 @@ int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
 
 // The work list of the distance checks in heaviest-first order (edges x contours, like the glyph classes above): whole batches of at least
 // 256 glyphs whose per-glyph counts are on the host; views of the host-output pipeline and the single-shape groups keep batch order.
-int ensureEcOrder(const MsdfHipBatch *b, const int **order) {
+int ensureEcOrder(const MsdfHipBatch *b, const int **order, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(b->scratchMutex);
     *order = b->dEcOrder;
-    if (b->ecOrderTried)
+    if (b->ecOrderTried) {
+        if (b->dEcOrder && b->ecOrderReady)                      // uploaded on the first caller's stream: any other stream waits for that (a no-op once it has landed)
+            HIPCHK(hipStreamWaitEvent(stream, b->ecOrderReady, 0));
         return MSDFHIP_OK;
+    }
     b->ecOrderTried = true;
     if (tuning().noClassSort || b->serialClasses || b->bucketExternal || b->nGlyphs < 256 || b->hEdges.size() != (size_t) b->nGlyphs ||
         b->hContours.size() != (size_t) b->nGlyphs)
         return MSDFHIP_OK;
-    std::vector<int> host((size_t) b->nGlyphs);
+    const size_t bytes = sizeof(int)*(size_t) b->nGlyphs;
+    HIPCHK(pinnedAlloc((void **) &b->hEcOrder, bytes));         // pinned and kept with the batch: the upload is ordered on the launch stream, nobody waits
+    int *host = b->hEcOrder;
     for (int g = 0; g < b->nGlyphs; ++g)
         host[g] = g;
     const int *hE = b->hEdges.data(), *hC = b->hContours.data();
-    std::stable_sort(host.begin(), host.end(), [hE, hC](int x, int y) { return (long long) hE[x]*(hC[x] > 1 ? hC[x] : 1) > (long long) hE[y]*(hC[y] > 1 ? hC[y] : 1); });
-    HIPCHK(hipMalloc((void **) &b->dEcOrder, sizeof(int)*host.size()));
-    HIPCHK(hipMemcpy(b->dEcOrder, host.data(), sizeof(int)*host.size(), hipMemcpyHostToDevice));   // once per batch; blocks the host, not a stream
+    std::stable_sort(host, host+b->nGlyphs, [hE, hC](int x, int y) { return (long long) hE[x]*(hC[x] > 1 ? hC[x] : 1) > (long long) hE[y]*(hC[y] > 1 ? hC[y] : 1); });
+    HIPCHK(hipMalloc((void **) &b->dEcOrder, bytes));
+    const int rcUp = uploadSmall(b->dEcOrder, host, bytes, stream);
+    if (rcUp != MSDFHIP_OK)
+        return rcUp;
+    HIPCHK(hipEventCreateWithFlags(&b->ecOrderReady, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(b->ecOrderReady, stream));
     *order = b->dEcOrder;
     return MSDFHIP_OK;
 }
@@ -819,7 +830,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     hipLaunchKernelGGL(k_ec_params, dim3((unsigned) b->nGlyphs), dim3(WAVE), 0, stream, b->dEcParams, viewOf(b), dGlyphs, cfg,
                        reinterpret_cast<unsigned *>(deferred), corners, offsets+ecSizesAt(b->nGlyphs));   // also zeroes the candidate header
     const int *ecOrder = NULL;                                   // glyphs heaviest first for the distance checks' work list (NULL: batch order)
-    rc = ensureEcOrder(b, &ecOrder);
+    rc = ensureEcOrder(b, &ecOrder, stream);
     if (rc != MSDFHIP_OK)
         return rc;
     hipLaunchKernelGGL((k_ec_fast<N>), dim3(blocks), dim3(WAVE), fastLds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, src, out, stencil, cfg,
@@ -1302,6 +1313,10 @@ void msdfhip_batch_destroy(MsdfHipBatch *b) {
     hipFree(b->dDeferred);
     hipFree(b->dEcParams);
     hipFree(b->dEcOrder);
+    if (b->hEcOrder)
+        pinnedFree(b->hEcOrder);
+    if (b->ecOrderReady)
+        hipEventDestroy(b->ecOrderReady);
     hipFree(b->dGres);
     if (!b->bucketExternal) {
         hipFree(b->dBucket);
