@@ -1161,11 +1161,13 @@ MSDF_HD size_t ecSizesAt(int nGlyphs) { return 2*((size_t) nGlyphs+1)+2; }
 // starts last, like the distance pass (msdf_capi.hip: ensureBuckets).
 __global__ void __launch_bounds__(1024)
 k_ec_scan(int nGlyphs, const unsigned *__restrict__ header, unsigned seg, int *__restrict__ offsets, EcQueryPolicy lpcMaxContours, const int *__restrict__ order) {
-    __shared__ int partial[2][1024];
+    // Sixteen wavefronts: sums and prefix sums run inside a wavefront with lane shuffles and meet once per step in LDS (the first form met at
+    // ~30 workgroup barriers -- a tree in LDS -- and took 47 us of a 1.8 ms correction pass).
+    __shared__ int waveTotals[2][16];
+    __shared__ float waveLoad[16];
     enum { PER = 8 };                                               // positions per thread and round: their loads are issued together
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t&(WAVE-1), wave = t/WAVE;
     const int *sizes = offsets+ecSizesAt(nGlyphs);
-    __shared__ float load[1024];
     float mine = 0;
     for (int base = 0; base < nGlyphs; base += 1024*PER) {
         unsigned count[PER];
@@ -1181,14 +1183,15 @@ k_ec_scan(int nGlyphs, const unsigned *__restrict__ header, unsigned seg, int *_
             if (count[k] <= seg)
                 mine += (float) count[k]*(340.f*((nE[k]+WAVE-1)/WAVE)+10.f*nE[k]+1000.f);
     }
-    load[t] = mine;
+    for (int off = WAVE/2; off > 0; off >>= 1)
+        mine += __shfl_down(mine, off);
+    if (lane == 0)
+        waveLoad[wave] = mine;
     __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if (t < off)
-            load[t] += load[t+off];
-        __syncthreads();
-    }
-    if (load[0] > lpcMaxContours.wideLoad && lpcMaxContours.wideMaxEdges > lpcMaxContours.lpcMaxEdges)
+    float total = 0;
+    for (int w = 0; w < 16; ++w)
+        total += waveLoad[w];                                       // (the same sum in every thread; it only picks a policy, no result depends on it)
+    if (total > lpcMaxContours.wideLoad && lpcMaxContours.wideMaxEdges > lpcMaxContours.lpcMaxEdges)
         lpcMaxContours.lpcMaxEdges = lpcMaxContours.wideMaxEdges;
     int *coop = offsets+nGlyphs+1;
     int carry[2] = { 0, 0 };                                        // items of the earlier rounds (batches of more than 8 192 glyphs)
@@ -1206,15 +1209,23 @@ k_ec_scan(int nGlyphs, const unsigned *__restrict__ header, unsigned seg, int *_
             items[k] = g >= 0 ? ecQueryItems(count, seg, nE, C, lpcMaxContours) : 0;
             sum[chunky[k] ? 0 : 1] += items[k];
         }
-        partial[0][t] = sum[0], partial[1][t] = sum[1];
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {                  // inclusive scans of the 1024 partial sums
-            const int v0 = t >= off ? partial[0][t-off] : 0, v1 = t >= off ? partial[1][t-off] : 0;
-            __syncthreads();
-            partial[0][t] += v0, partial[1][t] += v1;
-            __syncthreads();
+        int incl[2] = { sum[0], sum[1] };                           // inclusive scan over the lanes of this wavefront
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const int n0 = __shfl_up(incl[0], off), n1 = __shfl_up(incl[1], off);
+            if (lane >= off)
+                incl[0] += n0, incl[1] += n1;
         }
-        int at[2] = { carry[0]+partial[0][t]-sum[0], carry[1]+partial[1][t]-sum[1] };
+        if (lane == WAVE-1)
+            waveTotals[0][wave] = incl[0], waveTotals[1][wave] = incl[1];
+        __syncthreads();
+        int before[2] = { 0, 0 }, all[2] = { 0, 0 };
+        for (int w = 0; w < 16; ++w) {
+            const int v0 = waveTotals[0][w], v1 = waveTotals[1][w];
+            if (w < wave)
+                before[0] += v0, before[1] += v1;
+            all[0] += v0, all[1] += v1;
+        }
+        int at[2] = { carry[0]+before[0]+incl[0]-sum[0], carry[1]+before[1]+incl[1]-sum[1] };
         MSDF_UNROLL
         for (int k = 0; k < PER; ++k) {
             const int p = base+t*PER+k;
@@ -1223,8 +1234,8 @@ k_ec_scan(int nGlyphs, const unsigned *__restrict__ header, unsigned seg, int *_
                 at[chunky[k] ? 0 : 1] += items[k];
             }
         }
-        carry[0] += partial[0][1023], carry[1] += partial[1][1023];
-        __syncthreads();
+        carry[0] += all[0], carry[1] += all[1];
+        __syncthreads();                                            // waveTotals are rewritten by the next round
     }
     if (t == 1023) {
         offsets[nGlyphs] = carry[0];
