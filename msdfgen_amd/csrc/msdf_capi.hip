@@ -160,6 +160,9 @@ int channelsOf(int mode) { return mode <= 2 ? 1 : mode; }
 // hipHostMalloc for the library's own staging buffers. The HIP runtime recycles pinned address ranges without ThreadSanitizer seeing
 // the free / allocation pair (it is not instrumented), so under TSan the allocator's own synchronisation is stated explicitly (release at
 // the free, acquire at the allocation) -- otherwise writes of two threads to buffers that merely reuse an address are reported as races.
+// The pairing goes through ONE tag for all pinned memory, not through the block's base address: a recycled range may come back inside a
+// block with another base (seen once in four runs: staging writes of one call reported against the scatter reads of an earlier call of
+// another thread, same addresses, different owners) -- every allocation then acquires every earlier free, as a heap allocator would.
 #if defined(__has_feature)
 #if __has_feature(thread_sanitizer)
 #define MSDFHIP_TSAN 1
@@ -167,18 +170,21 @@ extern "C" void __tsan_acquire(void *addr);
 extern "C" void __tsan_release(void *addr);
 #endif
 #endif
-hipError_t pinnedAlloc(void **p, size_t bytes) {
-    const hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault);
+#if defined(MSDFHIP_TSAN)
+static char gPinnedHeapTag;
+#endif
+hipError_t pinnedAlloc(void **p, size_t bytes, unsigned flags = hipHostMallocDefault) {
+    const hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, flags);
 #if defined(MSDFHIP_TSAN)
     if (e == hipSuccess)
-        __tsan_acquire(*p);                                      // pairs with pinnedFree of the address range's previous owner
+        __tsan_acquire(&gPinnedHeapTag);                         // pairs with the pinnedFree of whoever owned (any part of) the range before
 #endif
     return e;
 }
 hipError_t pinnedFree(void *p) {
 #if defined(MSDFHIP_TSAN)
     if (p)
-        __tsan_release(p);
+        __tsan_release(&gPinnedHeapTag);
 #endif
     return hipHostFree(p);
 }
@@ -1935,13 +1941,13 @@ int msdfhip_host_alloc(void **p, size_t bytes) {
     if (rc != MSDFHIP_OK)
         return rc;
     // portable: usable by every device of the process (the sharded generator writes one buffer from several GPUs)
-    if (hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess)
+    if (pinnedAlloc(p, bytes, hipHostMallocPortable) != hipSuccess)
         return fail(MSDFHIP_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
     return MSDFHIP_OK;
 }
 
 int msdfhip_host_free(void *p) {
-    if (p && hipHostFree(p) != hipSuccess)
+    if (p && pinnedFree(p) != hipSuccess)
         return fail(MSDFHIP_ERR_HIP, "hipHostFree failed");
     return MSDFHIP_OK;
 }
