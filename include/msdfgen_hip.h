@@ -312,8 +312,9 @@ int msdfhip_front_door_devices(int *out, int cap);
 /* The library reads its MSDFHIP_* environment knobs ("environment") once, at first use. Tests and A/B scripts that change
  * the environment of a running process call this to have them read again. Not meant for production code. */
 int msdfhip_reload_tuning(void);
-/* Measurement builds only (-DMSDF_PROFILE_WAITS, tools/profile_waits.py): the per-wavefront cycle table of the distance kernel; a regular
- * build reports zeros. out24: 24 counters. */
+/* Measurement builds only: the per-wavefront cycle table of the distance kernel (-DMSDF_PROFILE_WAITS, tools/profile_waits.py) or of the
+ * distance checks of the error correction (-DMSDF_PROFILE_QUERY, tools/profile_query.py; reset = 2 reads its second page); a regular build
+ * reports zeros. out24: 24 counters. reset = 1 clears the table after reading. */
 int msdfhip_debug_wait_profile(unsigned long long *out24, int reset);
 
 #ifdef __cplusplus
