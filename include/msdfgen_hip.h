@@ -58,7 +58,8 @@ extern "C" {
 #define MSDFHIP_ERR_NO_DEVICE      -1 /* no HIP device / not gfx950 / runtime error at init */
 #define MSDFHIP_ERR_INVALID        -2 /* bad argument */
 #define MSDFHIP_ERR_HIP            -3 /* a HIP call failed; see msdfhip_last_error() */
-#define MSDFHIP_ERR_TOO_COMPLEX    -4 /* a shape has more contours than the LDS-resident combiner state supports */
+#define MSDFHIP_ERR_TOO_COMPLEX    -4 /* (round 3: no longer returned for large shapes -- they take list-free kernels; kept for the error-correction
+                                         kernel's fixed LDS exceeding a device's limit, which no gfx950 input reaches) */
 #define MSDFHIP_ERR_NOMEM          -5
 
 /* MSDFGeneratorConfig + ErrorCorrectionConfig (core/generator-config.h:13-64) without the buffer pointer. */
