@@ -519,12 +519,20 @@ int ensureEcOrder(const MsdfHipBatch *b, const int **order, hipStream_t stream) 
         host[g] = g;
     const int *hE = b->hEdges.data(), *hC = b->hContours.data();
     std::stable_sort(host, host+b->nGlyphs, [hE, hC](int x, int y) { return (long long) hE[x]*(hC[x] > 1 ? hC[x] : 1) > (long long) hE[y]*(hC[y] > 1 ? hC[y] : 1); });
-    HIPCHK(hipMalloc((void **) &b->dEcOrder, bytes));
-    const int rcUp = uploadSmall(b->dEcOrder, host, bytes, stream);
-    if (rcUp != MSDFHIP_OK)
-        return rcUp;
-    HIPCHK(hipEventCreateWithFlags(&b->ecOrderReady, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(b->ecOrderReady, stream));
+    int *dOrder = NULL;
+    HIPCHK(hipMalloc((void **) &dOrder, bytes));
+    if (uploadSmall(dOrder, host, bytes, stream) != MSDFHIP_OK) {  // the list is optional: without it the work list keeps batch order
+        hipFree(dOrder);
+        return MSDFHIP_OK;
+    }
+    if (hipEventCreateWithFlags(&b->ecOrderReady, hipEventDisableTiming) != hipSuccess || hipEventRecord(b->ecOrderReady, stream) != hipSuccess) {
+        (void) hipGetLastError();
+        if (b->ecOrderReady)
+            hipEventDestroy(b->ecOrderReady);
+        b->ecOrderReady = NULL;
+        HIPCHK(hipStreamSynchronize(stream));                    // no event for the other streams to wait on: make sure the list has landed
+    }
+    b->dEcOrder = dOrder;                                        // published only once it is (or is ordered to be) complete
     *order = b->dEcOrder;
     return MSDFHIP_OK;
 }
