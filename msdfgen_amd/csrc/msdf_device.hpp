@@ -34,6 +34,16 @@
 
 namespace msdfhip {
 
+// Wave vote: does ANY lane of the wavefront need this? Used where skipping work is exact whenever no lane needs it and evaluating more is
+// harmless (the walk of k_distance is wave-uniform: every lane looks at the same edge / contour).
+#if defined(MSDF_NO_DYNAMIC_CULL)
+#define MSDF_WAVE_ANY(pred) (true)
+#elif defined(__HIP_DEVICE_COMPILE__)
+#define MSDF_WAVE_ANY(pred) (__any((int) (pred)) != 0)
+#else
+#define MSDF_WAVE_ANY(pred) (pred)                   // host walk: one "lane" at a time, i.e. the most aggressive skipping
+#endif
+
 // ----------------------------------------------------------------------------------------------------- edge record
 
 enum : int32_t {
@@ -112,7 +122,36 @@ MSDF_HD V2 operator-(V2 a) { return mk(-a.x, -a.y); }
 MSDF_HD V2 operator*(double a, V2 b) { return mk(a*b.x, a*b.y); }
 MSDF_HD double dot(V2 a, V2 b) { return a.x*b.x+a.y*b.y; }
 MSDF_HD double cross(V2 a, V2 b) { return a.x*b.y-a.y*b.x; }
-MSDF_HD double vlen(V2 a) { return sqrt(a.x*a.x+a.y*a.y); }
+
+// ---- square root ------------------------------------------------------------------------------------------------------------------
+// hipcc expands the correctly rounded fp64 sqrt(x) to: scale x by 2^256 if x < 2^-767; y = v_rsq_f64(x); g = x*y, h = y/2; one coupled
+// Goldschmidt step on (g, h) and two Newton corrections of g (seven FMAs); scale back; patch x = 0 / inf. For 2^-767 <= x < inf the scaling
+// is the identity and the patch never applies: the SAME seven FMAs without them yield the same bits with 10 instead of 18 instructions.
+// The wavefront takes the compiler's sqrt whenever any lane is outside that range (a texel exactly on a control point: x = 0).
+// msdfhip_debug_sqrt_mismatches compares the two on the device (tests/test_gpu_parity.py).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MSDF_NO_LEAN_SQRT)
+__device__ inline double leanSqrtCore(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x*y;
+    double h = y*.5;
+    const double r = __builtin_fma(-h, g, .5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+__device__ inline double msdfSqrt(double x) {
+    const unsigned hi = (unsigned) __double2hiint(x);
+    if (__any((int) (hi-0x10000000u >= 0x7ff00000u-0x10000000u)))      // some lane: x < 2^-767 (incl. 0, negative) or inf / nan
+        return sqrt(x);
+    return leanSqrtCore(x);
+}
+#else
+MSDF_HD double msdfSqrt(double x) { return sqrt(x); }
+#endif
+MSDF_HD double vlen(V2 a) { return msdfSqrt(a.x*a.x+a.y*a.y); }
 MSDF_HD V2 ld(const double *p) { return mk(p[0], p[1]); }
 MSDF_HD V2 EdgeRec::Lo() const { return ld(lo); }
 MSDF_HD V2 EdgeRec::Hi() const { return ld(hi); }
@@ -131,6 +170,13 @@ MSDF_HD V2 EdgeRec::EP1() const { return ld(ep1); }
 
 MSDF_HD V2 normalize(V2 a, bool allowZero) {                                 // Vector2.hpp:42-46
     double len = vlen(a);
+    if (len != 0)
+        return mk(a.x/len, a.y/len);
+    return mk(0, allowZero ? 0. : 1.);
+}
+
+// normalize(a, allowZero) given len = vlen(a) (the callers below have it at hand; the square root is not recomputed)
+MSDF_HD V2 normalizeLen(V2 a, double len, bool allowZero) {
     if (len != 0)
         return mk(a.x/len, a.y/len);
     return mk(0, allowZero ? 0. : 1.);
@@ -197,7 +243,7 @@ MSDF_HD int solveQuadratic(double x[2], double a, double b, double c) {      // 
     }
     double dscr = b*b-4*a*c;
     if (dscr > 0) {
-        dscr = sqrt(dscr);
+        dscr = msdfSqrt(dscr);
         x[0] = (-b+dscr)/(2*a);
         x[1] = (-b-dscr)/(2*a);
         return 2;
@@ -360,7 +406,12 @@ template <class Rec> MSDF_HD SD sdLinear(const Rec &e, V2 o, double &param) {   
     V2 p0 = e.P0(), p1 = e.PE(), ab = e.AB();
     V2 aq = o-p0;
     param = (e.Flags()&REC_FASTDIV) ? divExact(dot(aq, ab), e.K(0), e.K(5)) : dot(aq, ab)/e.K(0);
-    V2 eq = (param > .5 ? p1 : p0)-o;
+    // eq = (param > .5 ? p1 : p0)-o in the reference. Here its NEGATIVE, picked from o-p1 and o-p0 -- which selAddEdge needs anyway (bp, ap):
+    // four selects instead of eight moves, four selects and a subtraction. IEEE subtraction, multiplication and division are odd functions
+    // (round-to-nearest is symmetric), so -eq yields the same length, and a normalised vector / dot product that differ in sign only --
+    // taken away by the fabs below (an exact zero may change its sign; it is squared, or added to the other product, or fabs'd).
+    V2 bq = o-p1;
+    V2 eq = param > .5 ? bq : aq;
     double endpointDistance = vlen(eq);
     if (param > 0 && param < 1) {
         double orthoDistance = dot(mk(e.K(1), e.K(2)), aq);
@@ -369,7 +420,7 @@ template <class Rec> MSDF_HD SD sdLinear(const Rec &e, V2 o, double &param) {   
             return r;
         }
     }
-    SD r = { nonZeroSign(cross(aq, ab))*endpointDistance, fabs(dot(mk(e.K(3), e.K(4)), normalize(eq, false))) };
+    SD r = { nonZeroSign(cross(aq, ab))*endpointDistance, fabs(dot(mk(e.K(3), e.K(4)), normalizeLen(eq, endpointDistance, false))) };
     return r;
 }
 
@@ -406,15 +457,15 @@ template <class Rec> MSDF_HD SD sdQuadratic(const Rec &e, V2 o, double &param) {
             const double r2 = r*r;
             const double q3 = q*q*q;
             if (r2 < q3) {
-                double t = r/sqrt(q3);
+                double t = r/msdfSqrt(q3);
                 if (t < -1) t = -1;
                 if (t > 1) t = 1;
                 trigT = acos(t);
-                trigQ = -2*sqrt(q);
+                trigQ = -2*msdfSqrt(q);
                 trig = true;
                 solutions = 3;
             } else {
-                const double u = (r < 0 ? 1. : -1.)*powThird(fabs(r)+sqrt(r2-q3));
+                const double u = (r < 0 ? 1. : -1.)*powThird(fabs(r)+msdfSqrt(r2-q3));
                 const double v = u == 0 ? 0 : q/u;
                 x0 = (u+v)-e.K(5);
                 solutions = 1;
@@ -431,11 +482,13 @@ template <class Rec> MSDF_HD SD sdQuadratic(const Rec &e, V2 o, double &param) {
     }
 
     V2 epDir = e.EP0();
-    double minDistance = nonZeroSign(cross(epDir, qa))*vlen(qa);
+    const double lenA = vlen(qa);
+    double minDistance = nonZeroSign(cross(epDir, qa))*lenA;
     param = fast ? divExact(-dot(qa, epDir), e.E0dot(), e.Rcp(1)) : -dot(qa, epDir)/e.E0dot();
+    const V2 qb = p2-o;
+    const double lenB = vlen(qb);
     {
-        V2 qb = p2-o;
-        double distance = vlen(qb);
+        double distance = lenB;
         if (distance < fabs(minDistance)) {
             epDir = e.EP1();
             minDistance = nonZeroSign(cross(epDir, qb))*distance;
@@ -461,9 +514,9 @@ template <class Rec> MSDF_HD SD sdQuadratic(const Rec &e, V2 o, double &param) {
     if (param >= 0 && param <= 1)
         r.dot = 0;
     else if (param < .5)
-        r.dot = fabs(dot(dirN0(e), normalize(qa, false)));
+        r.dot = fabs(dot(dirN0(e), normalizeLen(qa, lenA, false)));
     else
-        r.dot = fabs(dot(dirN1(e), normalize(p2-o, false)));
+        r.dot = fabs(dot(dirN1(e), normalizeLen(qb, lenB, false)));
     return r;
 }
 
@@ -473,11 +526,13 @@ template <class Rec> MSDF_HD SD sdCubic(const Rec &e, V2 o, double &param) {    
     V2 qa = p0-o;
     const bool fast = (e.Flags()&REC_FASTDIV) != 0;
     V2 epDir = e.EP0();
-    double minDistance = nonZeroSign(cross(epDir, qa))*vlen(qa);
+    const double lenA = vlen(qa);
+    double minDistance = nonZeroSign(cross(epDir, qa))*lenA;
     param = fast ? divExact(-dot(qa, epDir), e.E0dot(), e.Rcp(1)) : -dot(qa, epDir)/e.E0dot();
+    const V2 qb = p3-o;
+    const double lenB = vlen(qb);
     {
-        V2 qb = p3-o;
-        double distance = vlen(qb);
+        double distance = lenB;
         if (distance < fabs(minDistance)) {
             epDir = e.EP1();
             minDistance = nonZeroSign(cross(epDir, qb))*distance;
@@ -513,9 +568,9 @@ template <class Rec> MSDF_HD SD sdCubic(const Rec &e, V2 o, double &param) {    
     if (param >= 0 && param <= 1)
         r.dot = 0;
     else if (param < .5)
-        r.dot = fabs(dot(dirN0(e), normalize(qa, false)));
+        r.dot = fabs(dot(dirN0(e), normalizeLen(qa, lenA, false)));
     else
-        r.dot = fabs(dot(dirN1(e), normalize(p3-o, false)));
+        r.dot = fabs(dot(dirN1(e), normalizeLen(qb, lenB, false)));
     return r;
 }
 
@@ -592,6 +647,19 @@ MSDF_HD void pbAddPerp(PB &b, double d) {                                    // 
     if (d >= 0 && d < b.pos)
         b.pos = d;
 }
+// ... for a channel the edge may or may not carry (on: wave-uniform in k_distance). Folded into the conditions, the channel test is a scalar
+// AND on the compare masks; as "if (on) pbAddPerp()" the compiler selected twice (new value, then channel).
+MSDF_HD void pbAddPerpIf(PB &b, double d, bool on) {
+#if defined(MSDF_NO_DIET_PERPMASK)
+    if (on)
+        pbAddPerp(b, d);
+#else
+    if (on & (d <= 0) & (d > b.neg))
+        b.neg = d;
+    if (on & (d >= 0) & (d < b.pos))
+        b.pos = d;
+#endif
+}
 
 MSDF_HD void pbMerge(PB &b, const PB &o) {                                   // edge-selectors.cpp:96-106
     SD a = { o.td, o.tdot }, c = { b.td, b.tdot };
@@ -601,6 +669,24 @@ MSDF_HD void pbMerge(PB &b, const PB &o) {                                   // 
         b.neg = o.neg;
     if (o.pos < b.pos)
         b.pos = o.pos;
+}
+
+// pbMerge for the wave-uniform walk of k_distance: the three selects of the minimum only when some lane's contour is nearer.
+MSDF_HD void pbMergeWave(PB &b, const PB &o) {
+#if defined(MSDF_NO_DIET_MERGE)
+    pbMerge(b, o);
+#else
+    SD a = { o.td, o.tdot }, c = { b.td, b.tdot };
+    const bool less = sdLess(a, c);
+    if (MSDF_WAVE_ANY(less)) {
+        if (less)
+            b.td = o.td, b.tdot = o.tdot, b.perp = o.perp;
+    }
+    if (o.neg > b.neg)
+        b.neg = o.neg;
+    if (o.pos < b.pos)
+        b.pos = o.pos;
+#endif
 }
 
 MSDF_HD double pbCompute(const PB &b) {                                      // edge-selectors.cpp:108-117
@@ -652,6 +738,20 @@ MSDF_HD void selInit(Selector<SEL> &s) {
 MSDF_HD bool sdReplaces(SD sd, int idx, SD cur, int curIdx) {
     return sdLess(sd, cur) || (fabs(sd.d) == fabs(cur.d) && sd.dot == cur.dot && idx < curIdx);
 }
+// The same predicate for the wave-uniform walk of k_distance (every lane looks at the same edge): |distance| decides nearly always; the
+// tie-break (three more compares) is evaluated only when SOME lane has an exact tie (edges meeting in a corner point, seen from a texel
+// beyond it).
+MSDF_HD bool sdReplacesWave(SD sd, int idx, SD cur, int curIdx) {
+#if defined(MSDF_NO_DIET_TIES)
+    return sdReplaces(sd, idx, cur, curIdx);
+#else
+    const double a = fabs(sd.d), b = fabs(cur.d);
+    bool r = a < b;
+    if (MSDF_WAVE_ANY(a == b))
+        r = r || (a == b && (sd.dot < cur.dot || (sd.dot == cur.dot && idx < curIdx)));
+    return r;
+#endif
+}
 
 // addEdge: edge-selectors.cpp:19-29 (true), :129-160 (perpendicular), :174-227 (multi)
 template <int SEL, class Rec>
@@ -659,7 +759,7 @@ MSDF_HD void selAddEdge(Selector<SEL> &s, const Rec &e, int idx, V2 o) {
     if (SEL == 1) {
         double dummy;
         SD sd = signedDistance(e, o, dummy);
-        if (sdReplaces(sd, idx, s.m, s.idx[0]))
+        if (sdReplacesWave(sd, idx, s.m, s.idx[0]))
             s.m = sd, s.idx[0] = idx;
         return;
     }
@@ -672,7 +772,7 @@ MSDF_HD void selAddEdge(Selector<SEL> &s, const Rec &e, int idx, V2 o) {
     bool any = false;
     for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i) {                     // addEdgeTrueDistance, edge-selectors.cpp:81-87
         SD cur = { s.c[i].td, s.c[i].tdot };
-        nearer[i] = (mask&(1<<i)) && sdReplaces(sd, idx, cur, s.idx[i]);
+        nearer[i] = (mask&(1<<i)) && sdReplacesWave(sd, idx, cur, s.idx[i]);
         any = any || nearer[i];
     }
     if (any) {
@@ -691,16 +791,14 @@ MSDF_HD void selAddEdge(Selector<SEL> &s, const Rec &e, int idx, V2 o) {
         if (getPerpendicularDistance(pd, ap, -e.ADirN())) {
             pd = -pd;
             for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
-                if (mask&(1<<i))
-                    pbAddPerp(s.c[i], pd);
+                pbAddPerpIf(s.c[i], pd, (mask&(1<<i)) != 0);
         }
     }
     if (bdd > 0) {
         double pd = sd.d;
         if (getPerpendicularDistance(pd, bp, e.BDirN())) {
             for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
-                if (mask&(1<<i))
-                    pbAddPerp(s.c[i], pd);
+                pbAddPerpIf(s.c[i], pd, (mask&(1<<i)) != 0);
         }
     }
 }
@@ -725,9 +823,16 @@ MSDF_HD bool selEdgeRelevantBox(const Selector<SEL> &s, const Rec &e, V2 o, doub
         if (!mask)
             return false;
         bound2 = 0;
+#if defined(MSDF_NO_DIET_BOUND)
         for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
             if (mask&(1<<i))
                 bound2 = cmax(bound2, s.c[i].td*s.c[i].td);
+#else
+        // a channel the edge does not carry contributes (td*0)*td = +0 (also for td = -DBL_MAX): the wave-uniform channel bit becomes a scalar
+        // factor of the product instead of two selects per channel
+        for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
+            bound2 = cmax(bound2, (s.c[i].td*((mask&(1<<i)) ? 1. : 0.))*s.c[i].td);
+#endif
     }
     bound2 *= 1+1e-9;                                // (-DBL_MAX)^2 = inf: nothing is skipped until a channel has a candidate
     const double dx = cmax(cmax(e.Lo().x-o.x, o.x-e.Hi().x), 0.);
@@ -758,14 +863,6 @@ MSDF_HD bool selEdgeRelevant(const Selector<SEL> &s, const Rec &e, V2 o) {
     return selEdgeRelevantBox(s, e, o, bound2) || selEdgeRelevantWedges<SEL>(e, o, bound2);
 }
 
-#if defined(MSDF_NO_DYNAMIC_CULL)
-#define MSDF_WAVE_ANY(pred) (true)
-#elif defined(__HIP_DEVICE_COMPILE__)
-#define MSDF_WAVE_ANY(pred) (__any((int) (pred)) != 0)
-#else
-#define MSDF_WAVE_ANY(pred) (pred)                   // host walk: one "lane" at a time, i.e. the most aggressive skipping
-#endif
-
 template <int SEL>
 MSDF_HD void selMerge(Selector<SEL> &s, const Selector<SEL> &o) {            // edge-selectors.cpp:31-34, 229-233
     if (SEL == 1) {
@@ -774,7 +871,7 @@ MSDF_HD void selMerge(Selector<SEL> &s, const Selector<SEL> &o) {            // 
         return;
     }
     for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
-        pbMerge(s.c[i], o.c[i]);
+        pbMergeWave(s.c[i], o.c[i]);
 }
 
 // distance(): edge-selectors.cpp:36, :162, :235-260. out has NCH entries.
@@ -913,7 +1010,18 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
                     res[(c*NCH+ch)*rstride] = d[ch];
                 const double m = resolve<SEL>(d);
                 const int w = windings[c];
+#if !defined(MSDF_DIET_FIRSTCONTOUR)
                 selMerge(acc, sel);
+#else                                                 // measured: +31 spilled VGPRs in <3,true,false> (the branch keeps both paths live); off
+                // merge(initial state, sel) == sel, field by field (edge-selectors.cpp:96-106 against :54: any minimum beats -DBL_MAX, an
+                // untouched channel IS the initial state): the first contour's selector is copied instead of merged
+                if (c == 0) {
+                    acc.m = sel.m;
+                    for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
+                        acc.c[i] = sel.c[i];
+                } else
+                    selMerge(acc, sel);
+#endif
                 if (w > 0 && m >= 0) {
                     if (!nInner)
                         firstInner = c;
@@ -951,10 +1059,14 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
     double dist[NCH];
     for (int ch = 0; ch < NCH; ++ch)
         dist[ch] = -DBL_MAX;
+    // dm = resolve(dist) travels with dist (the reference re-evaluates the median in every comparison, contour-combiners.cpp:113-130: the
+    // same function of the same values -- when dist becomes a contour's distance, its median is that contour's cm)
     int winding = 0;
+    double dm;
     if (innerScalar >= 0 && fabs(innerScalar) <= fabs(outerScalar)) {
         for (int ch = 0; ch < NCH; ++ch)
             dist[ch] = innerD[ch];
+        dm = innerScalar;
         winding = 1;
         for (int c = 0; c < C; ++c)
             if (windings[c] > 0) {
@@ -962,13 +1074,16 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
                 for (int ch = 0; ch < NCH; ++ch)
                     cd[ch] = res[(c*NCH+ch)*rstride];
                 const double cm = resolve<SEL>(cd);
-                if (fabs(cm) < fabs(outerScalar) && cm > resolve<SEL>(dist))
+                if (fabs(cm) < fabs(outerScalar) && cm > dm) {
                     for (int ch = 0; ch < NCH; ++ch)
                         dist[ch] = cd[ch];
+                    dm = cm;
+                }
             }
     } else if (outerScalar <= 0 && fabs(outerScalar) < fabs(innerScalar)) {
         for (int ch = 0; ch < NCH; ++ch)
             dist[ch] = outerD[ch];
+        dm = outerScalar;
         winding = -1;
         for (int c = 0; c < C; ++c)
             if (windings[c] < 0) {
@@ -976,9 +1091,11 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
                 for (int ch = 0; ch < NCH; ++ch)
                     cd[ch] = res[(c*NCH+ch)*rstride];
                 const double cm = resolve<SEL>(cd);
-                if (fabs(cm) < fabs(innerScalar) && cm < resolve<SEL>(dist))
+                if (fabs(cm) < fabs(innerScalar) && cm < dm) {
                     for (int ch = 0; ch < NCH; ++ch)
                         dist[ch] = cd[ch];
+                    dm = cm;
+                }
             }
     } else {
         for (int ch = 0; ch < NCH; ++ch)
@@ -991,12 +1108,14 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
             double cd[NCH];
             for (int ch = 0; ch < NCH; ++ch)
                 cd[ch] = res[(c*NCH+ch)*rstride];
-            const double cm = resolve<SEL>(cd), dm = resolve<SEL>(dist);
-            if (cm*dm >= 0 && fabs(cm) < fabs(dm))
+            const double cm = resolve<SEL>(cd);
+            if (cm*dm >= 0 && fabs(cm) < fabs(dm)) {
                 for (int ch = 0; ch < NCH; ++ch)
                     dist[ch] = cd[ch];
+                dm = cm;
+            }
         }
-    if (resolve<SEL>(dist) == resolve<SEL>(shapeD))
+    if (dm == resolve<SEL>(shapeD))
         for (int ch = 0; ch < NCH; ++ch)
             dist[ch] = shapeD[ch];
     for (int ch = 0; ch < NCH; ++ch)
