@@ -84,6 +84,54 @@ def rank_shard(batch, xfs, glyphs_per_gpu, world, rank, w, h):
     return batch.select(idx[lo:hi]), xfs[idx[lo:hi]], (lo, hi), bounds
 
 
+def config4_sets():
+    """BASELINE.json configs[3] AS STATED: ONE 8 192-glyph atlas, msdf 48x48, glyph-sharded over the GPUs (strong scaling). NotoSansCJK is not
+    on the box; two stand-ins: the CJK-like synthetic set (512 distinct many-contour shapes x 16: 82.6 edges / 13.7 contours per glyph, the
+    class that runs in the global workspace; pinned by tests/golden/cjk512.npz) and the real-font set (8 192 distinct DejaVu glyphs)."""
+    from msdfgen_amd import synth
+    from msdfgen_amd.shape import ShapeBatch, autoframe
+    base = [synth.cjk_like_shape(20000+i) for i in range(512)]
+    cj = ShapeBatch.from_shapes([base[i % 512] for i in range(8192)])
+    cx = np.stack([autoframe(s.bounds(), 48, 48, 4) for s in base])[np.arange(8192) % 512]
+    z = np.load(os.path.join(ROOT, "tests", "golden", "dejavu8192.npz"))
+    return {"cjk_like": (cj, cx), "dejavu": (_batch(z), z["xf48"])}
+
+
+def step_ms(M, torch, lib, dev, stream, batch, xfs, w, h, cfg, steps, warmup=2):
+    """ms per step (digest + distance + correction, HBM resident) of one glyph list alone on the device."""
+    gb = M.GlyphBatch(batch, dev)
+    out = torch.empty((batch.n_glyphs, h, w, 3), dtype=torch.float32, device=dev)
+    elapsed, kd, kc, _ = timed_steps(M, torch, None, lib, gb, gb.descriptors(xfs, w, h, 3), out, cfg, w, h, steps, warmup, 1, dev, stream)
+    gb.close()
+    return 1e3*elapsed/steps, kd, kc
+
+
+def strong_scaling_one_gpu(M, torch, lib, dev, stream, cfg, steps=6, parts=(2, 4, 8), only=None):
+    """Strong scaling of config 4 REHEARSED ON ONE GPU: the 8 192-glyph set cut into N contiguous shards of equal modelled cost
+    (msdfgen_amd.shard, what `--strong --gpus N` gives rank r), every shard timed ALONE on this device.  efficiency(N) = T(whole set) /
+    (N x max_r T(shard r)) -- what N such GPUs would deliver relative to N times one GPU, PCIe / host effects aside."""
+    from msdfgen_amd.shard import partition_contiguous, glyph_costs
+    res = {}
+    for name, (batch, xfs) in config4_sets().items():
+        if only and name != only:
+            continue
+        whole, kd, kc = step_ms(M, torch, lib, dev, stream, batch, xfs, 48, 48, cfg, steps)
+        costs = glyph_costs(batch, 48, 48)
+        row = {"ms_whole_set": round(whole, 3), "glyphs_per_s_1gpu": round(batch.n_glyphs/whole*1e3), "kernel_ms": {"distance": round(kd, 3), "error_correction": round(kc, 3)}}
+        for n in parts:
+            b = partition_contiguous(costs, n)
+            t = []
+            for r in range(n):
+                lo, hi = int(b[r]), int(b[r+1])
+                t.append(step_ms(M, torch, lib, dev, stream, batch.select(range(lo, hi)), xfs[lo:hi], 48, 48, cfg, steps)[0])
+            row["x%d" % n] = {"efficiency": round(whole/(n*max(t)), 3), "ms_per_shard": [round(v, 3) for v in t], "glyphs_per_shard": [int(b[r+1]-b[r]) for r in range(n)],
+                              "projected_glyphs_per_s": round(batch.n_glyphs/max(t)*1e3)}
+        res[name] = row
+    res["note"] = ("BASELINE config 4 as stated (ONE 8192-glyph 48x48 msdf atlas over N GPUs), rehearsed on one GPU: every shard timed alone on this device; "
+                   "efficiency = T(8192) / (N * max_r T(shard r)); measured multi-GPU: bench.py --strong --gpus N")
+    return res
+
+
 def algorithmic_bytes(batch, w, h, n):
     """per glyph W*H*N*4 (texels written once) + 72*E (each edge read once) + 48 (transform, mapping, dims)."""
     return batch.n_glyphs*(w*h*n*4+48)+72*batch.n_edges
@@ -145,8 +193,10 @@ def profile_counters(args, w, h):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         t = json.load(open(path))
-        if t.get("glyphs_per_gpu") == args.glyphs and t.get("tile") == [w, h] and t.get("workload") == "dejavu8192":
-            return t
+        if t.get("glyphs_per_gpu") == args.glyphs and t.get("tile") == [w, h] and t.get("workload") == "dejavu8192" and not args.strong:
+            from msdfgen_amd.build import source_hash
+            if t.get("source_hash") == source_hash():               # counters of OTHER kernels than the ones timed here are not quoted
+                return t
     except (OSError, ValueError, KeyError):
         pass
     return None
@@ -346,6 +396,9 @@ def main():
     ap.add_argument("--mock", action="store_true", help="CPU rehearsal of the multi-rank control path (gloo, no kernels); used by the tests")
     ap.add_argument("--same-device", action="store_true", help="rehearsal of the N > 1 path on a ONE-GPU box: every rank uses cuda:0 and the process "
                                                                 "group is gloo (RCCL refuses two ranks on one device); the number is not a scaling result")
+    ap.add_argument("--strong", action="store_true", help="BASELINE config 4 as stated: ONE 8192-glyph 48x48 msdf atlas (--strong-set) glyph-sharded over "
+                                                           "--gpus ranks (strong scaling: total work fixed); with --gpus 1 also the one-GPU rehearsal of the N-way splits")
+    ap.add_argument("--strong-set", default="cjk_like", choices=["cjk_like", "dejavu"])
     ap.add_argument("--inprocess", action="store_true", help="one process drives all --gpus devices through msdfhip_generate_sharded (end to end; prints its own JSON line)")
     args = ap.parse_args()
 
@@ -385,11 +438,20 @@ def main():
     lib = M.load()
 
     w = h = args.size
-    dejavu, xf64, bounds = load_dejavu()
-    if w != 64:
-        from msdfgen_amd.shape import autoframe
-        xf64 = np.stack([autoframe(b, w, h, 4) for b in bounds])
-    batch, xfs, (lo, hi), shard_bounds = rank_shard(dejavu, xf64, args.glyphs, world, rank, w, h)
+    if args.strong:
+        # config 4 as BASELINE states it: ONE 8 192-glyph set, 48x48, cut into `world` contiguous shards of equal modelled cost (total work fixed)
+        from msdfgen_amd.shard import partition_contiguous, glyph_costs
+        w = h = 48
+        whole, wxf = config4_sets()[args.strong_set]
+        shard_bounds = partition_contiguous(glyph_costs(whole, w, h), world)
+        lo, hi = int(shard_bounds[rank]), int(shard_bounds[rank+1])
+        batch, xfs = whole.select(range(lo, hi)), wxf[lo:hi]
+    else:
+        dejavu, xf64, bounds = load_dejavu()
+        if w != 64:
+            from msdfgen_amd.shape import autoframe
+            xf64 = np.stack([autoframe(b, w, h, 4) for b in bounds])
+        batch, xfs, (lo, hi), shard_bounds = rank_shard(dejavu, xf64, args.glyphs, world, rank, w, h)
     gb = M.GlyphBatch(batch, dev)
     desc = gb.descriptors(xfs, w, h, 3)
     out = torch.empty((batch.n_glyphs, h, w, 3), dtype=torch.float32, device=dev)
@@ -403,23 +465,26 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        total_glyphs = world*args.glyphs*args.steps
+        total_glyphs = (8192 if args.strong else world*args.glyphs)*args.steps
         ab = algorithmic_bytes(batch, w, h, 3)
         achieved = ab/(dist_ms*1e-3)/1e9 if dist_ms > 0 else 0.
         gflops = algorithmic_flops(batch, w, h)/(dist_ms*1e-3)/1e9 if dist_ms > 0 else 0.
         prof = profile_counters(args, w, h)
         res = {
-            "metric": "MSDF glyphs/sec (64x64, fp32)", "value": total_glyphs/elapsed, "unit": "glyphs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3*elapsed/args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "MSDF glyphs/sec (48x48, fp32), BASELINE config 4: one 8192-glyph atlas glyph-sharded over the GPUs" if args.strong else "MSDF glyphs/sec (64x64, fp32)",
+            "value": total_glyphs/elapsed, "unit": "glyphs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3*elapsed/args.steps, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "msdf %dx%d tiles, %d DISTINCT glyphs per GPU per step = the first 8192 glyphs with outlines of DejaVuSans + DejaVuSans-Bold "
+            "config": {"workload": ("STRONG scaling, BASELINE config 4: ONE 8192-glyph set (%s) msdf 48x48 cut into %d contiguous shards of equal modelled cost, "
+                                    "library-default config; step = digest + distance field + error correction of the rank's shard, HBM resident; value = 8192 glyphs / slowest rank"
+                                    % (args.strong_set, world)) if args.strong else "msdf %dx%d tiles, %d DISTINCT glyphs per GPU per step = the first 8192 glyphs with outlines of DejaVuSans + DejaVuSans-Bold "
                                    "(%.1f edges, %.2f contours per glyph; tests/golden/dejavu8192.npz, every tile pinned to the compiled reference); "
                                    "overlapSupport=true, error correction EDGE_PRIORITY+CHECK_DISTANCE_AT_EDGE (library defaults); "
                                    "step = digest + distance field + error correction, inputs/outputs resident in HBM" % (
                                        w, h, args.glyphs, batch.n_edges/batch.n_glyphs, batch.n_contours/batch.n_glyphs),
-                       "glyphs_per_gpu": args.glyphs, "tile": [w, h], "mode": "msdf",
+                       "glyphs_per_gpu": batch.n_glyphs if args.strong else args.glyphs, "tile": [w, h], "mode": "msdf",
                        "parallelism": "glyph-sharded x%d into ranges of equal modelled cost (msdfgen_amd.shard), no collective; rank 0 owns glyphs [%d, %d) of %d%s" % (
-                           world, lo, hi, world*args.glyphs, " -- REHEARSAL: all ranks on one GPU, gloo" if args.same_device else "")},
+                           world, lo, hi, 8192 if args.strong else world*args.glyphs, " -- REHEARSAL: all ranks on one GPU, gloo" if args.same_device else "")},
             "roofline": {"bound": "hbm", "kernel": "k_distance<3,...> distance pass (msdf; three launches: 1-contour glyphs / combiner scratch in LDS / in the global workspace)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS,
                          "traffic": prof["hbm_bytes_per_launch"] if prof else None,
@@ -428,7 +493,12 @@ def main():
                          "algorithmic_bytes_per_launch": ab, "avg_launch_ms": dist_ms, "launches_timed": launches,
                          "note": "arithmetic intensity ~400 fp64 flop/B: the pass is fp64-VALU bound, not HBM bound (SURVEY.md 8d); "
                                  "the HBM fraction is reported as the contract asks, the binding resource is in `valu_fp64`"},
-            "valu_fp64": {"achieved": gflops, "peak": FP64_VECTOR_PEAK_GFLOPS, "unit": "GFLOP/s (algorithmic estimate, SURVEY.md 8d)", "frac": gflops/FP64_VECTOR_PEAK_GFLOPS,
+            "valu_fp64": {"achieved": gflops, "peak": FP64_VECTOR_PEAK_GFLOPS, "unit": "GFLOP/s (algorithmic ESTIMATE: SURVEY.md 8d's per-edge flop figures over ALL edges; the "
+                                                                                      "kernels cull most of them -- not an achieved rate, see measured_*)", "frac": gflops/FP64_VECTOR_PEAK_GFLOPS,
+                          "measured_gflops": prof.get("fp64_gflops_pmc") if prof else None,
+                          "measured_frac": (prof["fp64_gflops_pmc"]/FP64_VECTOR_PEAK_GFLOPS if prof and prof.get("fp64_gflops_pmc") else None),
+                          "measured_note": prof.get("fp64_note") if prof else None,
+                          "valu_other_over_valu_insts": prof.get("valu_other_over_valu_insts") if prof else None,
                           "valu_issue_frac_pmc": prof.get("valu_busy_frac_calibrated") if prof else None,
                           "valu_issue_frac_pmc_per_kernel": prof.get("valu_busy_per_kernel") if prof else None,
                           "valu_issue_frac_pmc_note": prof.get("valu_busy_note") if prof else None},
@@ -459,7 +529,9 @@ def main():
                                  "note": "all %d ranks run msdfhip_batch_create + msdfhip_batch_generate_host / _bytes_host on their shards SIMULTANEOUSLY "
                                          "(barrier, then each rank its own median of 2 runs); aggregate = all glyphs / slowest rank" % world,
                                  "rank0": mine}
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and args.strong:
+        res["strong_scaling"] = strong_scaling_one_gpu(M, torch, lib, dev, stream, cfg, steps=max(3, args.steps//4), only=args.strong_set)
+    if rank == 0 and world == 1 and not args.no_extras and not args.strong:
         res["end_to_end"] = end_to_end(M, batch, xfs, w, h)
         latin, lxf = load_latin()
         if w != 64:
@@ -469,6 +541,19 @@ def main():
         g2 = M.GlyphBatch(lb, dev)
         o2 = torch.empty((lb.n_glyphs, h, w, 3), dtype=torch.float32, device=dev)
         e2, d2, c2, _ = timed_steps(M, torch, dist, lib, g2, g2.descriptors(lx, w, h, 3), o2, cfg, w, h, max(5, args.steps//3), 2, 1, dev, stream)
+        e2e = res["end_to_end"]
+        fl = min(e2e["ms_flatten"]["per_pass_over_all_glyphs"].values()) if "ms_flatten" in e2e else None
+        ms_u8 = e2e["float_tiles"]["ms_upload_and_digest"]+e2e["uint8_atlas"]["ms_generate_convert_and_copy_back"]
+        ms_f32 = e2e["float_tiles"]["ms_upload_and_digest"]+e2e["float_tiles"]["ms_generate_and_copy_back"]
+        res["end_to_end_metric"] = {
+            "metric": "MSDF glyphs/sec (64x64) END TO END as SURVEY.md 8(d) defines it: Shape -> CSR flatten + H2D + digest + kernels incl. error correction + D2H",
+            "uint8_atlas_glyphs_per_s": batch.n_glyphs/((ms_u8+(fl or 0.))*1e-3), "float_tiles_glyphs_per_s": batch.n_glyphs/((ms_f32+(fl or 0.))*1e-3),
+            "ms": {"flatten": fl, "upload_and_digest": e2e["float_tiles"]["ms_upload_and_digest"], "uint8_generate_convert_copy_back": e2e["uint8_atlas"]["ms_generate_convert_and_copy_back"],
+                   "float_generate_copy_back": e2e["float_tiles"]["ms_generate_and_copy_back"]},
+            "note": "the 8-bit atlas (pixelFloatToByte on the device, a quarter of the D2H bytes) is what an atlas tool consumes; the float path is PCIe bound "
+                    "(%d MB D2H). `value` above is the HBM-resident step as the bench contract asks; flatten %s" % (
+                        e2e["float_tiles"]["d2h_bytes"]//1000000, "measured by the shim's own client on the usable host threads" if fl else "NOT measured on this box (tests/shim/shim_check absent)")}
+        res["strong_scaling"] = strong_scaling_one_gpu(M, torch, lib, dev, stream, cfg, steps=max(3, args.steps//6))
         res["secondary"] = {"workload": "round 1's bench workload: DejaVuSans Basic-Latin (94 prepared shapes, 15.6 edges / 1.41 contours per glyph) tiled to %d glyphs" % args.glyphs,
                             "glyphs_per_s": args.glyphs*max(5, args.steps//3)/e2, "kernel_ms": {"distance": d2, "error_correction": c2}}
         g2.close()

@@ -39,6 +39,16 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+def source_hash():
+    """sha256 (12 hex digits) over the kernel / C-ABI sources: profiles record it, bench.py quotes a committed PMC profile only if it matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def build_lib(force=False, verbose=False):
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "msdfgen_hip.h")]
     if not force and not _stale(LIB, srcs):

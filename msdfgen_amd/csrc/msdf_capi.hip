@@ -41,10 +41,10 @@ int fail(int code, const char *fmt, ...) {
 
 // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), in order WITHIN a queue: the host-output
 // pipeline's three chunk streams (plus the caller's own streams) then alias, and a chunk's kernels wait for another chunk's 100 MB copy
-// (measured with MSDFHIP_PIPELINE_TRACE: 12.0 -> 10.2 ms per 8 192 glyphs with 8 queues). The variable is read when the runtime initialises,
-// so this library asks for 8 when it is LOADED -- unless the environment already says something, and without effect if the host
-// initialised HIP earlier. INTEGRATION.md, "environment".
-__attribute__((constructor)) static void msdfhipAskForHardwareQueues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// (measured with MSDFHIP_PIPELINE_TRACE: 12.0 -> 10.2 ms per 8 192 glyphs with 8 queues). The variable is read when the runtime initialises
+// and belongs to the HOST PROCESS: the library does not touch the environment (round 3 called setenv from a load-time constructor --
+// not thread-safe against the host's other threads, and a silent change for every other HIP user of the process). INTEGRATION.md,
+// "environment", recommends GPU_MAX_HW_QUEUES=8; msdfgen_amd/lib.py (the Python host of the tests and the bench) sets it before HIP starts.
 
 static long long nowNsEarly() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -67,13 +67,16 @@ struct Tuning {
     int sidePriority;                // MSDFHIP_SIDE_PRIORITY       queue priority of the side-class streams: low (-1, default) / none (0) / high (+1) / one (-2) / rest (-3)
     bool noClassSort;                // MSDFHIP_NO_CLASS_SORT       glyph classes in batch order instead of heaviest first (A/B)
     int queryBatch;                  // MSDFHIP_QUERY_BATCH         cooperative distance checks a wavefront of k_ec_query takes per ticket (default 1: more only lengthens the tail)
+    long smallLaunchTiles;           // MSDFHIP_SMALL_LAUNCH_TILES  launches of at most this many tiles take one tile per wavefront (latency-shaped form)
     char devices[256];               // MSDFHIP_DEVICES             "all" | "0,1,..." devices the single-shape front door spreads over
 };
-Tuning gTuning;
-std::once_flag gTuningOnce;
+// Published through an atomic pointer: msdfhip_reload_tuning() builds a fresh table and swaps it in while launch paths on other threads keep
+// reading the one they loaded (superseded tables are never freed: a few hundred bytes per reload, tests and A/B scripts only).
+std::atomic<const Tuning *> gTuning(NULL);
+std::mutex gTuningMutex;
 
 void readTuning() {
-    Tuning t;
+    Tuning &t = *new Tuning;
     const char *env;
     t.resLdsBudget = (env = getenv("MSDFHIP_RES_LDS_BUDGET")) ? (size_t) atol(env) : (size_t) 13*1024;
     t.persistentRounds = (env = getenv("MSDFHIP_PERSISTENT_ROUNDS")) ? atol(env) : 8;
@@ -99,14 +102,21 @@ void readTuning() {
     t.sidePriority = (env = getenv("MSDFHIP_SIDE_PRIORITY")) ? (env[0] == 'l' ? -1 : env[0] == 'h' ? 1 : env[0] == 'o' ? -2 : env[0] == 'r' ? -3 : 0) : -1;
     t.noClassSort = getenv("MSDFHIP_NO_CLASS_SORT") != NULL;
     t.queryBatch = (env = getenv("MSDFHIP_QUERY_BATCH")) && atoi(env) > 0 ? atoi(env) : 1;
+    t.smallLaunchTiles = (env = getenv("MSDFHIP_SMALL_LAUNCH_TILES")) ? atol(env) : 8192;
     if ((env = getenv("MSDFHIP_DEVICES")))
         snprintf(t.devices, sizeof(t.devices), "%s", env);
-    gTuning = t;
+    gTuning.store(&t, std::memory_order_release);
 }
 
 const Tuning &tuning() {
-    std::call_once(gTuningOnce, readTuning);
-    return gTuning;
+    const Tuning *t = gTuning.load(std::memory_order_acquire);
+    if (!t) {
+        std::lock_guard<std::mutex> lock(gTuningMutex);
+        if (!gTuning.load(std::memory_order_acquire))
+            readTuning();
+        t = gTuning.load(std::memory_order_acquire);
+    }
+    return *t;
 }
 
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void) hipGetLastError(); return fail(MSDFHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
@@ -287,6 +297,7 @@ int digest(MsdfHipBatch *b, hipStream_t stream) {
 struct LdsPlan { size_t bytes; bool globalRes; size_t resBytes, ldsBudget, idxBytes; int listStride; };
 const size_t GRES_WORKSPACE_CAP = (size_t) 1<<30;   // bound of the global combiner scratch; larger launches are chunked
 const int SMALL_MAX_EDGES = 128;                    // glyphs of the LDS-scratch class have at most this many edges (bounds their survivor lists)
+const int COST_LDS_MAX_CONTOURS = 7;                // cost model only: the LDS class's contour bound at the default LDS budget, msdf (ensureBuckets derives the real one per launch)
 
 // SIMDs of a device (4 per compute unit): the number of wavefronts of a W-waves-per-SIMD kernel it holds at once is residentSlots()*W.
 int residentSlots(int device) {
@@ -513,15 +524,23 @@ int ensureEcOrder(const MsdfHipBatch *b, const int **order, hipStream_t stream) 
         b->hContours.size() != (size_t) b->nGlyphs)
         return MSDFHIP_OK;
     const size_t bytes = sizeof(int)*(size_t) b->nGlyphs;
-    HIPCHK(pinnedAlloc((void **) &b->hEcOrder, bytes));         // pinned and kept with the batch: the upload is ordered on the launch stream, nobody waits
+    // The list is an optimisation: every failure below leaves *order = NULL (batch order) and the call succeeds.
+    if (pinnedAlloc((void **) &b->hEcOrder, bytes) != hipSuccess) {   // pinned and kept with the batch: the upload is ordered on the launch stream, nobody waits
+        (void) hipGetLastError();
+        b->hEcOrder = NULL;
+        return MSDFHIP_OK;
+    }
     int *host = b->hEcOrder;
     for (int g = 0; g < b->nGlyphs; ++g)
         host[g] = g;
     const int *hE = b->hEdges.data(), *hC = b->hContours.data();
     std::stable_sort(host, host+b->nGlyphs, [hE, hC](int x, int y) { return (long long) hE[x]*(hC[x] > 1 ? hC[x] : 1) > (long long) hE[y]*(hC[y] > 1 ? hC[y] : 1); });
     int *dOrder = NULL;
-    HIPCHK(hipMalloc((void **) &dOrder, bytes));
-    if (uploadSmall(dOrder, host, bytes, stream) != MSDFHIP_OK) {  // the list is optional: without it the work list keeps batch order
+    if (hipMalloc((void **) &dOrder, bytes) != hipSuccess) {
+        (void) hipGetLastError();
+        return MSDFHIP_OK;
+    }
+    if (uploadSmall(dOrder, host, bytes, stream) != MSDFHIP_OK) {
         hipFree(dOrder);
         return MSDFHIP_OK;
     }
@@ -530,7 +549,11 @@ int ensureEcOrder(const MsdfHipBatch *b, const int **order, hipStream_t stream) 
         if (b->ecOrderReady)
             hipEventDestroy(b->ecOrderReady);
         b->ecOrderReady = NULL;
-        HIPCHK(hipStreamSynchronize(stream));                    // no event for the other streams to wait on: make sure the list has landed
+        if (hipStreamSynchronize(stream) != hipSuccess) {        // no event for the other streams to wait on: the list must have landed before it is published
+            (void) hipGetLastError();
+            hipFree(dOrder);
+            return MSDFHIP_OK;
+        }
     }
     b->dEcOrder = dOrder;                                        // published only once it is (or is ordered to be) complete
     *order = b->dEcOrder;
@@ -615,7 +638,7 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     // global workspace (single 64x64 glyph: 19 -> 8 us simple, ~100 -> ~30 us overlapping combiner).
     const int tilesAll = ((w+TILE-1)/TILE)*((h+TILE-1)/TILE);
     const size_t gresAll = (size_t) b->nGlyphs*tilesAll*(size_t) b->maxContours*SelTraits<SEL>::NCH*WAVE*sizeof(double);
-    const bool smallLaunch = (size_t) b->nGlyphs*tilesAll <= 8192 && (!overlap || gresAll <= ((size_t) 64<<20));
+    const bool smallLaunch = (size_t) b->nGlyphs*tilesAll <= (size_t) tuning().smallLaunchTiles && (!overlap || gresAll <= ((size_t) 64<<20));
     LdsPlan single = plan;                                       // one tile per wavefront: one survivor list, scratch (if any) in global memory
     single.globalRes = true;
     single.bytes = tileListBytes(b->maxEdges, b->maxContours, true);
@@ -1970,9 +1993,9 @@ int msdfhip_host_free(void *p) {
 // times (tools/fit_cost_model.py, profiles/r03_cost_model.json; the same table as msdfgen_amd/shard.py: COST_MODEL).
 static double glyphCost(int contours, int edges) {
     static const double kOne[4] = { 0.27680, 0.01348, 0.00000, 0.00000 }, kLds[4] = { 0.44322, 0.00935, -0.01895, 0.00420 }, kGlobal[4] = { 2.33907, 0.02717, -0.18818, 0.00156 };
-    const double *k = contours <= 1 ? kOne : (contours <= 7 && edges <= SMALL_MAX_EDGES) ? kLds : kGlobal;
+    const double *k = contours <= 1 ? kOne : (contours <= COST_LDS_MAX_CONTOURS && edges <= SMALL_MAX_EDGES) ? kLds : kGlobal;
     const double c = k[0]+k[1]*edges+k[2]*contours+k[3]*(double) edges*contours;
-    return c > 1e-3 ? c : 1e-3;
+    return c > k[0] ? c : k[0];                                  // never below the class's intercept (the fit's negative contour terms are local to the measured range)
 }
 
 static void shardRanges(const int32_t *gco, const int32_t *co, int nGlyphs, int parts, std::vector<int> &bounds) {
@@ -2829,8 +2852,12 @@ int msdfhip_front_door_devices(int *out, int cap) {
 }
 
 int msdfhip_reload_tuning(void) {
-    tuning();                                                     // (make sure the one-time read is behind us)
-    readTuning();
+    // Knobs consumed when a resource is CREATED (MSDFHIP_SIDE_PRIORITY: a batch's side streams; pooled pipeline slots) apply to resources created
+    // after the reload; msdfhip_trim() drops the pooled ones.
+    {
+        std::lock_guard<std::mutex> lock(gTuningMutex);
+        readTuning();
+    }
     gMaxGroup.store(-1);
     {
         std::lock_guard<std::mutex> lock(gFrontMutex);

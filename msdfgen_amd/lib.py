@@ -125,6 +125,9 @@ def load(build_if_missing=True):
             import torch  # noqa: F401
         except ImportError:
             pass
+        # The host-output pipeline wants its three chunk streams on distinct hardware queues ("environment"). The variable is the
+        # HOST's to set -- this binding is the host of the tests and the bench -- and is read when the HIP runtime starts (first HIP call).
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         path = os.environ.get("MSDFGEN_HIP_LIB") or _build.LIB   # override: A/B-ing kernel build variants from bench.py
         if path == _build.LIB and not os.path.exists(path):
             if not build_if_missing:

@@ -23,8 +23,11 @@ COST_MODEL = {
 }
 
 
+LDS_MAX_CONTOURS, LDS_MAX_EDGES = 7, 128       # msdf_capi.hip: COST_LDS_MAX_CONTOURS, SMALL_MAX_EDGES (the one place these live on this side)
+
+
 def glyph_class(contours, edges):
-    return np.where(contours <= 1, 0, np.where((contours <= 7) & (edges <= 128), 1, 2))
+    return np.where(contours <= 1, 0, np.where((contours <= LDS_MAX_CONTOURS) & (edges <= LDS_MAX_EDGES), 1, 2))
 
 
 def glyph_costs(batch: ShapeBatch, width: int, height: int) -> np.ndarray:
@@ -33,7 +36,9 @@ def glyph_costs(batch: ShapeBatch, width: int, height: int) -> np.ndarray:
     contours = (gco[1:]-gco[:-1]).astype(np.float64)
     coef = np.array([COST_MODEL["one_contour"], COST_MODEL["lds"], COST_MODEL["global"]])[glyph_class(contours, edges)]
     per_glyph = coef[:, 0]+coef[:, 1]*edges+coef[:, 2]*contours+coef[:, 3]*edges*contours
-    return float(width*height)/4096.*np.maximum(per_glyph, 1e-3)
+    # never below the class's intercept: the fit's negative contour terms are local to the measured range (a 30-contour, 30-edge glyph of the
+    # global class would otherwise count as free while taking the most expensive kernel)
+    return float(width*height)/4096.*np.maximum(per_glyph, coef[:, 0])
 
 
 def partition_contiguous(costs: Sequence[float], parts: int) -> np.ndarray:

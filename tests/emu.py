@@ -12,11 +12,14 @@ SO = os.path.join(HERE, "libhostemu.so")
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "msdfgen_amd", "csrc")
 
 
-def build():
+def build(lean=False):
+    """lean: -DMSDF_LEAN_MATH, i.e. the device's own < 1 ulp cos / cbrt (msdf_device.hpp) instead of libm's in solveCubicNormed -- the host
+    rendition then follows the KERNELS bit for bit also where the last ulp of a transcendental decides."""
+    so = SO.replace(".so", "_lean.so") if lean else SO
     srcs = [os.path.join(HERE, "hostemu.cpp")]+[os.path.join(CSRC, f) for f in ("msdf_device.hpp", "msdf_prep.hpp", "msdf_ec.hpp", "msdf_ec_fast.hpp", "msdf_cull.hpp", "msdf_scanline.hpp", "msdf_shapeprep.hpp")]
-    if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", SO, srcs[0]], check=True)
-    return SO
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]+(["-DMSDF_LEAN_MATH"] if lean else [])+["-o", so, srcs[0]], check=True)
+    return so
 
 
 def _p(a, t):
@@ -24,8 +27,8 @@ def _p(a, t):
 
 
 class Emu:
-    def __init__(self):
-        self.lib = C.CDLL(build())
+    def __init__(self, lean=False):
+        self.lib = C.CDLL(build(lean))
 
     def _shape(self, s):
         co = np.ascontiguousarray(s.contour_offsets, np.int32)

@@ -19,6 +19,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def db(tag, kind):
@@ -55,7 +56,14 @@ def main():
     dk = {k: v for k, v in rep.items() if like in k}
     total_ms = sum(v["ms_alone"] for v in dk.values())
     busy_w = sum(v["valu_busy_frac_calibrated"]*v["ms_alone"] for v in dk.values())/total_ms
-    out = {"workload": "dejavu8192", "glyphs_per_gpu": 8192, "tile": [64, 64], "commit": commit, "steps_profiled": steps,
+    from msdfgen_amd.build import source_hash
+    # fp64 operations the distance kernels actually EXECUTED per step (PMC class counts x 64 lanes, FMA = 2; masked-off lanes included, so an
+    # upper bound of the useful ones) over the pass's duration with the three launches concurrent: the achieved fp64 rate, not an estimate
+    flops = sum((v["valu_class_counts"].get("ADD_F64", 0)+v["valu_class_counts"].get("MUL_F64", 0)+2*v["valu_class_counts"].get("FMA_F64", 0))*64. for v in dk.values())
+    other = sum(v["valu_other"] for v in dk.values())/max(1., sum(v["valu_insts"] for v in dk.values()))
+    out = {"workload": "dejavu8192", "source_hash": source_hash(), "fp64_gflops_pmc": round(flops/(dist_ns*1e-9)/1e9, 1),
+           "fp64_note": "(SQ_INSTS_VALU_ADD_F64 + MUL_F64 + 2 x FMA_F64) x 64 lanes of the three k_distance launches / duration of the pass (launches concurrent)",
+           "valu_other_over_valu_insts": round(other, 4), "glyphs_per_gpu": 8192, "tile": [64, 64], "commit": commit, "steps_profiled": steps,
            "kernels": "every k_distance<...> launch of a step (1-contour / LDS-scratch / global-scratch classes)",
            "distance_pass_ms": round(dist_ns/1e6, 4), "kernel_ms_per_step_concurrent": per_kernel,
            "FETCH_SIZE_raw_KiB": fetch, "WRITE_SIZE_raw_KiB": write,
