@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "msdf_kernels.hpp"
+#include "msdf_single.hpp"
 
 using namespace msdfhip;
 
@@ -67,6 +68,7 @@ struct Tuning {
     int sidePriority;                // MSDFHIP_SIDE_PRIORITY       queue priority of the side-class streams: low (-1, default) / none (0) / high (+1) / one (-2) / rest (-3)
     bool noClassSort;                // MSDFHIP_NO_CLASS_SORT       glyph classes in batch order instead of heaviest first (A/B)
     int queryBatch;                  // MSDFHIP_QUERY_BATCH         cooperative distance checks a wavefront of k_ec_query takes per ticket (default 1: more only lengthens the tail)
+    bool noFusedSingle;              // MSDFHIP_NO_FUSED_SINGLE     single-shape calls through the batched launch sequence instead of k_single_call (A/B)
     long smallLaunchTiles;           // MSDFHIP_SMALL_LAUNCH_TILES  launches of at most this many tiles take one tile per wavefront (latency-shaped form)
     char devices[256];               // MSDFHIP_DEVICES             "all" | "0,1,..." devices the single-shape front door spreads over
 };
@@ -102,6 +104,7 @@ void readTuning() {
     t.sidePriority = (env = getenv("MSDFHIP_SIDE_PRIORITY")) ? (env[0] == 'l' ? -1 : env[0] == 'h' ? 1 : env[0] == 'o' ? -2 : env[0] == 'r' ? -3 : 0) : -1;
     t.noClassSort = getenv("MSDFHIP_NO_CLASS_SORT") != NULL;
     t.queryBatch = (env = getenv("MSDFHIP_QUERY_BATCH")) && atoi(env) > 0 ? atoi(env) : 1;
+    t.noFusedSingle = getenv("MSDFHIP_NO_FUSED_SINGLE") != NULL;
     t.smallLaunchTiles = (env = getenv("MSDFHIP_SMALL_LAUNCH_TILES")) ? atol(env) : 8192;
     if ((env = getenv("MSDFHIP_DEVICES")))
         snprintf(t.devices, sizeof(t.devices), "%s", env);
@@ -2085,6 +2088,8 @@ struct ThreadArena {
     hipStream_t stream;
     char *dev, *pinned;
     size_t devCap, pinnedCap;
+    unsigned *barrier;               // grid-barrier counter of k_single_call: zeroed once, only ever counted up (barrierEpoch = its value between calls)
+    unsigned barrierEpoch;
 };
 
 static std::mutex gArenaMutex;
@@ -2115,9 +2120,18 @@ struct ArenaLease {
         }
         ThreadArena *fresh = new ThreadArena();
         fresh->device = device, fresh->stream = NULL, fresh->dev = fresh->pinned = NULL, fresh->devCap = fresh->pinnedCap = 0;
+        fresh->barrier = NULL, fresh->barrierEpoch = 0;
         if (hipStreamCreateWithFlags(&fresh->stream, hipStreamNonBlocking) != hipSuccess) {
             delete fresh;
             return fail(MSDFHIP_ERR_HIP, "hipStreamCreate failed");
+        }
+        if (hipMalloc((void **) &fresh->barrier, 256) != hipSuccess || hipMemset(fresh->barrier, 0, 256) != hipSuccess) {
+            (void) hipGetLastError();
+            if (fresh->barrier)
+                hipFree(fresh->barrier);
+            hipStreamDestroy(fresh->stream);
+            delete fresh;
+            return fail(MSDFHIP_ERR_HIP, "hipMalloc failed (single-call barrier)");
         }
         a = fresh;
         return MSDFHIP_OK;
@@ -2383,8 +2397,65 @@ static int runGroup(ShapeCall *const *calls, int n) {
     uint8_t *dStencil = anyStencil ? reinterpret_cast<uint8_t *>(a.dev+hStencil) : NULL;
     b.overflowOut = reinterpret_cast<unsigned *>(a.dev+hStatus);
 
-    rc = digest(&b, a.stream);
-    for (int attempt = 0; rc == MSDFHIP_OK && attempt < 2; ++attempt) {
+    // ---- one launch for the whole call (msdf_single.hpp) where it applies: ONE shape, a generate*() call without the scanline pass, a bitmap of
+    // at most 256 tiles, lists / correction scratch within 64 KB of LDS. A candidate overflow (pathological inputs) reruns the batched sequence below.
+    bool fusedDone = false;
+    if (n == 1 && op == OP_GENERATE && !tuning().noFusedSingle && !cfg->sign_correction && cfg->ec_stage_limit == 0 && tilesAll <= 256) {
+        const bool overlapEff = cfg->overlap_support && maxC > 1;
+        const int slotCapWanted = maxE > 0 ? (maxE < 1024 ? maxE : 1024) : 1;
+        const int slotOffset = overlapEff ? (maxC > 0 ? maxC : 1) : 0;
+        int slotCap = slotCapWanted;
+        size_t queryLds = (size_t) slotOffset*sizeof(double)+((size_t) slotCap+(size_t) (maxC < slotCap ? (maxC > 0 ? maxC : 1) : slotCap))*sizeof(PBSlot);
+        if (queryLds > (size_t) 48*1024) {                       // too many edges for the slots: per-contour lane merges instead (EdgesCooperative)
+            slotCap = 1;
+            queryLds = (size_t) slotOffset*sizeof(double)+2*sizeof(PBSlot);
+        }
+        const size_t listLds = tileListBytes(maxE, maxC, true);
+        size_t lds = listLds;
+        if (correct) {
+            lds = lds > ecFastLdsBytes(maxE, channels) ? lds : ecFastLdsBytes(maxE, channels);
+            lds = lds > queryLds ? lds : queryLds;
+        }
+        const size_t resBytes = overlapEff ? (size_t) maxC*channels*WAVE*sizeof(double) : 0;
+        if (lds <= (size_t) 64*1024 && (!overlapEff || gresNeed >= tilesAll*resBytes)) {
+            SingleArgs sa;
+            sa.glyphContourOffsets = b.dGlyphContourOffsets, sa.contourOffsets = b.dContourOffsets, sa.points = b.dPoints, sa.types = b.dTypes, sa.colors = b.dColors;
+            sa.nContours = (int) sumC, sa.nEdges = (int) sumE, sa.glyph = dGlyph, sa.recs = b.dRecs, sa.windings = b.dWindings;
+            sa.width = w, sa.height = h, sa.tilesX = (w+TILE-1)/TILE, sa.tiles = (int) tilesAll, sa.listStride = maxE;
+            sa.scratch = correct ? reinterpret_cast<float *>(a.dev+dScratch) : NULL, sa.out = dOut, sa.stencil = dStencil;
+            sa.gres = overlapEff ? reinterpret_cast<double *>(a.dev+dGresOff) : NULL, sa.gresStride = resBytes/sizeof(double);
+            sa.cfg = *cfg, sa.correct = correct ? 1 : 0, sa.ecParams = b.dEcParams, sa.cands = b.dDeferred, sa.seg = ecSegment(texels);
+            int *offsets = correct ? reinterpret_cast<int *>(b.dDeferred+candidateRecords(1, texels)) : NULL;
+            sa.corners = correct ? reinterpret_cast<int *>(b.dDeferred+candidateRecords(1, texels)+offsetRecords(1)) : NULL;
+            sa.sizes = NULL, sa.ticket = correct ? offsets+4 : NULL;
+            sa.slotCap = slotCap, sa.slotOffset = slotOffset;
+            const unsigned groups = (unsigned) tilesAll+(correct ? 1u : 0u);
+            sa.barrier = a.barrier, sa.barrierBase = a.barrierEpoch, sa.status = reinterpret_cast<unsigned *>(a.dev+hStatus);
+            a.barrierEpoch += (correct ? 3u : 1u)*groups;          // what this launch adds to the counter
+            switch ((mode <= 2 ? mode : channels)*2+(overlapEff ? 1 : 0)) {
+                case 2: hipLaunchKernelGGL((k_single_call<1, false>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
+                case 3: hipLaunchKernelGGL((k_single_call<1, true>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
+                case 4: hipLaunchKernelGGL((k_single_call<2, false>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
+                case 5: hipLaunchKernelGGL((k_single_call<2, true>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
+                case 6: hipLaunchKernelGGL((k_single_call<3, false>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
+                case 7: hipLaunchKernelGGL((k_single_call<3, true>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
+                case 8: hipLaunchKernelGGL((k_single_call<4, false>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
+                default: hipLaunchKernelGGL((k_single_call<4, true>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(a.pinned+hStatus, a.dev+hStatus, 256+(anyStencil ? resultBytes : n*tileBytes), hipMemcpyDeviceToHost, a.stream));
+            HIPCHK(waitStream(a.stream));
+            if (reinterpret_cast<const unsigned *>(a.pinned+hStatus)[1] != 0) {
+                // workgroups gave up at a barrier: the counter no longer matches the epoch kept here -- start over from a fresh counter
+                HIPCHK(hipMemsetAsync(a.barrier, 0, 256, a.stream));
+                a.barrierEpoch = 0;
+                return fail(MSDFHIP_ERR_HIP, "k_single_call: a grid barrier timed out (workgroups of one launch not co-resident?)");
+            }
+            fusedDone = *reinterpret_cast<const unsigned *>(a.pinned+hStatus) == 0;
+        }
+    }
+    rc = fusedDone ? MSDFHIP_OK : digest(&b, a.stream);
+    for (int attempt = 0; !fusedDone && rc == MSDFHIP_OK && attempt < 2; ++attempt) {
         b.overflowMirrored = false;
         if (op == OP_ERROR_CORRECTION)
             rc = runCorrection(&b, channels, w, h, dGlyph, reinterpret_cast<const float *>(a.dev+hSrc), dOut, dStencil, *cfg, a.stream);
@@ -2829,6 +2900,7 @@ int msdfhip_trim(void) {
         if (a->stream)
             (void) hipStreamSynchronize(a->stream);
         hipFree(a->dev);
+        hipFree(a->barrier);
         if (a->pinned)
             pinnedFree(a->pinned);
         if (a->stream)

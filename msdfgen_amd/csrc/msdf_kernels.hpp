@@ -421,23 +421,23 @@ struct DistanceArgs {
     unsigned workItems;
 };
 
-template <int SEL, bool OVERLAP, bool GRES = false>
-__global__ void __launch_bounds__(WAVE, OVERLAP ? MSDF_DISTANCE_WAVES_PER_SIMD : GRES ? MSDF_SIMPLE_WAVES_PER_SIMD-1 : MSDF_SIMPLE_WAVES_PER_SIMD)   // (simple combiner, one tile per wavefront = latency-bound launches only: 128 VGPRs, no spills)
-k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const int32_t *__restrict__ contourOffsets, const EdgeRec *__restrict__ recs,
+// The body of k_distance as a device function: k_distance is its only caller per instantiation (inlined: the kernel's code is what it was);
+// k_single_call (msdf_single.hpp) runs the same body as one phase of a fused launch. blockId = the workgroup's index in the launch.
+template <int SEL, bool OVERLAP, bool GRES>
+__device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const int32_t *__restrict__ contourOffsets, const EdgeRec *__restrict__ recs,
            const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges,
            float *__restrict__ dst, int toScratch, unsigned blockBase, double *__restrict__ gres, size_t gresStride, const int *__restrict__ glyphMap, int nMapped,
-           unsigned *__restrict__ workQueue, unsigned workItems) {
+           unsigned *__restrict__ workQueue, unsigned workItems, const unsigned blockId, double *smem) {
     // (every pointer __restrict__: the survivor records are read with SCALAR loads only while the compiler can prove that none of the
     // kernel's own stores -- tiles, workspace, and in the persistent form those of the previous item -- may have clobbered them)
     enum { NCH = SelTraits<SEL>::NCH, TPW = GRES ? 1 : (int) QUAD, ROW = WAVE/TPW };   // tiles per wavefront, lanes per tile in phase 1
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     // One wavefront = TPW consecutive tiles of one glyph. Phase 1 culls for all of them at once -- the edges of a contour rarely fill
     // 64 lanes, so each 16-lane row takes one tile -- and phase 2 then walks the tiles one after the other, lanes = texels.
     // workQueue (global-scratch form only): a persistent launch -- one workgroup per resident wavefront slot, each drawing items from
     // the queue and reusing ITS slice of the workspace, which then stays in L2 / Infinity Cache instead of streaming through HBM.
     BatchView batch;
     batch.nGlyphs = nGlyphs, batch.glyphContourOffsets = glyphContourOffsets, batch.contourOffsets = contourOffsets, batch.recs = recs, batch.windings = windings;
-    unsigned item = blockIdx.x+blockBase;
+    unsigned item = blockId+blockBase;
     int steal = 0;
     const bool persistent = GRES && workQueue != NULL;
     for (;;) {
@@ -452,13 +452,15 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
         return;                                                         // (direct mapping only: every queued item is valid)
     if (glyphMap)
         wk.g = glyphMap[wk.g];                                          // this launch covers a subset of the batch (bucketed by contour count)
-    const int c0 = batch.glyphContourOffsets[wk.g], C = batch.glyphContourOffsets[wk.g+1]-c0;
+    // (wave-uniform values; made scalar explicitly: inside k_single_call the offsets are memory the launch itself wrote, which the compiler
+    // reads with vector loads -- the record pointer of the hand-placed s_load batches has to live in SGPRs)
+    const int c0 = MSDF_UNIFORM(batch.glyphContourOffsets[wk.g]), C = MSDF_UNIFORM(batch.glyphContourOffsets[wk.g+1])-c0;
     const int32_t *coff = batch.contourOffsets+c0;
-    const int e0 = coff[0];
+    const int e0 = MSDF_UNIFORM(coff[0]);
     const int lane = threadIdx.x;
     const EdgeRec *rec = batch.recs+e0;
 
-    double *res = GRES ? gres+(size_t) blockIdx.x*gresStride : smem; // [C][NCH][64] (overlap only)
+    double *res = GRES ? gres+(size_t) blockId*gresStride : smem; // [C][NCH][64] (overlap only)
     int *lists = reinterpret_cast<int *>(smem+(OVERLAP && !GRES ? (size_t) C*NCH*WAVE : 0));   // [QUAD][maxEdges] survivor indices
     int *cstarts = lists+(size_t) TPW*maxEdges;                                                 // [TPW][C+1] offsets per contour
 
@@ -674,6 +676,17 @@ k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
     }
 }
 
+template <int SEL, bool OVERLAP, bool GRES = false>
+__global__ void __launch_bounds__(WAVE, OVERLAP ? MSDF_DISTANCE_WAVES_PER_SIMD : GRES ? MSDF_SIMPLE_WAVES_PER_SIMD-1 : MSDF_SIMPLE_WAVES_PER_SIMD)   // (simple combiner, one tile per wavefront = latency-bound launches only: 128 VGPRs, no spills)
+k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const int32_t *__restrict__ contourOffsets, const EdgeRec *__restrict__ recs,
+           const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges,
+           float *__restrict__ dst, int toScratch, unsigned blockBase, double *__restrict__ gres, size_t gresStride, const int *__restrict__ glyphMap, int nMapped,
+           unsigned *__restrict__ workQueue, unsigned workItems) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    distanceBody<SEL, OVERLAP, GRES>(nGlyphs, glyphContourOffsets, contourOffsets, recs, windings, glyphs, width, height, tilesX, tilesPerGlyph, maxEdges, dst, toScratch, blockBase,
+                                     gres, gresStride, glyphMap, nMapped, workQueue, workItems, blockIdx.x, smem);
+}
+
 // --------------------------------------------------------------------------------------------------- error correction
 
 // Wind: Contour::winding per contour -- the int8 array in memory, or (k_ec_query) WindingMasks: the combiner reads it up to four times per
@@ -883,9 +896,8 @@ static_assert(sizeof(EcGlyphParams) == 64, "EcGlyphParams layout");
 // the texel corners protectCorners marks (:121-151; lanes = edges, the (l, b) texel pair of every colour-change corner under this
 // call's transform, appended at corners[2*(e0+slot)]). k_ec_fast then needs ONE dependent load per tile (params -> its corner list)
 // instead of walking glyphContourOffsets -> contourOffsets -> the records' flags in each of the glyph's tiles.
-__global__ void __launch_bounds__(WAVE)
-k_ec_params(EcGlyphParams *out, BatchView batch, const MsdfHipGlyph *glyphs, MsdfHipConfig cfg, unsigned *candidateHeader, int *corners, int *sizes) {
-    const int g = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void ecParamsBody(EcGlyphParams *out, const BatchView &batch, const MsdfHipGlyph *glyphs, const MsdfHipConfig &cfg, unsigned *candidateHeader,
+                                             int *corners, int *sizes, const int g, const int lane) {
     if (candidateHeader && lane == 0) {                             // zero the candidate counters for k_ec_fast (saves a memset launch)
         candidateHeader[1+g] = 0;
         if (g == 0)
@@ -923,6 +935,10 @@ k_ec_params(EcGlyphParams *out, BatchView batch, const MsdfHipGlyph *glyphs, Msd
             sizes[2*g] = nE, sizes[2*g+1] = C;
     }
 }
+__global__ void __launch_bounds__(WAVE)
+k_ec_params(EcGlyphParams *out, BatchView batch, const MsdfHipGlyph *glyphs, MsdfHipConfig cfg, unsigned *candidateHeader, int *corners, int *sizes) {
+    ecParamsBody(out, batch, glyphs, cfg, candidateHeader, corners, sizes, (int) blockIdx.x, (int) threadIdx.x);
+}
 
 // Error correction, fast sweep over ALL texels (msdf_ec_fast.hpp). src: pre-correction field, packed [g][h][w][N] in native row order.
 // Writes corrected texels to the caller's bitmap (msdfErrorCorrectionInner, core/msdf-error-correction.cpp:12-48) and, if stencilOut,
@@ -939,12 +955,10 @@ __host__ __device__ inline size_t ecFastLdsBytes(int maxEdges, int n) {
 }
 
 template <int N>
-__global__ void __launch_bounds__(WAVE, MSDF_EC_FAST_WAVES_PER_SIMD)
-k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph,
-          const float *src, float *out, uint8_t *stencilOut, MsdfHipConfig cfg, const EcGlyphParams *glyphParams, EcCandidate *cands, unsigned seg,
-          int maxEdges, const int *corners) {
-    extern __shared__ int smemFast[];
-    const GlyphWork wk = decodeBlock(batch.nGlyphs, tilesPerGlyph);
+__device__ __forceinline__ void ecFastBody(const BatchView &batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph,
+          const float *src, float *out, uint8_t *stencilOut, const MsdfHipConfig &cfg, const EcGlyphParams *glyphParams, EcCandidate *cands, unsigned seg,
+          int maxEdges, const int *corners, const unsigned blockId, int *smemFast) {
+    const GlyphWork wk = decodeItem(blockId, batch.nGlyphs, tilesPerGlyph);
     if (!wk.valid)
         return;
     float *halo = reinterpret_cast<float *>(smemFast);                                      // [EC_HALO*EC_HALO][N]
@@ -1120,6 +1134,14 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
         px[i] = v[i];
     if (stencilOut)
         stencilOut[stencilIndex(texel, yn, width, height, cfg.stencil_y_down)] = (uint8_t) st;
+}
+template <int N>
+__global__ void __launch_bounds__(WAVE, MSDF_EC_FAST_WAVES_PER_SIMD)
+k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph,
+          const float *src, float *out, uint8_t *stencilOut, MsdfHipConfig cfg, const EcGlyphParams *glyphParams, EcCandidate *cands, unsigned seg,
+          int maxEdges, const int *corners) {
+    extern __shared__ int smemFast[];
+    ecFastBody<N>(batch, glyphs, width, height, tilesX, tilesPerGlyph, src, out, stencilOut, cfg, glyphParams, cands, seg, maxEdges, corners, blockIdx.x, smemFast);
 }
 
 // Two ways to spend a wavefront on deferred distance checks of a glyph with nE edges:
