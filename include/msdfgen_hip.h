@@ -317,6 +317,10 @@ int msdfhip_reload_tuning(void);
  * distance checks of the error correction (-DMSDF_PROFILE_QUERY, tools/profile_query.py; reset = 2 reads its second page); a regular build
  * reports zeros. out24: 24 counters. reset = 1 clears the table after reading. */
 int msdfhip_debug_wait_profile(unsigned long long *out24, int reset);
+/* Fused single-shape launches (k_single_call): out8[0] = calls since the last reset (+ 1e-6 x the shader clock in MHz the launches ran at), out8[1..6] = microseconds per call, as seen by workgroup 0, of:
+ * digest | its own distance tile | waiting for all tiles (grid barrier) | its own correction sweep | waiting for all sweeps | distance checks,
+ * out8[7] = start of workgroup 0 to the last workgroup's end. Diagnostics (tools/host_call_latency.py). */
+int msdfhip_debug_single_call_phases(double *out8, int reset);
 
 #ifdef __cplusplus
 }

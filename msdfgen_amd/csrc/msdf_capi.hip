@@ -68,7 +68,10 @@ struct Tuning {
     int sidePriority;                // MSDFHIP_SIDE_PRIORITY       queue priority of the side-class streams: low (-1, default) / none (0) / high (+1) / one (-2) / rest (-3)
     bool noClassSort;                // MSDFHIP_NO_CLASS_SORT       glyph classes in batch order instead of heaviest first (A/B)
     int queryBatch;                  // MSDFHIP_QUERY_BATCH         cooperative distance checks a wavefront of k_ec_query takes per ticket (default 1: more only lengthens the tail)
+    bool noArgPayloadSingle;         // MSDFHIP_NO_ARG_PAYLOAD_SINGLE k_single_call reads small shapes from the staging area instead of its kernel arguments (A/B)
+    bool noZeroCopySingle;           // MSDFHIP_NO_ZERO_COPY_SINGLE k_single_call on uploaded inputs / device outputs + one copy back (A/B)
     bool noFusedSingle;              // MSDFHIP_NO_FUSED_SINGLE     single-shape calls through the batched launch sequence instead of k_single_call (A/B)
+    long shortRounds;                // MSDFHIP_SHORT_ROUNDS        LDS-class launches of fewer rounds of four-tile wavefronts take one tile per wavefront
     long smallLaunchTiles;           // MSDFHIP_SMALL_LAUNCH_TILES  launches of at most this many tiles take one tile per wavefront (latency-shaped form)
     char devices[256];               // MSDFHIP_DEVICES             "all" | "0,1,..." devices the single-shape front door spreads over
 };
@@ -105,6 +108,9 @@ void readTuning() {
     t.noClassSort = getenv("MSDFHIP_NO_CLASS_SORT") != NULL;
     t.queryBatch = (env = getenv("MSDFHIP_QUERY_BATCH")) && atoi(env) > 0 ? atoi(env) : 1;
     t.noFusedSingle = getenv("MSDFHIP_NO_FUSED_SINGLE") != NULL;
+    t.noZeroCopySingle = getenv("MSDFHIP_NO_ZERO_COPY_SINGLE") != NULL;
+    t.noArgPayloadSingle = getenv("MSDFHIP_NO_ARG_PAYLOAD_SINGLE") != NULL;
+    t.shortRounds = (env = getenv("MSDFHIP_SHORT_ROUNDS")) ? atol(env) : 4;
     t.smallLaunchTiles = (env = getenv("MSDFHIP_SMALL_LAUNCH_TILES")) ? atol(env) : 8192;
     if ((env = getenv("MSDFHIP_DEVICES")))
         snprintf(t.devices, sizeof(t.devices), "%s", env);
@@ -328,14 +334,14 @@ size_t ldsBudget() {
 }
 
 // maxContours / maxEdges: of the glyphs this launch covers (default: of the whole batch).
-int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan, int maxContours = -1, int maxEdges = -1) {
+int planLds(const MsdfHipBatch *b, int nch, bool overlap, LdsPlan &plan, int maxContours = -1, int maxEdges = -1, int tilesPerWave = QUAD) {
     if (maxContours < 0)
         maxContours = b->maxContours;
     if (maxEdges < 0)
         maxEdges = b->maxEdges;
     const size_t resBytes = overlap ? (size_t) maxContours*nch*WAVE*sizeof(double) : 0;
     const size_t idxOne = tileListBytes(maxEdges, maxContours, false);   // survivor list + per-contour offsets of one tile
-    const size_t idxBytes = (size_t) QUAD*idxOne;                // the LDS-scratch variant culls a quad of tiles per wavefront
+    const size_t idxBytes = (size_t) tilesPerWave*idxOne;        // the LDS-scratch variant culls a quad of tiles per wavefront (one in short launches)
     plan.ldsBudget = ldsBudget();
     const size_t limit = (size_t) gLdsLimit.load();
     plan.resBytes = resBytes;
@@ -370,25 +376,25 @@ int ensureGres(const MsdfHipBatch *b, size_t bytes, double **out) {
     return MSDFHIP_OK;
 }
 
-template <int SEL, bool OVERLAP, bool GRES>
+template <int SEL, bool OVERLAP, bool GRES, int TPW_>
 void launchDistanceKernel(unsigned grid, size_t lds, hipStream_t stream, const DistanceArgs &a) {
-    hipLaunchKernelGGL((k_distance<SEL, OVERLAP, GRES>), dim3(grid), dim3(WAVE), lds, stream, a.batch.nGlyphs, a.batch.glyphContourOffsets, a.batch.contourOffsets,
+    hipLaunchKernelGGL((k_distance<SEL, OVERLAP, GRES, TPW_>), dim3(grid), dim3(WAVE), lds, stream, a.batch.nGlyphs, a.batch.glyphContourOffsets, a.batch.contourOffsets,
                        a.batch.recs, a.batch.windings, a.glyphs, a.width, a.height, a.tilesX, a.tilesPerGlyph, a.maxEdges, a.dst, a.toScratch, a.blockBase, a.gres,
                        a.gresStride, a.glyphMap, a.nMapped, a.workQueue, a.workItems);
 }
 
-template <int SEL, bool OVERLAP, bool GRES>
+template <int SEL, bool OVERLAP, bool GRES, int TPW_ = (GRES ? 1 : (int) QUAD)>
 int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, const LdsPlan &plan, hipStream_t stream,
                    const int *dGlyphMap = NULL, int nMapped = 0) {
     const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE, tiles = tilesX*tilesY;
     const int nG = dGlyphMap ? nMapped : b->nGlyphs;
     if (nG == 0)
         return MSDFHIP_OK;
-    const int tpw = GRES ? 1 : (int) QUAD;                        // tiles per wavefront (msdf_kernels.hpp)
+    const int tpw = TPW_;                                        // tiles per wavefront (msdf_kernels.hpp)
     const size_t blocks = (size_t) nG*(size_t) ((tiles+tpw-1)/tpw);               // decodeBlock (msdf_kernels.hpp)
     if (blocks > 0x7fffffffull)
         return fail(MSDFHIP_ERR_INVALID, "launch of %zu tile quads exceeds the grid limit; split the batch", blocks);
-    int rc = setLds(k_distance<SEL, OVERLAP, GRES>, plan.bytes);
+    int rc = setLds(k_distance<SEL, OVERLAP, GRES, TPW_>, plan.bytes);
     if (rc != MSDFHIP_OK)
         return rc;
     double *gres = NULL;
@@ -415,7 +421,7 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
             queue = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(gres)+chunk*plan.resBytes);
             HIPCHK(hipMemsetAsync(queue, 0, 8*sizeof(unsigned), stream));
             args.gres = gres, args.gresStride = stride, args.workQueue = queue, args.workItems = (unsigned) blocks;
-            launchDistanceKernel<SEL, OVERLAP, GRES>((unsigned) chunk, plan.bytes, stream, args);
+            launchDistanceKernel<SEL, OVERLAP, GRES, TPW_>((unsigned) chunk, plan.bytes, stream, args);
             HIPCHK(hipGetLastError());
             return MSDFHIP_OK;
         }
@@ -431,7 +437,7 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
     for (size_t base = 0; base < blocks; base += chunk) {
         const size_t n = blocks-base < chunk ? blocks-base : chunk;
         args.gres = gres, args.gresStride = stride, args.blockBase = (unsigned) base;
-        launchDistanceKernel<SEL, OVERLAP, GRES>((unsigned) n, plan.bytes, stream, args);
+        launchDistanceKernel<SEL, OVERLAP, GRES, TPW_>((unsigned) n, plan.bytes, stream, args);
     }
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
@@ -711,15 +717,25 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
         rc = launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, rest, sRest, b->dBucket+b->nOne+b->nSmall, nRest);
     }
     if (rc == MSDFHIP_OK && b->nSmall > 0) {
+        // A launch of few rounds of wavefronts (a shard of an atlas: BASELINE config 4 over 8 GPUs leaves 1 024 glyphs per device) ends when its
+        // last wavefronts do, and a wavefront of four tiles is four times as long: below shortRounds rounds the class takes one tile per wavefront.
+        const size_t slots = (size_t) residentSlots(b->device)*4u*MSDF_DISTANCE_WAVES_PER_SIMD;
+        const bool shortLaunch = (size_t) b->nSmall*(size_t) ((tilesAll+QUAD-1)/QUAD) < (size_t) tuning().shortRounds*slots;
         LdsPlan small;
-        rc = planLds(b, SelTraits<SEL>::NCH, true, small, b->smallMaxC, b->smallMaxE);
+        rc = planLds(b, SelTraits<SEL>::NCH, true, small, b->smallMaxC, b->smallMaxE, shortLaunch ? 1 : (int) QUAD);
         if (rc == MSDFHIP_OK)
-            rc = launchDistance<SEL, true, false>(b, dGlyphs, w, h, dst, toScratch, small, stream, b->dBucket+b->nOne, b->nSmall);
+            rc = shortLaunch ? launchDistance<SEL, true, false, 1>(b, dGlyphs, w, h, dst, toScratch, small, stream, b->dBucket+b->nOne, b->nSmall)
+                             : launchDistance<SEL, true, false>(b, dGlyphs, w, h, dst, toScratch, small, stream, b->dBucket+b->nOne, b->nSmall);
     }
     if (rc == MSDFHIP_OK && b->nOne > 0) {
+        const size_t slots = (size_t) residentSlots(b->device)*4u*MSDF_SIMPLE_WAVES_PER_SIMD;
+        const bool shortLaunch = (size_t) b->nOne*(size_t) ((tilesAll+QUAD-1)/QUAD) < (size_t) tuning().shortRounds*slots;   // as for the LDS class above
         LdsPlan simple;
-        rc = planLds(b, SelTraits<SEL>::NCH, false, simple, 1, b->oneMaxE);
-        if (rc == MSDFHIP_OK)
+        rc = planLds(b, SelTraits<SEL>::NCH, false, simple, 1, b->oneMaxE, shortLaunch ? 1 : (int) QUAD);
+        if (rc == MSDFHIP_OK && shortLaunch) {
+            simple.bytes = tileListBytes(b->oneMaxE, 1, true);
+            rc = launchDistance<SEL, false, true>(b, dGlyphs, w, h, dst, toScratch, simple, sOne, b->dBucket, b->nOne);
+        } else if (rc == MSDFHIP_OK)
             rc = launchDistance<SEL, false, false>(b, dGlyphs, w, h, dst, toScratch, simple, sOne, b->dBucket, b->nOne);
     }
     hipError_t joinError = hipSuccess;
@@ -2088,8 +2104,9 @@ struct ThreadArena {
     hipStream_t stream;
     char *dev, *pinned;
     size_t devCap, pinnedCap;
-    unsigned *barrier;               // grid-barrier counter of k_single_call: zeroed once, only ever counted up (barrierEpoch = its value between calls)
-    unsigned barrierEpoch;
+    unsigned *barrier;               // counters of k_single_call ([0] grid barrier, [16] finished workgroups): zeroed once, only ever counted up --
+    unsigned barrierEpoch, doneCount, doneEpoch;   // their values between calls, and the completion-flag value of the last call
+    char *pinnedDev;                 // the device's address of `pinned` (hipHostGetDevicePointer): k_single_call reads its inputs / writes its tile there
 };
 
 static std::mutex gArenaMutex;
@@ -2097,10 +2114,11 @@ static std::vector<ThreadArena *> gArenaPool;
 
 struct ArenaLease {
     ThreadArena *a;
-    ArenaLease() : a(NULL) { }
+    bool quiescent;                                              // the call saw its own completion (stream sync or k_single_call's flag): nothing of it is in flight
+    ArenaLease() : a(NULL), quiescent(false) { }
     ~ArenaLease() {
         if (a) {
-            if (a->stream) {                                     // (an error exit may leave copies / kernels of this call in flight)
+            if (a->stream && !quiescent) {                       // (an error exit may leave copies / kernels of this call in flight)
                 (void) hipStreamSynchronize(a->stream);
                 (void) hipGetLastError();
             }
@@ -2120,7 +2138,7 @@ struct ArenaLease {
         }
         ThreadArena *fresh = new ThreadArena();
         fresh->device = device, fresh->stream = NULL, fresh->dev = fresh->pinned = NULL, fresh->devCap = fresh->pinnedCap = 0;
-        fresh->barrier = NULL, fresh->barrierEpoch = 0;
+        fresh->barrier = NULL, fresh->barrierEpoch = fresh->doneCount = fresh->doneEpoch = 0, fresh->pinnedDev = NULL;
         if (hipStreamCreateWithFlags(&fresh->stream, hipStreamNonBlocking) != hipSuccess) {
             delete fresh;
             return fail(MSDFHIP_ERR_HIP, "hipStreamCreate failed");
@@ -2154,6 +2172,11 @@ static int arenaReserve(ThreadArena &a, size_t devBytes, size_t pinnedBytes) {
         const size_t cap = pinnedBytes+pinnedBytes/2+4096;
         HIPCHK(pinnedAlloc((void **) &a.pinned, cap));
         a.pinnedCap = cap;
+        a.pinnedDev = NULL;
+        if (hipHostGetDevicePointer((void **) &a.pinnedDev, a.pinned, 0) != hipSuccess) {   // not mapped: k_single_call then works on device copies
+            (void) hipGetLastError();
+            a.pinnedDev = NULL;
+        }
     }
     return MSDFHIP_OK;
 }
@@ -2219,6 +2242,7 @@ static bool sameLaunch(const ShapeCall &a, const ShapeCall &b) {
 }
 
 static std::atomic<long long> gNsStage(0), gNsDevice(0), gNsScatter(0);
+static std::atomic<unsigned long long> gSinglePhase[8], gSingleCalls(0), gSingleCycles(0);   // sums of k_single_call's phase stamps (msdfhip_debug_single_call_phases)
 static long long nowNs() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Runs n compatible calls as ONE device batch on the calling thread's arena: stage all inputs -> one H2D copy -> digest + kernels ->
@@ -2322,6 +2346,11 @@ static int runGroup(ShapeCall *const *calls, int n) {
     if (gresNeed > ((size_t) 64<<20))
         gresNeed = 0;
     const size_t dGresOff = dc.take(gresNeed);
+    // k_single_call: one private digest area per workgroup (msdf_single.hpp) -- only reserved for calls that can take that path
+    const size_t pvWind = (eAlloc*sizeof(EdgeRec)+63)/64*64, pvOff = (pvWind+cAlloc+63)/64*64, pvGco = (pvOff+(cAlloc+1)*sizeof(int32_t)+63)/64*64;
+    const size_t pvGlyph = pvGco+64, pvStride = (pvGlyph+sizeof(MsdfHipGlyph)+255)/256*256;
+    const bool fusedShape = n == 1 && op == OP_GENERATE && tilesAll <= 256 && (tilesAll+1)*pvStride <= ((size_t) 32<<20);
+    const size_t dPriv = dc.take(fusedShape ? (tilesAll+1)*pvStride : 0);
     ArenaLease lease;
     rc = lease.take(currentDevice());
     if (rc != MSDFHIP_OK)
@@ -2358,7 +2387,33 @@ static int runGroup(ShapeCall *const *calls, int n) {
     }
     gco[n] = (int32_t) cAt;
     const long long t1 = nowNs();
-    if (inputBytes <= ((size_t) 1<<20)) {                        // a few KB: read from the pinned staging by a kernel -- no SDMA submission on the latency path
+    // Does the call take ONE launch (k_single_call, msdf_single.hpp)? ONE shape, a generate*() call without the scanline pass, a bitmap of at most
+    // 256 tiles, lists / correction scratch within 64 KB of LDS. Decided before the upload: with the staging area mapped into the device the
+    // kernel reads its inputs from there and nothing is uploaded at all.
+    const bool overlapEff = cfg->overlap_support && maxC > 1;
+    const int slotCapWanted = maxE > 0 ? (maxE < 1024 ? maxE : 1024) : 1;
+    const int slotOffset = overlapEff ? (maxC > 0 ? maxC : 1) : 0;
+    int slotCap = slotCapWanted;
+    size_t queryLds = (size_t) slotOffset*sizeof(double)+((size_t) slotCap+(size_t) (maxC < slotCap ? (maxC > 0 ? maxC : 1) : slotCap))*sizeof(PBSlot);
+    if (queryLds > (size_t) 48*1024) {                       // too many edges for the slots: per-contour lane merges instead (EdgesCooperative)
+        slotCap = 1;
+        queryLds = (size_t) slotOffset*sizeof(double)+2*sizeof(PBSlot);
+    }
+    const size_t resBytes = overlapEff ? (size_t) maxC*channels*WAVE*sizeof(double) : 0;
+    const size_t resLdsForm = resBytes+tileListBytes(maxE, maxC, false);      // combiner scratch in LDS (k_distance's LDS form with one tile per wavefront)
+    const bool resInLds = overlapEff && resLdsForm <= (size_t) 60*1024;
+    const size_t listLds = resInLds ? resLdsForm : tileListBytes(maxE, maxC, true);
+    size_t lds = listLds;
+    if (correct) {
+        lds = lds > ecFastLdsBytes(maxE, channels) ? lds : ecFastLdsBytes(maxE, channels);
+        lds = lds > queryLds ? lds : queryLds;
+    }
+    const bool fusedOK = fusedShape && !tuning().noFusedSingle && !cfg->sign_correction && cfg->ec_stage_limit == 0 &&
+                         lds <= (size_t) 64*1024 && (!overlapEff || resInLds || gresNeed >= tilesAll*resBytes);
+    const bool zeroCopy = fusedOK && a.pinnedDev != NULL && !anyStencil && !tuning().noZeroCopySingle;
+    if (zeroCopy) {
+        // (nothing to upload)
+    } else if (inputBytes <= ((size_t) 1<<20)) {                 // a few KB: read from the pinned staging by a kernel -- no SDMA submission on the latency path
         rc = uploadSmall(a.dev, a.pinned, inputBytes, a.stream);
         if (rc != MSDFHIP_OK)
             return rc;
@@ -2400,39 +2455,54 @@ static int runGroup(ShapeCall *const *calls, int n) {
     // ---- one launch for the whole call (msdf_single.hpp) where it applies: ONE shape, a generate*() call without the scanline pass, a bitmap of
     // at most 256 tiles, lists / correction scratch within 64 KB of LDS. A candidate overflow (pathological inputs) reruns the batched sequence below.
     bool fusedDone = false;
-    if (n == 1 && op == OP_GENERATE && !tuning().noFusedSingle && !cfg->sign_correction && cfg->ec_stage_limit == 0 && tilesAll <= 256) {
-        const bool overlapEff = cfg->overlap_support && maxC > 1;
-        const int slotCapWanted = maxE > 0 ? (maxE < 1024 ? maxE : 1024) : 1;
-        const int slotOffset = overlapEff ? (maxC > 0 ? maxC : 1) : 0;
-        int slotCap = slotCapWanted;
-        size_t queryLds = (size_t) slotOffset*sizeof(double)+((size_t) slotCap+(size_t) (maxC < slotCap ? (maxC > 0 ? maxC : 1) : slotCap))*sizeof(PBSlot);
-        if (queryLds > (size_t) 48*1024) {                       // too many edges for the slots: per-contour lane merges instead (EdgesCooperative)
-            slotCap = 1;
-            queryLds = (size_t) slotOffset*sizeof(double)+2*sizeof(PBSlot);
-        }
-        const size_t listLds = tileListBytes(maxE, maxC, true);
-        size_t lds = listLds;
-        if (correct) {
-            lds = lds > ecFastLdsBytes(maxE, channels) ? lds : ecFastLdsBytes(maxE, channels);
-            lds = lds > queryLds ? lds : queryLds;
-        }
-        const size_t resBytes = overlapEff ? (size_t) maxC*channels*WAVE*sizeof(double) : 0;
-        if (lds <= (size_t) 64*1024 && (!overlapEff || gresNeed >= tilesAll*resBytes)) {
+    if (fusedOK) {
+        {
+            // Zero copy where the staging area is mapped into the device: the kernel reads the staged CSR arrays straight from pinned host memory
+            // (phase 0) and writes the result tile and its status words there -- no upload launch in front, no copy behind, and the host learns of
+            // the end by polling a word the last workgroup writes instead of a stream synchronisation. With a stencil (rare) the results take
+            // the device buffers and one copy, as the batched path does.
+            char *in = zeroCopy ? a.pinnedDev : a.dev;           // (a.dev already holds the inputs: uploaded above)
             SingleArgs sa;
-            sa.glyphContourOffsets = b.dGlyphContourOffsets, sa.contourOffsets = b.dContourOffsets, sa.points = b.dPoints, sa.types = b.dTypes, sa.colors = b.dColors;
-            sa.nContours = (int) sumC, sa.nEdges = (int) sumE, sa.glyph = dGlyph, sa.recs = b.dRecs, sa.windings = b.dWindings;
+            sa.srcContourOffsets = reinterpret_cast<const int32_t *>(in+hCo), sa.points = reinterpret_cast<const double *>(in+hPts);
+            sa.types = reinterpret_cast<const uint8_t *>(in+hTypes), sa.colors = reinterpret_cast<const uint8_t *>(in+hColors);
+            sa.srcGlyph = reinterpret_cast<const MsdfHipGlyph *>(in+hGlyph);
+            sa.priv = a.dev+dPriv, sa.privStride = pvStride, sa.privWindings = pvWind, sa.privOffsets = pvOff, sa.privGlyphOffsets = pvGco, sa.privGlyph = pvGlyph;
+            sa.nContours = (int) sumC, sa.nEdges = (int) sumE;
+            {   // small shapes inside the kernel arguments (msdf_single.hpp)
+                Carver pc;
+                const size_t pCo = pc.take((sumC+1)*sizeof(int32_t)), pPts = pc.take(sumE*8*sizeof(double)), pTypes = pc.take(sumE), pColors = pc.take(sumE);
+                const size_t pGlyph = pc.take(sizeof(MsdfHipGlyph));
+                sa.payloadBytes = 0;
+                if (pc.off <= sizeof(sa.payload) && !tuning().noArgPayloadSingle) {
+                    sa.payloadBytes = (unsigned) pc.off, sa.payOffsets = (unsigned) pCo, sa.payPoints = (unsigned) pPts, sa.payTypes = (unsigned) pTypes;
+                    sa.payColors = (unsigned) pColors, sa.payGlyph = (unsigned) pGlyph;
+                    memcpy(sa.payload+pCo, a.pinned+hCo, (sumC+1)*sizeof(int32_t));
+                    memcpy(sa.payload+pPts, a.pinned+hPts, sumE*8*sizeof(double));
+                    memcpy(sa.payload+pTypes, a.pinned+hTypes, sumE);
+                    memcpy(sa.payload+pColors, a.pinned+hColors, sumE);
+                    memcpy(sa.payload+pGlyph, a.pinned+hGlyph, sizeof(MsdfHipGlyph));
+                }
+            }
             sa.width = w, sa.height = h, sa.tilesX = (w+TILE-1)/TILE, sa.tiles = (int) tilesAll, sa.listStride = maxE;
-            sa.scratch = correct ? reinterpret_cast<float *>(a.dev+dScratch) : NULL, sa.out = dOut, sa.stencil = dStencil;
-            sa.gres = overlapEff ? reinterpret_cast<double *>(a.dev+dGresOff) : NULL, sa.gresStride = resBytes/sizeof(double);
+            sa.scratch = correct ? reinterpret_cast<float *>(a.dev+dScratch) : NULL;
+            sa.out = zeroCopy ? reinterpret_cast<float *>(a.pinnedDev+hOut) : dOut, sa.stencil = dStencil;
+            sa.gres = overlapEff && !resInLds ? reinterpret_cast<double *>(a.dev+dGresOff) : NULL, sa.gresStride = resBytes/sizeof(double);
             sa.cfg = *cfg, sa.correct = correct ? 1 : 0, sa.ecParams = b.dEcParams, sa.cands = b.dDeferred, sa.seg = ecSegment(texels);
             int *offsets = correct ? reinterpret_cast<int *>(b.dDeferred+candidateRecords(1, texels)) : NULL;
             sa.corners = correct ? reinterpret_cast<int *>(b.dDeferred+candidateRecords(1, texels)+offsetRecords(1)) : NULL;
             sa.sizes = NULL, sa.ticket = correct ? offsets+4 : NULL;
             sa.slotCap = slotCap, sa.slotOffset = slotOffset;
             const unsigned groups = (unsigned) tilesAll+(correct ? 1u : 0u);
-            sa.barrier = a.barrier, sa.barrierBase = a.barrierEpoch, sa.status = reinterpret_cast<unsigned *>(a.dev+hStatus);
-            a.barrierEpoch += (correct ? 3u : 1u)*groups;          // what this launch adds to the counter
-            switch ((mode <= 2 ? mode : channels)*2+(overlapEff ? 1 : 0)) {
+            sa.barrier = a.barrier, sa.barrierBase = a.barrierEpoch, sa.doneBase = a.doneCount;
+            a.barrierEpoch += (correct ? 2u : 0u)*groups, a.doneCount += groups;   // what this launch adds to the two counters
+            if (++a.doneEpoch == 0)
+                a.doneEpoch = 1;
+            sa.doneValue = a.doneEpoch;
+            volatile unsigned *hostStatus = reinterpret_cast<volatile unsigned *>(a.pinned+hStatus);
+            sa.status = reinterpret_cast<unsigned *>(zeroCopy ? a.pinnedDev+hStatus : a.dev+hStatus);
+            if (zeroCopy)
+                hostStatus[2] = 0;                               // (the staging area is recycled: whatever sits there is not this call's flag)
+            switch (mode*2+(overlapEff ? 1 : 0)) {
                 case 2: hipLaunchKernelGGL((k_single_call<1, false>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
                 case 3: hipLaunchKernelGGL((k_single_call<1, true>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
                 case 4: hipLaunchKernelGGL((k_single_call<2, false>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
@@ -2443,15 +2513,38 @@ static int runGroup(ShapeCall *const *calls, int n) {
                 default: hipLaunchKernelGGL((k_single_call<4, true>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
             }
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(a.pinned+hStatus, a.dev+hStatus, 256+(anyStencil ? resultBytes : n*tileBytes), hipMemcpyDeviceToHost, a.stream));
-            HIPCHK(waitStream(a.stream));
-            if (reinterpret_cast<const unsigned *>(a.pinned+hStatus)[1] != 0) {
-                // workgroups gave up at a barrier: the counter no longer matches the epoch kept here -- start over from a fresh counter
-                HIPCHK(hipMemsetAsync(a.barrier, 0, 256, a.stream));
-                a.barrierEpoch = 0;
+            if (zeroCopy) {
+                const long long deadline = nowNs()+2000000;      // 2 ms of polling, then the runtime's own wait (a failed launch never raises the flag)
+                while (hostStatus[2] != sa.doneValue && nowNs() < deadline) { }
+                if (hostStatus[2] != sa.doneValue) {
+                    HIPCHK(hipStreamSynchronize(a.stream));
+                    if (hostStatus[2] != sa.doneValue)
+                        return fail(MSDFHIP_ERR_HIP, "k_single_call ended without raising its completion flag");
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+                lease.quiescent = true;
+            } else {
+                HIPCHK(hipMemcpyAsync(a.pinned+hStatus, a.dev+hStatus, 256+(anyStencil ? resultBytes : n*tileBytes), hipMemcpyDeviceToHost, a.stream));
+                HIPCHK(waitStream(a.stream));
+            }
+            if (hostStatus[1] != 0) {
+                // workgroups gave up at a barrier: the counters no longer match the epochs kept here -- start over from fresh ones
+                lease.quiescent = false;
+                HIPCHK(hipStreamSynchronize(a.stream));
+                HIPCHK(hipMemset(a.barrier, 0, 256));
+                a.barrierEpoch = a.doneCount = 0;
                 return fail(MSDFHIP_ERR_HIP, "k_single_call: a grid barrier timed out (workgroups of one launch not co-resident?)");
             }
-            fusedDone = *reinterpret_cast<const unsigned *>(a.pinned+hStatus) == 0;
+            fusedDone = hostStatus[0] == 0;
+            if (fusedDone && correct && zeroCopy) {              // (all phases ran and the stamps are at hand: the diagnostics count these calls)
+                for (int k = 0; k < 7; ++k)
+                    gSinglePhase[k] += (unsigned long long) hostStatus[8+k];
+                gSinglePhase[7] += (unsigned long long) hostStatus[7];
+                gSingleCycles += (unsigned long long) hostStatus[15];
+                ++gSingleCalls;
+            }
+            if (!fusedDone && zeroCopy)                          // rerun through the batched sequence: it expects the inputs on the device
+                HIPCHK(hipMemcpyAsync(a.dev, a.pinned, inputBytes, hipMemcpyHostToDevice, a.stream));
         }
     }
     rc = fusedDone ? MSDFHIP_OK : digest(&b, a.stream);
@@ -2934,6 +3027,34 @@ int msdfhip_reload_tuning(void) {
     {
         std::lock_guard<std::mutex> lock(gFrontMutex);
         gFrontParsed = false;
+    }
+    return MSDFHIP_OK;
+}
+
+// Where the time of the fused single-shape launches went (k_single_call stamps workgroup 0's phase boundaries with the 100 MHz realtime counter):
+// out[0] calls, out[1..6] microseconds per call of workgroup 0's digest | distance tile | wait for all tiles | correction sweep | wait for all sweeps |
+// distance checks, out[7] start of workgroup 0 -> last workgroup finished.
+int msdfhip_debug_single_call_phases(double *out8, int reset) {
+    if (!out8)
+        return fail(MSDFHIP_ERR_INVALID, "NULL argument");
+    const unsigned long long calls = gSingleCalls.load();
+    unsigned long long v[8];
+    for (int k = 0; k < 8; ++k)
+        v[k] = gSinglePhase[k].load();
+    // stamps are 32-bit counter values summed over the calls: differences of the sums are sums of the differences (mod 2^32 per call is harmless for
+    // sub-second intervals as long as few calls straddle a wrap: 43 s apart)
+    out8[0] = (double) calls;
+    const double per = calls ? 0.01/(double) calls : 0.;         // 10 ns units -> us per call
+    out8[1] = (double) (long long) (v[1]-v[0])*per, out8[2] = (double) (long long) (v[2]-v[1])*per, out8[3] = (double) (long long) (v[3]-v[2])*per;
+    out8[4] = (double) (long long) (v[4]-v[3])*per, out8[5] = (double) (long long) (v[5]-v[4])*per, out8[6] = (double) (long long) (v[6]-v[5])*per;
+    out8[7] = (double) (long long) (v[7]-v[0])*per;
+    if ((long long) (v[6]-v[0]) > 0)                             // shader clock in MHz during the launches, encoded into the fraction of out8[0] would be obscure:
+        out8[0] = (double) calls+1e-6*((double) gSingleCycles.load()/((double) (long long) (v[6]-v[0])*0.01));   // calls + MHz * 1e-6
+    if (reset) {
+        gSingleCycles.store(0);
+        gSingleCalls.store(0);
+        for (int k = 0; k < 8; ++k)
+            gSinglePhase[k].store(0);
     }
     return MSDFHIP_OK;
 }

@@ -423,14 +423,15 @@ struct DistanceArgs {
 
 // The body of k_distance as a device function: k_distance is its only caller per instantiation (inlined: the kernel's code is what it was);
 // k_single_call (msdf_single.hpp) runs the same body as one phase of a fused launch. blockId = the workgroup's index in the launch.
-template <int SEL, bool OVERLAP, bool GRES>
+template <int SEL, bool OVERLAP, bool GRES, int TPW_ = (GRES ? 1 : (int) QUAD)>
 __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const int32_t *__restrict__ contourOffsets, const EdgeRec *__restrict__ recs,
            const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges,
            float *__restrict__ dst, int toScratch, unsigned blockBase, double *__restrict__ gres, size_t gresStride, const int *__restrict__ glyphMap, int nMapped,
-           unsigned *__restrict__ workQueue, unsigned workItems, const unsigned blockId, double *smem) {
+           unsigned *__restrict__ workQueue, unsigned workItems, const unsigned blockId, double *smem, const int knownContours = -1, const int knownEdges = -1) {
+    // (knownContours / knownEdges >= 0: a launch over ONE glyph whose counts are kernel arguments -- k_single_call -- skips the dependent loads of the offsets)
     // (every pointer __restrict__: the survivor records are read with SCALAR loads only while the compiler can prove that none of the
     // kernel's own stores -- tiles, workspace, and in the persistent form those of the previous item -- may have clobbered them)
-    enum { NCH = SelTraits<SEL>::NCH, TPW = GRES ? 1 : (int) QUAD, ROW = WAVE/TPW };   // tiles per wavefront, lanes per tile in phase 1
+    enum { NCH = SelTraits<SEL>::NCH, TPW = TPW_, ROW = WAVE/TPW };   // tiles per wavefront (4; 1 in the global-scratch form and in the latency-shaped launches), lanes per tile in phase 1
     // One wavefront = TPW consecutive tiles of one glyph. Phase 1 culls for all of them at once -- the edges of a contour rarely fill
     // 64 lanes, so each 16-lane row takes one tile -- and phase 2 then walks the tiles one after the other, lanes = texels.
     // workQueue (global-scratch form only): a persistent launch -- one workgroup per resident wavefront slot, each drawing items from
@@ -454,9 +455,9 @@ __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restr
         wk.g = glyphMap[wk.g];                                          // this launch covers a subset of the batch (bucketed by contour count)
     // (wave-uniform values; made scalar explicitly: inside k_single_call the offsets are memory the launch itself wrote, which the compiler
     // reads with vector loads -- the record pointer of the hand-placed s_load batches has to live in SGPRs)
-    const int c0 = MSDF_UNIFORM(batch.glyphContourOffsets[wk.g]), C = MSDF_UNIFORM(batch.glyphContourOffsets[wk.g+1])-c0;
+    const int c0 = knownContours >= 0 ? 0 : MSDF_UNIFORM(batch.glyphContourOffsets[wk.g]), C = knownContours >= 0 ? knownContours : MSDF_UNIFORM(batch.glyphContourOffsets[wk.g+1])-c0;
     const int32_t *coff = batch.contourOffsets+c0;
-    const int e0 = MSDF_UNIFORM(coff[0]);
+    const int e0 = knownContours >= 0 ? 0 : MSDF_UNIFORM(coff[0]);
     const int lane = threadIdx.x;
     const EdgeRec *rec = batch.recs+e0;
 
@@ -497,11 +498,11 @@ __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restr
         for (int c = col; c < C; c += ROW)
             cstart[c] = 0;
 #else
-        const int nE = coff[C]-e0;
+        const int nE = knownEdges >= 0 ? knownEdges : coff[C]-e0;
 #if defined(MSDF_PROFILE_WAITS)
         unsigned long long pHdr;
         {
-            int sink = nE+(int) gd.flip;                            // the header loads have landed when these are usable
+            int sink = MSDF_UNIFORM(nE+(int) gd.flip);              // the header loads have landed when these are usable
             asm volatile("" : "+s"(sink));
             pHdr = __builtin_readcyclecounter()+(unsigned long long) (sink&0);
         }
@@ -607,6 +608,29 @@ __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restr
     MSDF_STAMP(pPhase2);
 #endif
 
+    // A latency-shaped launch (k_single_call: this wavefront is alone on its SIMD, nothing hides a miss) first pulls the record lines of ALL the
+    // tile's survivors into the scalar cache, four records per wait -- the walk below then pays a cache hit per batch instead of an L2 round
+    // trip per evaluated edge, one after the other. (In the batched launches three wavefronts per SIMD hide those: measured, no gain there.)
+    if (TPW == 1 && knownContours >= 0) {
+        const int total = MSDF_UNIFORM(cstarts[C]);
+        for (int base = 0; base < total; base += WAVE) {
+            const int entry = base+lane < total ? lists[base+lane] : 0;
+            const int n = total-base < WAVE ? total-base : WAVE;
+            for (int k = 0; k < n; k += 4) {
+                const EdgeRec *r0 = rec+(__builtin_amdgcn_readlane(entry, k)&ENTRY_INDEX_MASK);
+                const EdgeRec *r1 = rec+(__builtin_amdgcn_readlane(entry, k+1 < n ? k+1 : k)&ENTRY_INDEX_MASK);
+                const EdgeRec *r2 = rec+(__builtin_amdgcn_readlane(entry, k+2 < n ? k+2 : k)&ENTRY_INDEX_MASK);
+                const EdgeRec *r3 = rec+(__builtin_amdgcn_readlane(entry, k+3 < n ? k+3 : k)&ENTRY_INDEX_MASK);
+                int sink;
+                asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\ts_load_dword %0, %1, 0xc0\n\ts_load_dword %0, %1, 0x100\n\t"
+                             "s_load_dword %0, %2, 0x0\n\ts_load_dword %0, %2, 0x40\n\ts_load_dword %0, %2, 0x80\n\ts_load_dword %0, %2, 0xc0\n\ts_load_dword %0, %2, 0x100\n\t"
+                             "s_load_dword %0, %3, 0x0\n\ts_load_dword %0, %3, 0x40\n\ts_load_dword %0, %3, 0x80\n\ts_load_dword %0, %3, 0xc0\n\ts_load_dword %0, %3, 0x100\n\t"
+                             "s_load_dword %0, %4, 0x0\n\ts_load_dword %0, %4, 0x40\n\ts_load_dword %0, %4, 0x80\n\ts_load_dword %0, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\t"
+                             "s_waitcnt lgkmcnt(0)" : "=&s"(sink) : "s"(r0), "s"(r1), "s"(r2), "s"(r3));
+            }
+        }
+    }
+
     // ---- phase 2: per-texel selection over the survivors (lanes = texels), tile after tile
     MSDF_NOUNROLL
     for (int q = 0; q < TPW; ++q) {
@@ -676,14 +700,14 @@ __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restr
     }
 }
 
-template <int SEL, bool OVERLAP, bool GRES = false>
+template <int SEL, bool OVERLAP, bool GRES = false, int TPW_ = (GRES ? 1 : (int) QUAD)>
 __global__ void __launch_bounds__(WAVE, OVERLAP ? MSDF_DISTANCE_WAVES_PER_SIMD : GRES ? MSDF_SIMPLE_WAVES_PER_SIMD-1 : MSDF_SIMPLE_WAVES_PER_SIMD)   // (simple combiner, one tile per wavefront = latency-bound launches only: 128 VGPRs, no spills)
 k_distance(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const int32_t *__restrict__ contourOffsets, const EdgeRec *__restrict__ recs,
            const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges,
            float *__restrict__ dst, int toScratch, unsigned blockBase, double *__restrict__ gres, size_t gresStride, const int *__restrict__ glyphMap, int nMapped,
            unsigned *__restrict__ workQueue, unsigned workItems) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    distanceBody<SEL, OVERLAP, GRES>(nGlyphs, glyphContourOffsets, contourOffsets, recs, windings, glyphs, width, height, tilesX, tilesPerGlyph, maxEdges, dst, toScratch, blockBase,
+    distanceBody<SEL, OVERLAP, GRES, TPW_>(nGlyphs, glyphContourOffsets, contourOffsets, recs, windings, glyphs, width, height, tilesX, tilesPerGlyph, maxEdges, dst, toScratch, blockBase,
                                      gres, gresStride, glyphMap, nMapped, workQueue, workItems, blockIdx.x, smem);
 }
 

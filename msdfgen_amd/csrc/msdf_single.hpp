@@ -25,19 +25,22 @@
 namespace msdfhip {
 
 struct SingleArgs {
-    // the shape: CSR arrays of ONE glyph (glyphContourOffsets = { 0, nContours })
-    const int32_t *glyphContourOffsets, *contourOffsets;
+    // the shape as the CALLER staged it: CSR arrays of ONE glyph, read once in phase 0 -- device memory or pinned host memory (zero copy:
+    // a few KB over PCIe, two dependent round trips, instead of an upload launch in front of this one)
+    const int32_t *srcContourOffsets;
     const double *points;
     const uint8_t *types, *colors;
+    const MsdfHipGlyph *srcGlyph;
     int nContours, nEdges;
-    const MsdfHipGlyph *glyph;
-    // derived on the device
-    EdgeRec *recs;
-    int8_t *windings;
+    // Every workgroup digests the WHOLE shape into an area of its own (priv + blockIdx * privStride: records | windings | contour offsets |
+    // { 0, nContours } | glyph descriptor): 25 edges are one round of lanes, and what a workgroup reads in the later phases it wrote itself --
+    // no grid barrier between digest and distance field, and the records are warm in its XCD's L2 when the survivor walk asks for them
+    char *priv;
+    size_t privStride, privWindings, privOffsets, privGlyphOffsets, privGlyph;   // byte offsets inside an area (records at 0)
     // the bitmap
     int width, height, tilesX, tiles, listStride;
     float *scratch;                    // pre-correction field [h][w][N] (only when the correction pass runs)
-    float *out;                        // the caller's tile (packed rows)
+    float *out;                        // the result tile, packed rows: device memory, or pinned host memory (written once per texel, posted writes)
     uint8_t *stencil;
     double *gres;                      // combiner scratch, one slice per tile
     size_t gresStride;
@@ -50,10 +53,19 @@ struct SingleArgs {
     int *corners, *sizes, *ticket;
     int slotCap, slotOffset;
     // launch bookkeeping
-    unsigned *barrier;
-    unsigned barrierBase;
-    unsigned *status;                  // [0] = candidate overflow (the host then reruns the call through the batched path)
+    unsigned *barrier;                 // [0] grid-barrier counter, [16] finished-workgroup counter: device memory, only ever counted up
+    unsigned barrierBase, doneBase;
+    unsigned *status;                  // [0] candidate overflow (the host reruns the call through the batched path) [1] a barrier gave up
+                                       // [2] completion flag (= doneValue, written last, system scope) [8..14] phase stamps of workgroup 0 (10 ns units) [15] its shader-clock cycles from the first to the last stamp
+    unsigned doneValue;
+    // Small shapes travel INSIDE the kernel arguments (the runtime keeps the argument buffer in device memory: the host writes it through the
+    // PCIe aperture, posted, and the digest reads it locally -- reading the staged arrays from pinned host memory instead costs two dependent
+    // PCIe round trips, ~8 of the ~11 us the digest took): payloadBytes != 0 -> contour offsets | points | types | colors | descriptor at
+    // the given offsets of `payload`, and the src* pointers above are not used.
+    unsigned payloadBytes, payOffsets, payPoints, payTypes, payColors, payGlyph;
+    alignas(16) unsigned char payload[3456];
 };
+static_assert(sizeof(SingleArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
 // (The spin is bounded -- ~0.3 s -- so that a launch whose workgroups could not all become resident ends with status[1] set instead of hanging
 // the queue; the host then fails the call loudly. It has never been seen to happen: <= 257 wavefronts on a device with 3 072+ slots.)
@@ -76,6 +88,66 @@ __device__ inline void gridBarrier(unsigned *counter, unsigned target, unsigned 
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // the hand-placed s_load batches of the survivor walk (see above)
 }
 
+__device__ __forceinline__ void stampPhase(const SingleArgs &a, int k) {
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        a.status[8+k] = (unsigned) __builtin_amdgcn_s_memrealtime();
+}
+
+// The distance checks of phase 3 (k_ec_query's cooperative form for ONE glyph): a ticket = one candidate, lanes = edges.
+template <int N, bool OVERLAP>
+__device__ __forceinline__ void singleCallChecks(const SingleArgs &a, const EdgeRec *recs, const int8_t *windings, const int32_t *contourOffsets, const MsdfHipGlyph *glyph,
+                                        double *smemSingle, unsigned count, int lane) {
+    const EcCandidate *segment = a.cands+ecHeaderRecords(1);
+    const MsdfHipGlyph gd = glyph[0];
+    EcParams p;
+    p.t = loadXform(gd);
+    p.minDeviationRatio = a.cfg.min_deviation_ratio;
+    p.minImproveRatio = a.cfg.min_improve_ratio;
+    p.mode = a.cfg.ec_mode, p.distanceCheck = a.cfg.ec_distance_check, p.overlap = OVERLAP, p.stageLimit = 0;
+    const EcGlyphParams gp = a.ecParams[0];
+    p.hSpan = gp.hSpan, p.vSpan = gp.vSpan, p.dSpan = gp.dSpan, p.texelX = gp.texelX, p.texelY = gp.texelY;
+    p.radiusH = gp.radiusH, p.radiusV = gp.radiusV, p.radiusD = gp.radiusD;
+    SdfView sdf;
+    sdf.px = a.scratch;
+    sdf.w = a.width, sdf.h = a.height, sdf.N = N, sdf.flip = gd.flip;
+    const int C = a.nContours;
+    WindingMasks wind;
+    wind.mem = windings;
+    wind.pos = wind.neg = 0;
+    if (OVERLAP) {
+        const int w = lane < C ? (int) wind.mem[lane] : 0;
+        wind.pos = __ballot(w > 0), wind.neg = __ballot(w < 0);
+    }
+    PBSlot *slotBuf = reinterpret_cast<PBSlot *>(smemSingle+a.slotOffset);
+    for (;;) {
+        int t = 0;
+        if (lane == 0)
+            t = atomicAdd(a.ticket, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= (int) count)
+            break;
+        const EcCandidate cand = segment[t];
+        PsdfQueryCooperative<OVERLAP, WindingMasks> query;
+        query.rec = recs, query.coff = contourOffsets, query.windings = wind, query.C = C, query.lane = lane;
+        query.res = smemSingle;
+        query.slots = a.nEdges <= a.slotCap && C <= a.slotCap ? slotBuf : NULL;
+        query.merged = slotBuf+a.slotCap;
+        const int rem = (int) cand.texel;
+        const int yn = rem/a.width, x = rem%a.width;
+        const int ys = gd.flip ? a.height-1-yn : yn;
+        const bool artifact = ecEvaluateCandidate(sdf, p, x, ys, cand.t, (cand.dir&3)-1, ((cand.dir>>2)&3)-1, query);
+        if (artifact && lane == 0) {
+            const float *in = sdf.native(x, yn);
+            const float m = medianf(in[0], in[1], in[2]);
+            float *px = a.out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
+            px[0] = m, px[1] = m, px[2] = m;
+            if (a.stencil)
+                a.stencil[stencilIndex((size_t) rem, yn, a.width, a.height, a.cfg.stencil_y_down)] |= (uint8_t) EC_ERROR;
+        }
+        waveSync();                                                 // the next candidate rewrites the LDS scratch
+    }
+}
+
 template <int SEL, bool OVERLAP>
 __global__ void __launch_bounds__(WAVE)
 k_single_call(SingleArgs a) {
@@ -84,106 +156,114 @@ k_single_call(SingleArgs a) {
     const int lane = threadIdx.x;
     const unsigned blk = blockIdx.x, groups = gridDim.x;
     const unsigned T = (unsigned) a.tiles;
-
     if (blk == 0 && lane == 0)
         a.status[0] = 0, a.status[1] = 0;                           // (phase 3 overwrites [0] with the candidate-overflow flag; [1]: a barrier gave up)
-    // ---- phase 0: digest (k_prep_records)
+    stampPhase(a, 0);
+    const unsigned long long cycles0 = __builtin_readcyclecounter();   // (shader clock: with the realtime stamps it tells at what clock the launch ran)
+
+    // ---- phase 0: digest (k_prep_records), the whole shape by every workgroup into its own area. The contour offsets go to LDS first (every
+    // lane searches them); the raw edges are read from the caller's staging (pinned host memory: two dependent PCIe round trips in all).
+    char *mine = a.priv+(size_t) blk*a.privStride;
+    EdgeRec *recs = reinterpret_cast<EdgeRec *>(mine);
+    int8_t *windings = reinterpret_cast<int8_t *>(mine+a.privWindings);
+    int32_t *contourOffsets = reinterpret_cast<int32_t *>(mine+a.privOffsets), *glyphContourOffsets = reinterpret_cast<int32_t *>(mine+a.privGlyphOffsets);
+    MsdfHipGlyph *glyph = reinterpret_cast<MsdfHipGlyph *>(mine+a.privGlyph);
     {
-        const int total = (int) groups*WAVE, tid = (int) blk*WAVE+lane;
-        for (int slot = tid; slot < a.nEdges; slot += total) {
+        // (the payload is addressed through the kernarg segment pointer: taking the address of a member of `a` would make the compiler copy
+        // the whole 4 KB struct to scratch)
+        const unsigned char *pay = (const unsigned char *) __builtin_amdgcn_kernarg_segment_ptr()+offsetof(SingleArgs, payload);
+        const bool inArgs = a.payloadBytes != 0;
+        const int32_t *srcOffsets = inArgs ? reinterpret_cast<const int32_t *>(pay+a.payOffsets) : a.srcContourOffsets;
+        const double *srcPoints = inArgs ? reinterpret_cast<const double *>(pay+a.payPoints) : a.points;
+        const uint8_t *srcTypes = inArgs ? pay+a.payTypes : a.types, *srcColors = inArgs ? pay+a.payColors : a.colors;
+        const MsdfHipGlyph *srcGlyph = inArgs ? reinterpret_cast<const MsdfHipGlyph *>(pay+a.payGlyph) : a.srcGlyph;
+        int32_t *coLds = reinterpret_cast<int32_t *>(smemSingle);
+        for (int i = lane; i <= a.nContours; i += WAVE)
+            coLds[i] = srcOffsets[i];
+        if (lane < (int) (sizeof(MsdfHipGlyph)/sizeof(double)))
+            reinterpret_cast<double *>(glyph)[lane] = reinterpret_cast<const double *>(srcGlyph)[lane];
+        if (lane < 2)
+            glyphContourOffsets[lane] = lane ? a.nContours : 0;
+        waveSync();
+        for (int i = lane; i <= a.nContours; i += WAVE)
+            contourOffsets[i] = coLds[i];
+        for (int slot = lane; slot < a.nEdges; slot += WAVE) {
             int lo = 0, hi = a.nContours-1;                         // last contour c with contourOffsets[c] <= slot (skips empty contours)
             while (lo < hi) {
                 const int mid = (lo+hi+1)>>1;
-                if (a.contourOffsets[mid] <= slot)
+                if (coLds[mid] <= slot)
                     lo = mid;
                 else
                     hi = mid-1;
             }
-            prepRecord(a.recs, slot, lo, a.contourOffsets, a.points, a.types, a.colors);
+            prepRecord(recs, slot, lo, coLds, srcPoints, srcTypes, srcColors);
         }
-        for (int c = tid; c < a.nContours; c += total)
-            a.windings[c] = (int8_t) contourWinding(c, a.contourOffsets, a.points, a.types, a.colors);
+        for (int c = lane; c < a.nContours; c += WAVE)
+            windings[c] = (int8_t) contourWinding(c, coLds, srcPoints, srcTypes, srcColors);
+        // the area is this wavefront's own: its stores only have to have LEFT the wavefront (they are written through to the XCD's L2, which
+        // also backs the scalar cache) before the phases below read them back; no other workgroup is involved
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        waveSync();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)\n\tbuffer_inv sc0" ::: "memory");
     }
-    gridBarrier(a.barrier, a.barrierBase+groups, a.status);
+    stampPhase(a, 1);
 
     BatchView batch;
-    batch.nGlyphs = 1, batch.glyphContourOffsets = a.glyphContourOffsets, batch.contourOffsets = a.contourOffsets, batch.recs = a.recs, batch.windings = a.windings;
+    batch.nGlyphs = 1, batch.glyphContourOffsets = glyphContourOffsets, batch.contourOffsets = contourOffsets, batch.recs = recs, batch.windings = windings;
 
     // ---- phase 1: distance field, one tile per workgroup; the extra workgroup prepares the correction pass
-    if (blk < T)
-        distanceBody<SEL, OVERLAP, true>(1, a.glyphContourOffsets, a.contourOffsets, a.recs, a.windings, a.glyph, a.width, a.height, a.tilesX, a.tiles, a.listStride,
-                                         a.correct ? a.scratch : a.out, a.correct, 0u, a.gres, a.gresStride, (const int *) NULL, 0, (unsigned *) NULL, 0u, blk, smemSingle);
+    if (blk < T) {
+        // the overlapping combiner's per-contour distances in LDS where they fit (a dependent L2 round trip per contour and pass otherwise)
+        if (OVERLAP && a.gres == NULL)
+            distanceBody<SEL, OVERLAP, false, 1>(1, glyphContourOffsets, contourOffsets, recs, windings, glyph, a.width, a.height, a.tilesX, a.tiles, a.listStride,
+                                                 a.correct ? a.scratch : a.out, a.correct, 0u, (double *) NULL, 0, (const int *) NULL, 0, (unsigned *) NULL, 0u, blk, smemSingle,
+                                                 a.nContours, a.nEdges);
+        else
+            distanceBody<SEL, OVERLAP, true, 1>(1, glyphContourOffsets, contourOffsets, recs, windings, glyph, a.width, a.height, a.tilesX, a.tiles, a.listStride,
+                                                a.correct ? a.scratch : a.out, a.correct, 0u, a.gres, a.gresStride, (const int *) NULL, 0, (unsigned *) NULL, 0u, blk, smemSingle,
+                                                a.nContours, a.nEdges);
+    }
     else if constexpr (SEL >= 3) {
-        ecParamsBody(a.ecParams, batch, a.glyph, a.cfg, reinterpret_cast<unsigned *>(a.cands), a.corners, a.sizes, 0, lane);
+        ecParamsBody(a.ecParams, batch, glyph, a.cfg, reinterpret_cast<unsigned *>(a.cands), a.corners, a.sizes, 0, lane);
         if (lane == 0)
             a.ticket[0] = 0;
     }
-    if (SEL < 3 || !a.correct)
-        return;
-    gridBarrier(a.barrier, a.barrierBase+2u*groups, a.status);
-
-    // ---- phase 2: error correction sweep (k_ec_fast)
+    stampPhase(a, 2);
     if constexpr (SEL >= 3) {
-        if (blk < T)
-            ecFastBody<(int) N>(batch, a.glyph, a.width, a.height, a.tilesX, a.tiles, a.scratch, a.out, a.stencil, a.cfg, a.ecParams, a.cands, a.seg,
-                                                 a.listStride, a.corners, blk, reinterpret_cast<int *>(smemSingle));
-        gridBarrier(a.barrier, a.barrierBase+3u*groups, a.status);
-
-        // ---- phase 3: deferred distance checks, cooperative (k_ec_query): a ticket = one candidate
-        const unsigned *header = reinterpret_cast<const unsigned *>(a.cands);
-        const unsigned count = header[1];
-        if (blk == 0 && lane == 0)
-            a.status[0] = count > a.seg ? 1u : header[0];
-        if (count == 0 || count > a.seg)
-            return;
-        const EcCandidate *segment = a.cands+ecHeaderRecords(1);
-        const MsdfHipGlyph gd = a.glyph[0];
-        EcParams p;
-        p.t = loadXform(gd);
-        p.minDeviationRatio = a.cfg.min_deviation_ratio;
-        p.minImproveRatio = a.cfg.min_improve_ratio;
-        p.mode = a.cfg.ec_mode, p.distanceCheck = a.cfg.ec_distance_check, p.overlap = OVERLAP, p.stageLimit = 0;
-        const EcGlyphParams gp = a.ecParams[0];
-        p.hSpan = gp.hSpan, p.vSpan = gp.vSpan, p.dSpan = gp.dSpan, p.texelX = gp.texelX, p.texelY = gp.texelY;
-        p.radiusH = gp.radiusH, p.radiusV = gp.radiusV, p.radiusD = gp.radiusD;
-        SdfView sdf;
-        sdf.px = a.scratch;
-        sdf.w = a.width, sdf.h = a.height, sdf.N = N, sdf.flip = gd.flip;
-        const int C = a.nContours;
-        WindingMasks wind;
-        wind.mem = a.windings;
-        wind.pos = wind.neg = 0;
-        if (OVERLAP) {
-            const int w = lane < C ? (int) wind.mem[lane] : 0;
-            wind.pos = __ballot(w > 0), wind.neg = __ballot(w < 0);
+        if (a.correct) {
+            gridBarrier(a.barrier, a.barrierBase+groups, a.status);
+            stampPhase(a, 3);
+            // ---- phase 2: error correction sweep (k_ec_fast)
+            if (blk < T)
+                ecFastBody<(int) N>(batch, glyph, a.width, a.height, a.tilesX, a.tiles, a.scratch, a.out, a.stencil, a.cfg, a.ecParams, a.cands, a.seg,
+                                    a.listStride, a.corners, blk, reinterpret_cast<int *>(smemSingle));
+            stampPhase(a, 4);
+            gridBarrier(a.barrier, a.barrierBase+2u*groups, a.status);
+            stampPhase(a, 5);
+            // ---- phase 3: deferred distance checks
+            const unsigned *header = reinterpret_cast<const unsigned *>(a.cands);
+            const unsigned count = header[1];
+            if (blk == 0 && lane == 0)
+                a.status[0] = count > a.seg ? 1u : header[0];
+            if (count != 0 && count <= a.seg)
+                singleCallChecks<(int) N, OVERLAP>(a, recs, windings, contourOffsets, glyph, smemSingle, count, lane);
         }
-        PBSlot *slotBuf = reinterpret_cast<PBSlot *>(smemSingle+a.slotOffset);
-        for (;;) {
-            int t = 0;
-            if (lane == 0)
-                t = atomicAdd(a.ticket, 1);
-            t = __builtin_amdgcn_readfirstlane(t);
-            if (t >= (int) count)
-                break;
-            const EcCandidate cand = segment[t];
-            PsdfQueryCooperative<OVERLAP, WindingMasks> query;
-            query.rec = a.recs, query.coff = a.contourOffsets, query.windings = wind, query.C = C, query.lane = lane;
-            query.res = smemSingle;
-            query.slots = a.nEdges <= a.slotCap && C <= a.slotCap ? slotBuf : NULL;
-            query.merged = slotBuf+a.slotCap;
-            const int rem = (int) cand.texel;
-            const int yn = rem/a.width, x = rem%a.width;
-            const int ys = gd.flip ? a.height-1-yn : yn;
-            const bool artifact = ecEvaluateCandidate(sdf, p, x, ys, cand.t, (cand.dir&3)-1, ((cand.dir>>2)&3)-1, query);
-            if (artifact && lane == 0) {
-                const float *in = sdf.native(x, yn);
-                const float m = medianf(in[0], in[1], in[2]);
-                float *px = a.out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
-                px[0] = m, px[1] = m, px[2] = m;
-                if (a.stencil)
-                    a.stencil[stencilIndex((size_t) rem, yn, a.width, a.height, a.cfg.stencil_y_down)] |= (uint8_t) EC_ERROR;
-            }
-            waveSync();                                             // the next candidate rewrites the LDS scratch
+    }
+    stampPhase(a, 6);
+    if (blk == 0 && lane == 0)
+        a.status[15] = (unsigned) (__builtin_readcyclecounter()-cycles0);
+
+    // ---- completion: the workgroup that finishes last raises the flag the host polls (status[2]); every workgroup's results are visible at
+    // system scope before it counts itself finished
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        const unsigned before = __hip_atomic_fetch_add(a.barrier+16, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before+1u == a.doneBase+groups) {
+            a.status[7] = (unsigned) __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __hip_atomic_store(a.status+2, a.doneValue, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

@@ -101,6 +101,7 @@ _PROTOS = {
     "msdfhip_trim": (C.c_int, []),
     "msdfhip_front_door_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "msdfhip_debug_wait_profile": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
+    "msdfhip_debug_single_call_phases": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_PROTOS))

@@ -5,6 +5,7 @@ operation order and no FMA contraction, so in practice outputs are bit-identical
 from glibc's in the last ulp; the tests report the number of texels whose bits differ and assert the 1e-5 bound on all of them.
 Stencils (integer flags) must match exactly.
 """
+import ctypes as C
 import threading
 
 import numpy as np
@@ -340,6 +341,76 @@ def test_scheduling_knobs_do_not_change_a_byte():
                 del os.environ[k]
             M.load().msdfhip_reload_tuning()
         assert (bits(got[0]) == bits(want[0])).all() and (bits(got[1]) == bits(want[1])).all(), env
+
+
+def test_single_shape_call_paths_are_byte_identical(latin, oracle):
+    """One generate*() call of one shape takes ONE launch (k_single_call, msdf_single.hpp): digest, distance field, correction sweep and distance
+    checks as phases of one grid, the inputs inside the kernel arguments or read from the pinned staging area, the tile written straight to host
+    memory. The same call through every other route -- inputs staged in pinned memory, uploaded inputs + device outputs, and the batched
+    launch sequence of round 3 -- must give the same bytes; and all of them the oracle's (1e-5; in practice bit-identical). Covers all four field
+    types, both combiners, an error-correction config with distance checks at every texel, a stencil buffer (which keeps the device-output
+    route), ragged sizes, a many-contour shape (combiner scratch in LDS / in the global workspace), a shape too large for the kernel arguments
+    and one beyond the fused path's limits (falls back by itself)."""
+    import os
+    batch, xf64, bounds = latin
+    cases = []
+    for g in (1, 12, 33, 45, 77):
+        cases.append((batch.shape(g), 64, 64, xf64[g]))
+    s = synth.cjk_like_shape(8601)
+    cases.append((s, 48, 40, autoframe(s.bounds(), 48, 40, 4)))
+    s = synth.random_shape(8700, n_contours=30, edges_per_contour=(3, 5), kinds=(1, 2))
+    cases.append((s, 33, 47, autoframe(s.bounds(), 33, 47, 3)))
+    s = synth.logo_shape(5)                                                       # 926 edges: neither argument payload nor (at 136 x 136 = 289 tiles) the fused path
+    cases.append((s, 72, 72, autoframe(s.bounds(), 72, 72, 4)))
+    cases.append((s, 136, 136, autoframe(s.bounds(), 136, 136, 4)))
+    always = cfg(True, M.EC_EDGE_PRIORITY, M.ALWAYS_CHECK_DISTANCE)
+    crowded = cfg(False, M.EC_EDGE_PRIORITY, M.ALWAYS_CHECK_DISTANCE)              # overlapping strokes without overlap support: candidate overflow -> the fused call hands over
+
+    def render():
+        out = []
+        for s, w, h, xf in cases:
+            out.append(gen(1, s, w, h, xf))
+            out.append(gen(2, s, w, h, xf, M.GeneratorConfig(False)))
+            out.append(gen(3, s, w, h, xf))
+            out.append(gen(3, s, w, h, xf, cfg(False, M.EC_DISABLED)))
+            out.append(gen(4, s, w, h, xf, always))
+            st = np.zeros((h, w), np.uint8)
+            out.append(gen(3, s, w, h, xf, cfg(True, buffer=st)))
+            out.append(st)
+        s = synth.cjk_like_shape(8801)
+        out.append(gen(3, s, 48, 48, autoframe(s.bounds(), 48, 48, 4), crowded))
+        return out
+    want = render()
+    lib = M.load()
+    ph = (C.c_double*8)()
+    lib.msdfhip_debug_single_call_phases(ph, 1)
+    render()
+    lib.msdfhip_debug_single_call_phases(ph, 1)
+    assert int(ph[0]) >= 10, "the fused launch did not run (%d calls counted)" % int(ph[0])
+    for env in ({"MSDFHIP_NO_ARG_PAYLOAD_SINGLE": "1"}, {"MSDFHIP_NO_ZERO_COPY_SINGLE": "1"}, {"MSDFHIP_NO_FUSED_SINGLE": "1"}):
+        os.environ.update(env)
+        lib.msdfhip_reload_tuning()
+        try:
+            got = render()
+        finally:
+            for k in env:
+                del os.environ[k]
+            lib.msdfhip_reload_tuning()
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a.shape == b.shape and (a.view(np.uint8) == b.view(np.uint8)).all(), (env, i)
+    k = 0
+    for s, w, h, xf in cases[:7]:                                                 # (the 926-edge logo costs the oracle seconds per render: the byte comparison above covers it)
+        close(want[k], oracle.generate(s, 1, w, h, xf), "sdf")
+        close(want[k+1], oracle.generate(s, 2, w, h, xf, overlap=False), "psdf")
+        close(want[k+2], oracle.generate(s, 3, w, h, xf), "msdf")
+        close(want[k+3], oracle.generate(s, 3, w, h, xf, overlap=False, ec_mode=0), "msdf, simple combiner, no correction")
+        close(want[k+4], oracle.generate(s, 4, w, h, xf, ec_mode=2, ec_dist=2), "mtsdf, distance checks everywhere")
+        sb = np.zeros((h, w), np.uint8)
+        close(want[k+5], oracle.generate(s, 3, w, h, xf, stencil=sb), "msdf with stencil")
+        assert (want[k+6] == sb).all()
+        k += 7
+    s = synth.cjk_like_shape(8801)
+    close(want[-1], oracle.generate(s, 3, 48, 48, autoframe(s.bounds(), 48, 48, 4), overlap=False, ec_mode=2, ec_dist=2), "candidate overflow")
 
 
 def test_very_many_contours_use_the_global_combiner_scratch(oracle):

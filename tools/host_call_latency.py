@@ -33,7 +33,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", default="1,4,16,64")
     ap.add_argument("--calls", type=int, default=400)
-    ap.add_argument("--leaders", default="2")
+    ap.add_argument("--leaders", default="2,0", help="micro-batcher leader slots per run; 0 = micro-batching off")
     args = ap.parse_args()
     import msdfgen_amd as M
     from msdfgen_amd.shape import distance_mapping
@@ -59,16 +59,20 @@ def main():
                                 p(xfs, C.c_double), 3, 64, 64, C.byref(bad), p(tile, C.c_float))
         assert bad.value == 0, "%d calls failed" % bad.value
         return secs
-    for micro in [int(x) for x in args.leaders.split(",")]+[0]:
+    for micro in [int(x) for x in args.leaders.split(",")]:
         M.set_microbatch(256 if micro else 1, max(micro, 1))
         run(4, 20)                                                       # warm the arenas
         for nt in [int(t) for t in args.threads.split(",")]:
             M.microbatch_stats(reset=True)
             secs = run(nt, args.calls)
             st = M.microbatch_stats()
+            ph = (C.c_double*8)()
+            M.load().msdfhip_debug_single_call_phases(ph, 1)
             print(json.dumps({"leaders": micro, "host_threads": nt, "calls": nt*args.calls, "us_per_call_per_thread": round(1e6*secs/args.calls, 1),
                               "glyphs_per_s": round(nt*args.calls/secs), "device_batches": st["batches"], "largest_group": st["largest"],
-                              "us_per_batch": {k: round(1e3*st[k+"_ms"]/max(st["batches"], 1), 1) for k in ("stage", "device", "scatter")}}), flush=True)
+                              "us_per_batch": {k: round(1e3*st[k+"_ms"]/max(st["batches"], 1), 1) for k in ("stage", "device", "scatter")},
+                              "fused_single_calls": int(ph[0]), "fused_shader_mhz": round((ph[0]-int(ph[0]))*1e6), "fused_phase_us": dict(zip(("digest", "distance_wg0", "wait_all_tiles", "sweep_wg0", "wait_all_sweeps", "checks", "first_to_last"),
+                                                                                        [round(v, 2) for v in list(ph)[1:]]))}), flush=True)
 
 
 if __name__ == "__main__":
