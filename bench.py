@@ -366,8 +366,15 @@ def mock_rank(args, rank, world):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    batch, xfs, _ = load_dejavu()
-    sub, sx, (lo, hi), bounds = rank_shard(batch, xfs, args.glyphs, world, rank, args.size, args.size)
+    if args.strong:                                                  # ONE set cut into `world` shards (total work fixed)
+        from msdfgen_amd.shard import partition_contiguous, glyph_costs
+        whole, wxf = config4_sets()[args.strong_set]
+        bounds = partition_contiguous(glyph_costs(whole, 48, 48), world)
+        lo, hi = int(bounds[rank]), int(bounds[rank+1])
+        sub = whole.select(range(lo, hi))
+    else:
+        batch, xfs, _ = load_dejavu()
+        sub, sx, (lo, hi), bounds = rank_shard(batch, xfs, args.glyphs, world, rank, args.size, args.size)
     t = torch.tensor([float(sub.n_edges), float(hi-lo)], dtype=torch.float64)
     parts = [torch.zeros_like(t) for _ in range(world)]
     if world > 1:
@@ -376,7 +383,7 @@ def mock_rank(args, rank, world):
     else:
         parts = [t]
     if rank == 0:
-        print(json.dumps({"mock": True, "n_gpus": world, "bounds": [int(v) for v in bounds], "glyphs_per_rank": [int(p[1]) for p in parts],
+        print(json.dumps({"mock": True, "n_gpus": world, "scaling": "strong" if args.strong else "weak", "bounds": [int(v) for v in bounds], "glyphs_per_rank": [int(p[1]) for p in parts],
                           "edges_per_rank": [int(p[0]) for p in parts]}))
     if world > 1:
         dist.barrier()

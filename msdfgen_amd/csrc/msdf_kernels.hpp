@@ -317,7 +317,10 @@ __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, con
         EdgeRegs r;
         r.meta = cur;
         unsigned nextV;
-        const unsigned nextAddr = (unsigned) (size_t) (edges.list+k+1);       // LDS byte address (low half of the flat address)
+        // LDS byte address of the next entry = the LOW 32 bits of its flat address: on gfx9-family devices (gfx950 included) a flat address
+        // inside the shared aperture is { src_shared_base (high dword) | LDS offset (low dword) } -- the aperture is 4 GB-aligned, so the
+        // truncation is the address-space cast the compiler itself emits for flat -> LDS. This library is built for gfx950 only (build.py).
+        const unsigned nextAddr = (unsigned) (size_t) (edges.list+k+1);
 #if defined(MSDF_PROFILE_WAITS)
         MSDF_STAMP(t0);
 #endif

@@ -32,7 +32,9 @@ struct FlatShape {
 };
 
 // const Shape & -> CSR edge buffer (read-only traversal: contours[i].edges[j]->type()/controlPoints()/color, core/Shape.h:24, core/edge-segments.h:28-31).
+// (`flat` is the calling thread's reusable buffer: after the first calls of a thread the four vectors have their capacity and a call allocates nothing)
 void flatten(const Shape &shape, FlatShape &flat) {
+    flat.contourOffsets.clear(), flat.points.clear(), flat.types.clear(), flat.colors.clear();
     const int edges = shape.edgeCount();
     flat.contourOffsets.reserve(shape.contours.size()+1);
     flat.points.reserve(8*(size_t) edges);
@@ -110,7 +112,7 @@ void check(int rc, const char *what) {
 
 template <int N>
 void generate(int mode, const BitmapSection<float, N> &output, const Shape &shape, const SDFTransformation &transformation, bool overlapSupport, const ErrorCorrectionConfig *ec) {
-    FlatShape flat;
+    static thread_local FlatShape flat;
     flatten(shape, flat);
     double xf[6];
     transformationToXf(transformation, xf);
@@ -124,7 +126,7 @@ void generate(int mode, const BitmapSection<float, N> &output, const Shape &shap
 
 template <int N>
 void correct(const BitmapSection<float, N> &sdf, const Shape &shape, const SDFTransformation &transformation, const MSDFGeneratorConfig &config) {
-    FlatShape flat;
+    static thread_local FlatShape flat;
     flatten(shape, flat);
     double xf[6];
     transformationToXf(transformation, xf);
@@ -138,7 +140,7 @@ void correct(const BitmapSection<float, N> &sdf, const Shape &shape, const SDFTr
 
 template <int N>
 void signCorrect(const BitmapSection<float, N> &sdf, const Shape &shape, const Projection &projection, float sdfZeroValue, FillRule fillRule) {
-    FlatShape flat;
+    static thread_local FlatShape flat;
     flatten(shape, flat);
     const Vector2 one = projection.projectVector(Vector2(1, 1)), origin = projection.unproject(Point2(0, 0));
     const double xf[6] = { one.x, one.y, -origin.x, -origin.y, 1, 0 };       // scale, translate (Projection.cpp:12-36)
@@ -258,7 +260,7 @@ void simulate8bit(const BitmapSection<float, 4> &bitmap) { check(msdfhip_simulat
 
 // ---- core/rasterization.h:13-27: together these replace the whole of core/rasterization.cpp
 void rasterize(BitmapSection<float, 1> output, const Shape &shape, const Projection &projection, FillRule fillRule) {
-    FlatShape flat;
+    static thread_local FlatShape flat;
     flatten(shape, flat);
     const Vector2 one = projection.projectVector(Vector2(1, 1)), origin = projection.unproject(Point2(0, 0));
     const double xf[6] = { one.x, one.y, -origin.x, -origin.y, 1, 0 };

@@ -84,3 +84,20 @@ def test_bench_gpus_2_spawns_two_ranks():
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mock"], capture_output=True, text=True, timeout=120, env=env2)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr+p.stdout)
+
+
+def test_bench_strong_scaling_mode_cuts_one_set():
+    """`bench.py --strong --gpus N` = BASELINE config 4 as stated: ONE 8 192-glyph 48x48 set cut into N contiguous shards of equal modelled cost
+    (total work fixed; the default mode gives every rank a full set). Control path on CPU (--mock, gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for name in ("dejavu", "cjk_like"):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mock", "--strong", "--strong-set", name], capture_output=True, text=True,
+                           timeout=300, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        r = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")][0]
+        assert r["scaling"] == "strong" and r["bounds"][0] == 0 and r["bounds"][-1] == 8192 and sum(r["glyphs_per_rank"]) == 8192
+        assert all(g > 2000 for g in r["glyphs_per_rank"]), r
