@@ -2323,7 +2323,9 @@ static int runGroup(ShapeCall *const *calls, int n) {
     }
     const size_t texels = (size_t) w*h, tileBytes = texels*channels*sizeof(float);
     const size_t eAlloc = sumE > 0 ? sumE : 1, cAlloc = sumC > 0 ? sumC : 1;
-    const size_t candCap = deferredRecords(n, texels, (int) sumE);
+    const size_t tilesAllEarly = (size_t) ((w+TILE-1)/TILE)*((h+TILE-1)/TILE);
+    const size_t singleCand = n == 1 && tilesAllEarly <= 256 ? ecHeaderRecords((int) tilesAllEarly)+tilesAllEarly*SINGLE_TILE_SEGMENT+(eAlloc*2*sizeof(int)+sizeof(EcCandidate)-1)/sizeof(EcCandidate) : 0;
+    const size_t candCap = deferredRecords(n, texels, (int) sumE) > singleCand ? deferredRecords(n, texels, (int) sumE) : singleCand;   // (k_single_call lays the buffer out per tile)
 
     // host staging layout (inputs first: one H2D copy; then the results: one D2H copy)
     Carver hc;
@@ -2487,21 +2489,23 @@ static int runGroup(ShapeCall *const *calls, int n) {
             sa.scratch = correct ? reinterpret_cast<float *>(a.dev+dScratch) : NULL;
             sa.out = zeroCopy ? reinterpret_cast<float *>(a.pinnedDev+hOut) : dOut, sa.stencil = dStencil;
             sa.gres = overlapEff && !resInLds ? reinterpret_cast<double *>(a.dev+dGresOff) : NULL, sa.gresStride = resBytes/sizeof(double);
-            sa.cfg = *cfg, sa.correct = correct ? 1 : 0, sa.ecParams = b.dEcParams, sa.cands = b.dDeferred, sa.seg = ecSegment(texels);
-            int *offsets = correct ? reinterpret_cast<int *>(b.dDeferred+candidateRecords(1, texels)) : NULL;
-            sa.corners = correct ? reinterpret_cast<int *>(b.dDeferred+candidateRecords(1, texels)+offsetRecords(1)) : NULL;
-            sa.sizes = NULL, sa.ticket = correct ? offsets+4 : NULL;
+            // candidates: a counter and a segment of SINGLE_TILE_SEGMENT records per TILE (the tile's workgroup judges them itself), then the corner list
+            sa.cfg = *cfg, sa.correct = correct ? 1 : 0, sa.ecParams = b.dEcParams, sa.cands = b.dDeferred, sa.seg = SINGLE_TILE_SEGMENT;
+            sa.corners = correct ? reinterpret_cast<int *>(b.dDeferred+ecHeaderRecords((int) tilesAll)+tilesAll*SINGLE_TILE_SEGMENT) : NULL;
+            sa.sizes = NULL;
             sa.slotCap = slotCap, sa.slotOffset = slotOffset;
             const unsigned groups = (unsigned) tilesAll+(correct ? 1u : 0u);
             sa.barrier = a.barrier, sa.barrierBase = a.barrierEpoch, sa.doneBase = a.doneCount;
-            a.barrierEpoch += (correct ? 2u : 0u)*groups, a.doneCount += groups;   // what this launch adds to the two counters
+            a.barrierEpoch += (correct ? 1u : 0u)*groups, a.doneCount += groups;   // what this launch adds to the two counters
             if (++a.doneEpoch == 0)
                 a.doneEpoch = 1;
             sa.doneValue = a.doneEpoch;
             volatile unsigned *hostStatus = reinterpret_cast<volatile unsigned *>(a.pinned+hStatus);
             sa.status = reinterpret_cast<unsigned *>(zeroCopy ? a.pinnedDev+hStatus : a.dev+hStatus);
             if (zeroCopy)
-                hostStatus[2] = 0;                               // (the staging area is recycled: whatever sits there is not this call's flag)
+                hostStatus[0] = hostStatus[1] = hostStatus[2] = 0;   // overflow / barrier flags are only ever RAISED by the kernel; [2]: the staging area is recycled, whatever sits there is not this call's flag
+            else
+                HIPCHK(hipMemsetAsync(a.dev+hStatus, 0, 64, a.stream));
             switch (mode*2+(overlapEff ? 1 : 0)) {
                 case 2: hipLaunchKernelGGL((k_single_call<1, false>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
                 case 3: hipLaunchKernelGGL((k_single_call<1, true>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;

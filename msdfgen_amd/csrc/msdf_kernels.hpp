@@ -984,7 +984,9 @@ __host__ __device__ inline size_t ecFastLdsBytes(int maxEdges, int n) {
 template <int N>
 __device__ __forceinline__ void ecFastBody(const BatchView &batch, const MsdfHipGlyph *glyphs, int width, int height, int tilesX, int tilesPerGlyph,
           const float *src, float *out, uint8_t *stencilOut, const MsdfHipConfig &cfg, const EcGlyphParams *glyphParams, EcCandidate *cands, unsigned seg,
-          int maxEdges, const int *corners, const unsigned blockId, int *smemFast) {
+          int maxEdges, const int *corners, const unsigned blockId, int *smemFast, const int sinkSlots = 0, const int sinkSlot = 0) {
+    // (sinkSlots > 0: the distance-check candidates go to segment sinkSlot of sinkSlots instead of the glyph's -- k_single_call gives every TILE its own
+    // segment and lets the tile's workgroup judge them itself)
     const GlyphWork wk = decodeItem(blockId, batch.nGlyphs, tilesPerGlyph);
     if (!wk.valid)
         return;
@@ -1131,8 +1133,8 @@ __device__ __forceinline__ void ecFastBody(const BatchView &batch, const MsdfHip
         const float *hb = halo+((sy+1)*EC_HALO+sx+1+dx)*N, *vc = halo+((sy+1+dy)*EC_HALO+sx+1)*N;
         CandidateSink sink;
         sink.header = reinterpret_cast<unsigned *>(cands);
-        sink.segment = cands+ecHeaderRecords(batch.nGlyphs)+(size_t) wk.g*seg;
-        sink.seg = seg, sink.g = wk.g;
+        sink.segment = sinkSlots > 0 ? cands+ecHeaderRecords(sinkSlots)+(size_t) sinkSlot*seg : cands+ecHeaderRecords(batch.nGlyphs)+(size_t) wk.g*seg;
+        sink.seg = seg, sink.g = sinkSlots > 0 ? sinkSlot : wk.g;
         sink.texel = (unsigned) (((size_t) wk.g*height+ty*TILE+sy)*width+tx*TILE+sx);
         const int v = evaluatePair(c, n, hb, vc, p, (verdictLds[s]&0x100) != 0, gd.flip, k, jp, sink);
         if (v)

@@ -24,6 +24,8 @@
 
 namespace msdfhip {
 
+enum { SINGLE_TILE_SEGMENT = 64 };     // distance-check candidates a tile may leave (default config: ~0.1 per tile; beyond, the call is rerun through the batched path)
+
 struct SingleArgs {
     // the shape as the CALLER staged it: CSR arrays of ONE glyph, read once in phase 0 -- device memory or pinned host memory (zero copy:
     // a few KB over PCIe, two dependent round trips, instead of an upload launch in front of this one)
@@ -50,7 +52,7 @@ struct SingleArgs {
     EcGlyphParams *ecParams;
     EcCandidate *cands;
     unsigned seg;
-    int *corners, *sizes, *ticket;
+    int *corners, *sizes;
     int slotCap, slotOffset;
     // launch bookkeeping
     unsigned *barrier;                 // [0] grid-barrier counter, [16] finished-workgroup counter: device memory, only ever counted up
@@ -93,11 +95,12 @@ __device__ __forceinline__ void stampPhase(const SingleArgs &a, int k) {
         a.status[8+k] = (unsigned) __builtin_amdgcn_s_memrealtime();
 }
 
-// The distance checks of phase 3 (k_ec_query's cooperative form for ONE glyph): a ticket = one candidate, lanes = edges.
+// The distance checks of a tile's own candidates (k_ec_query's cooperative form: one candidate at a time, lanes = edges). A candidate only ever
+// changes its own texel (ERROR: rgb := median of the pre-correction value, stencil |= ERROR) and reads the pre-correction field, which is
+// complete once the grid is past the barrier -- so the workgroup that swept the tile judges them itself, no work list and no further barrier.
 template <int N, bool OVERLAP>
 __device__ __forceinline__ void singleCallChecks(const SingleArgs &a, const EdgeRec *recs, const int8_t *windings, const int32_t *contourOffsets, const MsdfHipGlyph *glyph,
-                                        double *smemSingle, unsigned count, int lane) {
-    const EcCandidate *segment = a.cands+ecHeaderRecords(1);
+                                                 double *smemSingle, const EcCandidate *segment, unsigned count, int lane) {
     const MsdfHipGlyph gd = glyph[0];
     EcParams p;
     p.t = loadXform(gd);
@@ -119,13 +122,7 @@ __device__ __forceinline__ void singleCallChecks(const SingleArgs &a, const Edge
         wind.pos = __ballot(w > 0), wind.neg = __ballot(w < 0);
     }
     PBSlot *slotBuf = reinterpret_cast<PBSlot *>(smemSingle+a.slotOffset);
-    for (;;) {
-        int t = 0;
-        if (lane == 0)
-            t = atomicAdd(a.ticket, 1);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if (t >= (int) count)
-            break;
+    for (unsigned t = 0; t < count; ++t) {
         const EcCandidate cand = segment[t];
         PsdfQueryCooperative<OVERLAP, WindingMasks> query;
         query.rec = recs, query.coff = contourOffsets, query.windings = wind, query.C = C, query.lane = lane;
@@ -156,8 +153,7 @@ k_single_call(SingleArgs a) {
     const int lane = threadIdx.x;
     const unsigned blk = blockIdx.x, groups = gridDim.x;
     const unsigned T = (unsigned) a.tiles;
-    if (blk == 0 && lane == 0)
-        a.status[0] = 0, a.status[1] = 0;                           // (phase 3 overwrites [0] with the candidate-overflow flag; [1]: a barrier gave up)
+    // (status[0] / [1] -- candidate overflow, a barrier that gave up -- are zeroed by the HOST before the launch and only ever raised here)
     stampPhase(a, 0);
     const unsigned long long cycles0 = __builtin_readcyclecounter();   // (shader clock: with the realtime stamps it tells at what clock the launch ran)
 
@@ -225,29 +221,31 @@ k_single_call(SingleArgs a) {
                                                 a.nContours, a.nEdges);
     }
     else if constexpr (SEL >= 3) {
-        ecParamsBody(a.ecParams, batch, glyph, a.cfg, reinterpret_cast<unsigned *>(a.cands), a.corners, a.sizes, 0, lane);
-        if (lane == 0)
-            a.ticket[0] = 0;
+        ecParamsBody(a.ecParams, batch, glyph, a.cfg, (unsigned *) NULL, a.corners, a.sizes, 0, lane);
+        for (unsigned i = (unsigned) lane; i <= T; i += WAVE)       // the tiles' candidate counters ([0]: overflow flag)
+            reinterpret_cast<unsigned *>(a.cands)[i] = 0;
     }
     stampPhase(a, 2);
     if constexpr (SEL >= 3) {
         if (a.correct) {
             gridBarrier(a.barrier, a.barrierBase+groups, a.status);
             stampPhase(a, 3);
-            // ---- phase 2: error correction sweep (k_ec_fast)
-            if (blk < T)
+            // ---- phase 2: error correction sweep (k_ec_fast) of the tile, then the distance checks of the candidates it left
+            if (blk < T) {
                 ecFastBody<(int) N>(batch, glyph, a.width, a.height, a.tilesX, a.tiles, a.scratch, a.out, a.stencil, a.cfg, a.ecParams, a.cands, a.seg,
-                                    a.listStride, a.corners, blk, reinterpret_cast<int *>(smemSingle));
-            stampPhase(a, 4);
-            gridBarrier(a.barrier, a.barrierBase+2u*groups, a.status);
-            stampPhase(a, 5);
-            // ---- phase 3: deferred distance checks
-            const unsigned *header = reinterpret_cast<const unsigned *>(a.cands);
-            const unsigned count = header[1];
-            if (blk == 0 && lane == 0)
-                a.status[0] = count > a.seg ? 1u : header[0];
-            if (count != 0 && count <= a.seg)
-                singleCallChecks<(int) N, OVERLAP>(a, recs, windings, contourOffsets, glyph, smemSingle, count, lane);
+                                    a.listStride, a.corners, blk, reinterpret_cast<int *>(smemSingle), (int) T, (int) blk);
+                stampPhase(a, 4);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the candidates are this wavefront's own stores: they only have to have left it
+                waveSync();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const unsigned count = __hip_atomic_load(reinterpret_cast<const unsigned *>(a.cands)+1+blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                stampPhase(a, 5);
+                if (count > a.seg) {
+                    if (lane == 0)
+                        a.status[0] = 1u;                           // more candidates than a tile's segment holds: the host reruns the call through the batched path
+                } else if (count != 0)
+                    singleCallChecks<(int) N, OVERLAP>(a, recs, windings, contourOffsets, glyph, smemSingle, a.cands+ecHeaderRecords((int) T)+(size_t) blk*a.seg, count, lane);
+            }
         }
     }
     stampPhase(a, 6);

@@ -71,7 +71,7 @@ def main():
             print(json.dumps({"leaders": micro, "host_threads": nt, "calls": nt*args.calls, "us_per_call_per_thread": round(1e6*secs/args.calls, 1),
                               "glyphs_per_s": round(nt*args.calls/secs), "device_batches": st["batches"], "largest_group": st["largest"],
                               "us_per_batch": {k: round(1e3*st[k+"_ms"]/max(st["batches"], 1), 1) for k in ("stage", "device", "scatter")},
-                              "fused_single_calls": int(ph[0]), "fused_shader_mhz": round((ph[0]-int(ph[0]))*1e6), "fused_phase_us": dict(zip(("digest", "distance_wg0", "wait_all_tiles", "sweep_wg0", "wait_all_sweeps", "checks", "first_to_last"),
+                              "fused_single_calls": int(ph[0]), "fused_shader_mhz": round((ph[0]-int(ph[0]))*1e6), "fused_phase_us": dict(zip(("digest", "distance_wg0", "wait_all_tiles", "sweep_wg0", "candidates_visible", "checks_wg0", "first_to_last"),
                                                                                         [round(v, 2) for v in list(ph)[1:]]))}), flush=True)
 
 
