@@ -2,22 +2,30 @@
 // core/msdfgen.cpp:78-106 -- for the multi-channel types incl. msdfErrorCorrection, :92-98).
 //
 // The batched path spends 7 dependent launches on such a call (k_prep_records, k_distance, k_ec_params, k_ec_fast, k_ec_scan, k_ec_query, copies):
-// ~60 us of launch / dependency latency around ~60 us of kernels, 116-128 us per call, 8.3 k glyphs/s from one caller thread. Here the same
+// ~60 us of launch / dependency latency around ~60 us of kernels, 116-133 us per call, 7.5-8.3 k glyphs/s from one caller thread. Here the same
 // device code (distanceBody, ecParamsBody, ecFastBody and the cooperative distance checks -- the bodies of those kernels, msdf_kernels.hpp) runs as
-// the PHASES of one launch of tiles+1 single-wavefront workgroups, separated by grid barriers:
+// the PHASES of one launch of tiles+1 single-wavefront workgroups:
 //
-//   phase 0  digest: raw CSR edges -> EdgeRec records + contour windings (threads = edges / contours over the whole grid)
-//   phase 1  workgroup t < tiles: distance field of tile t (one tile per wavefront, the latency-shaped form of k_distance: combiner scratch
-//            in a global slice); workgroup `tiles`: the glyph's error-correction constants and corner texels (k_ec_params' job)
-//   phase 2  workgroup t: error correction of tile t (k_ec_fast's body: halo from the pre-correction field, corrected texels + stencil out,
-//            distance-check candidates appended)
-//   phase 3  the candidates, one per ticket, lanes = edges (k_ec_query's cooperative form)
+//   digest    EVERY workgroup digests the whole shape (raw CSR edges -> EdgeRec records + contour windings, lanes = edges) into an area of its
+//             own: a 25-edge glyph is one round of lanes, and what the workgroup reads later it wrote itself -- no grid barrier, and the
+//             records are warm in its XCD's L2. Small shapes arrive INSIDE the kernel arguments (device memory, written by the host through the
+//             PCIe aperture), larger ones are read from the caller's pinned staging area (two dependent PCIe round trips).
+//   distance  workgroup t < tiles: distance field of tile t (k_distance's body, one tile per wavefront, the scalar cache warmed with the
+//             survivors' records first; the overlapping combiner's scratch in LDS where it fits); workgroup `tiles`: the glyph's
+//             error-correction constants and corner texels (k_ec_params' job)
+//   -- grid barrier (the correction sweep reads the neighbouring tiles' pre-correction texels) --
+//   sweep     workgroup t: error correction of tile t (k_ec_fast's body: halo from the pre-correction field, corrected texels + stencil out),
+//             then the distance checks of the candidates the tile left, one at a time with lanes = edges (k_ec_query's cooperative form): a
+//             candidate only changes its own texel and reads the pre-correction field, so no work list and no further barrier are needed
+//   done      results go straight to pinned host memory (posted writes); the workgroup that finishes last raises a flag there, which the host polls
 //
-// All workgroups of the launch are resident at once (<= 257 wavefronts on 1 024 SIMDs), so a barrier is an atomic counter in device memory:
-// arrive with an agent-scope release (L2 write-back: the workgroups sit on different XCDs), spin, agent-scope acquire. The survivor walk of
-// phase 1 reads the records written in phase 0 with hand-placed SCALAR loads, which the compiler's memory model does not cover (it never
-// emits scalar loads of memory the kernel itself writes): the scalar data cache is invalidated explicitly after every barrier. The counter
-// is never reset -- each call waits for values above the ones the previous call on the same arena left behind (barrierBase).
+// All workgroups of the launch are resident at once (<= 257 wavefronts on 1 024 SIMDs), so the barrier is an atomic counter in device memory:
+// arrive with an agent-scope release (L2 write-back: the workgroups sit on different XCDs), spin, agent-scope acquire. The survivor walk reads
+// the records written in the digest with hand-placed SCALAR loads, which the compiler's memory model does not cover (it never emits scalar loads of
+// memory the kernel itself writes): the scalar data cache is invalidated explicitly after the digest and after the barrier. The counters are
+// never reset -- each call waits for values above the ones the previous call on the same arena left behind (barrierBase / doneBase).
+// Measured (profiles/r04_host_calls.jsonl): 128 -> 83 us per 64x64 generateMSDF from one host thread, 68 us of it inside the launch
+// (digest 8, slowest tile's distance field 33, barrier + slowest sweep 25).
 #pragma once
 
 #include "msdf_kernels.hpp"
