@@ -158,7 +158,7 @@ int msdfhip_rasterize(float *pixels, int width, int height, int row_stride, int 
 
 /* Transparent micro-batching of the single-shape entry points above. Host threads that call them concurrently
  * (msdf-atlas-gen's workers) are combined group-commit style into one device batch per set of calls with equal launch parameters
- * (mode, size, config); a lone caller never waits. On by default (groups of up to 256 calls, 2 concurrent leaders); the
+ * (mode, size, config); a lone caller never waits. On by default (groups of up to 256 calls, 4 concurrent leaders); the
  * environment variable MSDFHIP_MICROBATCH=0 or max_group <= 1 turns it off (every call then runs on its own stream).
  * msdfhip_microbatch_stats: calls served / device batches run / largest group since the last reset. */
 int msdfhip_set_microbatch(int max_group, int max_leaders);

@@ -76,9 +76,11 @@ struct Tuning {
     char devices[256];               // MSDFHIP_DEVICES             "all" | "0,1,..." devices the single-shape front door spreads over
 };
 // Published through an atomic pointer: msdfhip_reload_tuning() builds a fresh table and swaps it in while launch paths on other threads keep
-// reading the one they loaded (superseded tables are never freed: a few hundred bytes per reload, tests and A/B scripts only).
+// reading the one they loaded. Superseded tables stay alive -- a thread may still hold a reference -- in gTuningTables (a few hundred bytes per
+// reload; tests and A/B scripts only), which also keeps them reachable for leak checkers.
 std::atomic<const Tuning *> gTuning(NULL);
 std::mutex gTuningMutex;
+std::vector<Tuning *> gTuningTables;                             // every table ever published (guarded by gTuningMutex)
 
 void readTuning() {
     Tuning &t = *new Tuning;
@@ -114,6 +116,7 @@ void readTuning() {
     t.smallLaunchTiles = (env = getenv("MSDFHIP_SMALL_LAUNCH_TILES")) ? atol(env) : 8192;
     if ((env = getenv("MSDFHIP_DEVICES")))
         snprintf(t.devices, sizeof(t.devices), "%s", env);
+    gTuningTables.push_back(&t);                                 // (callers hold gTuningMutex)
     gTuning.store(&t, std::memory_order_release);
 }
 
@@ -2247,7 +2250,11 @@ static long long nowNs() { return std::chrono::duration_cast<std::chrono::nanose
 
 // Runs n compatible calls as ONE device batch on the calling thread's arena: stage all inputs -> one H2D copy -> digest + kernels ->
 // one D2H copy -> scatter the tiles into the callers' bitmaps. n == 1 is the plain single-shape call.
-static std::atomic<int> gMaxGroup(-1), gMaxLeaders(2);
+// Leader slots = groups in flight at once. Two was right while a lone call was seven launches (more leaders only interleaved their launch chains);
+// with one fused launch per lone call (k_single_call) four measured better at every thread count: 4 threads 21.5 -> 42.8 k glyphs/s, 16 threads
+// 45 -> 49 k, 64 threads 96 -> 122 k (8 leaders: 43 / 53 / 103 k; 16: 27 / 62 / 75 k; profiles/r04_host_calls.jsonl).
+enum { DEFAULT_LEADERS = 4 };
+static std::atomic<int> gMaxGroup(-1), gMaxLeaders(DEFAULT_LEADERS);
 
 // End of a latency-bound call: poll the stream for a bounded time before handing the thread to the blocking wait (whose wake-up alone
 // costs 10-20 us, a sixth of a single-shape call).
@@ -2293,8 +2300,8 @@ static int frontDoorDevice() {
                 }
         }
         (void) hipGetLastError();
-        if (gFrontDevices.size() > 1 && gMaxLeaders.load() == 2)     // two groups in flight per device, as on one device
-            gMaxLeaders.store(2*(int) gFrontDevices.size());
+        if (gFrontDevices.size() > 1 && gMaxLeaders.load() == DEFAULT_LEADERS)   // as many groups in flight per device as on one device
+            gMaxLeaders.store(DEFAULT_LEADERS*(int) gFrontDevices.size());
     }
     if (gFrontDevices.empty())
         return -1;

@@ -535,7 +535,7 @@ def test_micro_batched_concurrent_calls_mixed_parameters(latin, oracle):
         assert not errors, errors[:3]
         assert failures == [M.lib.ERR_INVALID]*6
         assert st["calls"] == 23*6 and (enabled or st["batches"] == st["calls"])
-    M.set_microbatch(256, 2)
+    M.set_microbatch(256, 4)
 
 
 # ---- distanceSignCorrection (core/rasterization.cpp:19-92) on the device

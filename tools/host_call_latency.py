@@ -33,7 +33,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", default="1,4,16,64")
     ap.add_argument("--calls", type=int, default=400)
-    ap.add_argument("--leaders", default="2,0", help="micro-batcher leader slots per run; 0 = micro-batching off")
+    ap.add_argument("--leaders", default="4,0", help="micro-batcher leader slots per run; 0 = micro-batching off")
     args = ap.parse_args()
     import msdfgen_amd as M
     from msdfgen_amd.shape import distance_mapping

@@ -1,6 +1,6 @@
 # One gpurun call: every profile the bench line and DESIGN.md quote, for the bench command (counters in their own passes, --kernel-trace only).
 # Usage: bash tools/profile_round.sh <tag> [commit]     -> gpurun_out/<tag>_*  and  profiles/<tag>_kernel_stats.txt, <tag>_pmc_bench.json, pmc_traffic.json
-TAG=${1:-r03}; COMMIT=${2:-?}
+TAG=${1:-r04}; COMMIT=${2:-?}
 REPO=$PWD; export TMPDIR=/tmp
 P1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64"
 P2="SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU"
