@@ -57,9 +57,9 @@ struct Tuning {
     bool serialClasses;              // MSDFHIP_SERIAL_CLASSES      glyph classes one after the other instead of on side streams
     int querySlotCap, queryLpcContours;   // MSDFHIP_QUERY_LDS      "slotCap,lpcMaxContours"
     bool hasQueryLds;
-    bool hasQueryPolicy;             // MSDFHIP_QUERY_POLICY        "edgeCost,maxEdges,minCount,wideMaxEdges,wideLoad"
+    bool hasQueryPolicy;             // MSDFHIP_QUERY_POLICY        "edgeCost,maxEdges,minCount,wideMaxEdges,wideLoad[,wideMeanCount]"
     int qpEdgeCost, qpMaxEdges, qpMinCount, qpWideMaxEdges;
-    float qpWideLoad;
+    float qpWideLoad, qpWideMeanCount;
     size_t signCap;                  // MSDFHIP_SIGN_CAP            row-list capacity of the sign pass
     bool pipelineUniform;            // MSDFHIP_PIPELINE_UNIFORM    equal pipeline chunks (no half chunks at the ends)
     char pipelineLengths[128];       // MSDFHIP_PIPELINE_LENGTHS    experiment: explicit chunk lengths "512,1024,..." (the last one repeats)
@@ -92,10 +92,10 @@ void readTuning() {
     t.hasQueryLds = (env = getenv("MSDFHIP_QUERY_LDS")) != NULL;
     if (env)
         sscanf(env, "%d,%d", &t.querySlotCap, &t.queryLpcContours);
-    t.qpEdgeCost = 150, t.qpMaxEdges = 48, t.qpMinCount = 0x7fffffff, t.qpWideMaxEdges = 128, t.qpWideLoad = 4e8f;
+    t.qpEdgeCost = 150, t.qpMaxEdges = 48, t.qpMinCount = 0x7fffffff, t.qpWideMaxEdges = 128, t.qpWideLoad = 4e8f, t.qpWideMeanCount = 24.f;
     t.hasQueryPolicy = (env = getenv("MSDFHIP_QUERY_POLICY")) != NULL;
     if (env)
-        sscanf(env, "%d,%d,%d,%d,%f", &t.qpEdgeCost, &t.qpMaxEdges, &t.qpMinCount, &t.qpWideMaxEdges, &t.qpWideLoad);
+        sscanf(env, "%d,%d,%d,%d,%f,%f", &t.qpEdgeCost, &t.qpMaxEdges, &t.qpMinCount, &t.qpWideMaxEdges, &t.qpWideLoad, &t.qpWideMeanCount);
     t.signCap = (env = getenv("MSDFHIP_SIGN_CAP")) ? (size_t) atol(env) : (size_t) 192;
     t.pipelineUniform = getenv("MSDFHIP_PIPELINE_UNIFORM") != NULL;
     t.pipelineTrace = getenv("MSDFHIP_PIPELINE_TRACE") != NULL;
@@ -856,7 +856,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     // relative to a cooperative round re-swept (340 / 200 / 120 / 60): 1.80 / 1.78 / 1.79 / 1.78 ms on the DejaVu set, 1.57 / 1.51 / 1.50 / 1.52 on
     // Basic-Latin -- 150 (profiles/r03_ab_notes.md).
     lpcMaxContours.lpcEdgeCost = tuning().qpEdgeCost, lpcMaxContours.lpcMaxEdges = tuning().qpMaxEdges, lpcMaxContours.lpcMinCount = tuning().qpMinCount;   // 150, 48, never
-    lpcMaxContours.wideMaxEdges = tuning().qpWideMaxEdges, lpcMaxContours.wideLoad = tuning().qpWideLoad;                                                   // 128, 4e8 (MSDFHIP_QUERY_POLICY)
+    lpcMaxContours.wideMaxEdges = tuning().qpWideMaxEdges, lpcMaxContours.wideLoad = tuning().qpWideLoad, lpcMaxContours.wideMeanCount = tuning().qpWideMeanCount;                                                   // 128, 4e8 (MSDFHIP_QUERY_POLICY)
     const size_t resLanes = OVERLAP ? (size_t) (lpcMaxContours.lpcMaxContours > 0 ? lpcMaxContours.lpcMaxContours : 1)*WAVE*sizeof(double) : 0;
     const int slotOffset = OVERLAP ? (b->maxContours > 0 ? b->maxContours : 1) : 0;
     const int mergedCap = b->maxContours < slotCap ? (b->maxContours > 0 ? b->maxContours : 1) : slotCap;   // per-contour merged states of a glyph that uses the slots

@@ -1179,7 +1179,7 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
 //   lane per candidate 64 candidates at a time, every lane walks all edges (uniform control flow, scalar record loads -- the loop of
 //                      k_distance): cost per chunk ~ 340*nE + 1000, whatever the number of live lanes.
 // The first wins for the usual handful of candidates, the second for many (an icon with 186, a 1024x1024 logo with thousands).
-struct EcQueryPolicy { int lpcMaxContours, lpcEdgeCost, lpcMaxEdges, lpcMinCount, wideMaxEdges; float wideLoad; };
+struct EcQueryPolicy { int lpcMaxContours, lpcEdgeCost, lpcMaxEdges, lpcMinCount, wideMaxEdges; float wideLoad, wideMeanCount; };
 MSDF_HD bool ecQueryLanePerCandidate(unsigned count, int nE, int C, EcQueryPolicy q) {
     if (C > q.lpcMaxContours)                                        // its [contour][lane] scratch would not fit the LDS the launch reserved
         return false;
@@ -1215,11 +1215,11 @@ k_ec_scan(int nGlyphs, const unsigned *__restrict__ header, unsigned seg, int *_
     // Sixteen wavefronts: sums and prefix sums run inside a wavefront with lane shuffles and meet once per step in LDS (the first form met at
     // ~30 workgroup barriers -- a tree in LDS -- and took 47 us of a 1.8 ms correction pass).
     __shared__ int waveTotals[2][16];
-    __shared__ float waveLoad[16];
+    __shared__ float waveLoad[16], waveCount[16];
     enum { PER = 8 };                                               // positions per thread and round: their loads are issued together
     const int t = threadIdx.x, lane = t&(WAVE-1), wave = t/WAVE;
     const int *sizes = offsets+ecSizesAt(nGlyphs);
-    float mine = 0;
+    float mine = 0, mineCount = 0;
     for (int base = 0; base < nGlyphs; base += 1024*PER) {
         unsigned count[PER];
         int nE[PER];
@@ -1232,17 +1232,21 @@ k_ec_scan(int nGlyphs, const unsigned *__restrict__ header, unsigned seg, int *_
         MSDF_UNROLL
         for (int k = 0; k < PER; ++k)
             if (count[k] <= seg)
-                mine += (float) count[k]*(340.f*((nE[k]+WAVE-1)/WAVE)+10.f*nE[k]+1000.f);
+                mine += (float) count[k]*(340.f*((nE[k]+WAVE-1)/WAVE)+10.f*nE[k]+1000.f), mineCount += (float) count[k];
     }
     for (int off = WAVE/2; off > 0; off >>= 1)
-        mine += __shfl_down(mine, off);
+        mine += __shfl_down(mine, off), mineCount += __shfl_down(mineCount, off);
     if (lane == 0)
-        waveLoad[wave] = mine;
+        waveLoad[wave] = mine, waveCount[wave] = mineCount;
     __syncthreads();
-    float total = 0;
+    float total = 0, totalCount = 0;
     for (int w = 0; w < 16; ++w)
-        total += waveLoad[w];                                       // (the same sum in every thread; it only picks a policy, no result depends on it)
-    if (total > lpcMaxContours.wideLoad && lpcMaxContours.wideMaxEdges > lpcMaxContours.lpcMaxEdges)
+        total += waveLoad[w], totalCount += waveCount[w];           // (the same sums in every thread; they only pick a policy, no result depends on them)
+    // ... or when the launch's glyphs have MANY candidates each (round 4): a chunk of a glyph with ~50 candidates fills its lanes whatever the size of
+    // the launch -- a 1 024-glyph shard of the CJK-like set (load 9e7, like ALL of the DejaVu set with its 7 candidates per glyph) was left with
+    // the cooperative form: config-4 shards 8.29 -> 7.13 ms (2-way), 4.39 -> 3.94 (4-way), 2.45 -> 2.32 (8-way)
+    const bool dense = lpcMaxContours.wideMeanCount > 0 && totalCount >= lpcMaxContours.wideMeanCount*(float) nGlyphs;
+    if ((total > lpcMaxContours.wideLoad || dense) && lpcMaxContours.wideMaxEdges > lpcMaxContours.lpcMaxEdges)
         lpcMaxContours.lpcMaxEdges = lpcMaxContours.wideMaxEdges;
     int *coop = offsets+nGlyphs+1;
     int carry[2] = { 0, 0 };                                        // items of the earlier rounds (batches of more than 8 192 glyphs)
