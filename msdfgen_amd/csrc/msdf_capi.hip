@@ -71,6 +71,8 @@ struct Tuning {
     bool noArgPayloadSingle;         // MSDFHIP_NO_ARG_PAYLOAD_SINGLE k_single_call reads small shapes from the staging area instead of its kernel arguments (A/B)
     bool noZeroCopySingle;           // MSDFHIP_NO_ZERO_COPY_SINGLE k_single_call on uploaded inputs / device outputs + one copy back (A/B)
     bool noFusedSingle;              // MSDFHIP_NO_FUSED_SINGLE     single-shape calls through the batched launch sequence instead of k_single_call (A/B)
+    double shareGridFactor;          // MSDFHIP_SHARE_GRID          the global-scratch class's persistent grid = its share of the batch's cost x this factor of the slots (0: off)
+    long persistentGrid;             // MSDFHIP_PERSISTENT_GRID     workgroups of a persistent global-scratch launch (0: one per resident wavefront slot)
     long shortRounds;                // MSDFHIP_SHORT_ROUNDS        LDS-class launches of fewer rounds of four-tile wavefronts take one tile per wavefront
     long smallLaunchTiles;           // MSDFHIP_SMALL_LAUNCH_TILES  launches of at most this many tiles take one tile per wavefront (latency-shaped form)
     char devices[256];               // MSDFHIP_DEVICES             "all" | "0,1,..." devices the single-shape front door spreads over
@@ -113,6 +115,8 @@ void readTuning() {
     t.noZeroCopySingle = getenv("MSDFHIP_NO_ZERO_COPY_SINGLE") != NULL;
     t.noArgPayloadSingle = getenv("MSDFHIP_NO_ARG_PAYLOAD_SINGLE") != NULL;
     t.shortRounds = (env = getenv("MSDFHIP_SHORT_ROUNDS")) ? atol(env) : 4;
+    t.persistentGrid = (env = getenv("MSDFHIP_PERSISTENT_GRID")) ? atol(env) : 0;
+    t.shareGridFactor = (env = getenv("MSDFHIP_SHARE_GRID")) ? atof(env) : 1.0;
     t.smallLaunchTiles = (env = getenv("MSDFHIP_SMALL_LAUNCH_TILES")) ? atol(env) : 8192;
     if ((env = getenv("MSDFHIP_DEVICES")))
         snprintf(t.devices, sizeof(t.devices), "%s", env);
@@ -264,6 +268,7 @@ struct MsdfHipBatch {
     mutable bool bucketExternal;      // dBucket / hBucket belong to someone else (the single-shape calls carve them from their arena)
     mutable bool bucketUploaded;
     mutable int nOne, nSmall, smallMaxC, smallMaxE, oneMaxE;
+    mutable float restShare;          // the global-scratch class's share of the batch's modelled cost (glyphCost): sizes its persistent launch
     bool serialClasses;               // launch the glyph classes one after the other on the caller's stream (host-output pipeline: its chunks overlap instead)
     unsigned *overflowOut;            // single-shape host calls: where k_ec_query mirrors the candidate-overflow count (then no k_ec_slow launch)
     mutable bool overflowMirrored;    // set by the correction launch when it did so
@@ -277,7 +282,7 @@ struct MsdfHipBatch {
     MsdfHipBatch() : device(0), nGlyphs(0), nContours(0), nEdges(0), maxContours(0), maxEdges(0), ownsInputs(false), dGlyphContourOffsets(NULL),
                      dContourOffsets(NULL), dPoints(NULL), dTypes(NULL), dColors(NULL), dRecs(NULL), dWindings(NULL), dScratch(NULL), scratchFloats(0),
                      dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
-                     smallMaxC(0), smallMaxE(0), oneMaxE(0), serialClasses(false), overflowOut(NULL), overflowMirrored(false), hEcOrder(NULL), ecOrderReady(NULL), dEcOrder(NULL), ecOrderTried(false), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
+                     smallMaxC(0), smallMaxE(0), oneMaxE(0), restShare(1.f), serialClasses(false), overflowOut(NULL), overflowMirrored(false), hEcOrder(NULL), ecOrderReady(NULL), dEcOrder(NULL), ecOrderTried(false), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
 };
 
 namespace {
@@ -388,7 +393,7 @@ void launchDistanceKernel(unsigned grid, size_t lds, hipStream_t stream, const D
 
 template <int SEL, bool OVERLAP, bool GRES, int TPW_ = (GRES ? 1 : (int) QUAD)>
 int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, const LdsPlan &plan, hipStream_t stream,
-                   const int *dGlyphMap = NULL, int nMapped = 0) {
+                   const int *dGlyphMap = NULL, int nMapped = 0, size_t shareGrid = 0) {
     const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE, tiles = tilesX*tilesY;
     const int nG = dGlyphMap ? nMapped : b->nGlyphs;
     if (nG == 0)
@@ -416,8 +421,15 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
         // (Only for launches of many rounds: a persistent workgroup never yields its slot, so next to the other glyph classes' launches
         // it freezes the split of the device between them -- measured 2 % slower than the direct mapping at 5 rounds, 12 % faster at 96.)
         const size_t minRounds = (size_t) tuning().persistentRounds;   // 8; MSDFHIP_PERSISTENT_ROUNDS, 0 = never
-        if (minRounds && blocks >= minRounds*slots && blocks < 0xffffffffull-8u*slots) {
-            chunk = slots;
+        // shareGrid (round 4): a class that is a small share of a batch's work runs persistent on that share of the slots -- the launch is no
+        // longer (the other classes fill the device, it finishes inside the pass either way: 3.74 vs 3.77 ms) and its few workspace slices, rewritten by
+        // one tile after the other, stay in the L2s instead of being written once per tile: HBM bytes of the pass 922 -> 634 MB on the bench workload
+        // (2.2x -> 1.5x algorithmic; tools/persistent_grid_traffic.sh)
+        const bool byShare = shareGrid > 0 && shareGrid < slots && blocks > shareGrid;
+        if (((minRounds && blocks >= minRounds*slots) || byShare) && blocks < 0xffffffffull-8u*slots) {
+            chunk = byShare ? shareGrid : slots;
+            if (tuning().persistentGrid > 0 && (size_t) tuning().persistentGrid < chunk)
+                chunk = (size_t) tuning().persistentGrid;            // (A/B: a fixed grid)
             rc = ensureGres(b, chunk*plan.resBytes+8*sizeof(unsigned), &gres);
             if (rc != MSDFHIP_OK)
                 return rc;
@@ -455,6 +467,15 @@ int uploadSmall(void *dst, const void *srcPinned, size_t bytes, hipStream_t stre
     hipLaunchKernelGGL(k_upload_words, dim3(blocks ? blocks : 1), dim3(256), 0, stream, reinterpret_cast<uint32_t *>(dst), reinterpret_cast<const uint32_t *>(srcPinned), words);
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
+}
+
+// Cost of one glyph in microseconds at 64x64 (only the ratios matter): a + b*E + c*C + d*E*C per kernel class, fitted to measured kernel
+// times (tools/fit_cost_model.py, profiles/r03_cost_model.json; the same table as msdfgen_amd/shard.py: COST_MODEL).
+static double glyphCost(int contours, int edges) {
+    static const double kOne[4] = { 0.27680, 0.01348, 0.00000, 0.00000 }, kLds[4] = { 0.44322, 0.00935, -0.01895, 0.00420 }, kGlobal[4] = { 2.33907, 0.02717, -0.18818, 0.00156 };
+    const double *k = contours <= 1 ? kOne : (contours <= COST_LDS_MAX_CONTOURS && edges <= SMALL_MAX_EDGES) ? kLds : kGlobal;
+    const double c = k[0]+k[1]*edges+k[2]*contours+k[3]*(double) edges*contours;
+    return c > k[0] ? c : k[0];                                  // never below the class's intercept (the fit's negative contour terms are local to the measured range)
 }
 
 // Glyph indices sorted into three classes of the overlapping combiner; cached per limit:
@@ -517,6 +538,14 @@ int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
             return rcUp;
     }
     b->bucketUploaded = true;
+    {
+        double all = 0, rest = 0;
+        for (int g = 0; g < b->nGlyphs; ++g)
+            all += glyphCost(b->hContours[g], b->hEdges[g]);
+        for (int k = nOne+nSmall; k < at; ++k)
+            rest += glyphCost(b->hContours[order[k]], b->hEdges[order[k]]);
+        b->restShare = all > 0 ? (float) (rest/all) : 1.f;
+    }
     b->bucketLimit = limit, b->nOne = nOne, b->nSmall = nSmall, b->smallMaxC = smallMaxC, b->smallMaxE = smallMaxE, b->oneMaxE = oneMaxE;
     return MSDFHIP_OK;
 }
@@ -717,7 +746,13 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
         LdsPlan rest = plan;                                     // sized for the batch's largest glyph
         rest.globalRes = true;
         rest.bytes = tileListBytes(b->maxEdges, b->maxContours, true);
-        rc = launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, rest, sRest, b->dBucket+b->nOne+b->nSmall, nRest);
+        size_t shareGrid = 0;
+        if (tuning().shareGridFactor > 0 && concurrent) {
+            const size_t slots = (size_t) residentSlots(b->device)*4u*MSDF_DISTANCE_WAVES_PER_SIMD;
+            shareGrid = (size_t) ((double) slots*b->restShare*tuning().shareGridFactor);
+            shareGrid = shareGrid < 256 ? 256 : shareGrid;
+        }
+        rc = launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, rest, sRest, b->dBucket+b->nOne+b->nSmall, nRest, shareGrid);
     }
     if (rc == MSDFHIP_OK && b->nSmall > 0) {
         // A launch of few rounds of wavefronts (a shard of an atlas: BASELINE config 4 over 8 GPUs leaves 1 024 glyphs per device) ends when its
@@ -2010,15 +2045,6 @@ int msdfhip_host_free(void *p) {
 // glyphs are independent, so a glyph list is cut into contiguous ranges of equal modelled cost (glyphCost), one range per device, one
 // host thread + its own streams per device, no exchange between devices; every device copies its tiles straight into the caller's
 // buffer. The bytes do not depend on the split.
-
-// Cost of one glyph in microseconds at 64x64 (only the ratios matter): a + b*E + c*C + d*E*C per kernel class, fitted to measured kernel
-// times (tools/fit_cost_model.py, profiles/r03_cost_model.json; the same table as msdfgen_amd/shard.py: COST_MODEL).
-static double glyphCost(int contours, int edges) {
-    static const double kOne[4] = { 0.27680, 0.01348, 0.00000, 0.00000 }, kLds[4] = { 0.44322, 0.00935, -0.01895, 0.00420 }, kGlobal[4] = { 2.33907, 0.02717, -0.18818, 0.00156 };
-    const double *k = contours <= 1 ? kOne : (contours <= COST_LDS_MAX_CONTOURS && edges <= SMALL_MAX_EDGES) ? kLds : kGlobal;
-    const double c = k[0]+k[1]*edges+k[2]*contours+k[3]*(double) edges*contours;
-    return c > k[0] ? c : k[0];                                  // never below the class's intercept (the fit's negative contour terms are local to the measured range)
-}
 
 static void shardRanges(const int32_t *gco, const int32_t *co, int nGlyphs, int parts, std::vector<int> &bounds) {
     bounds.assign((size_t) parts+1, nGlyphs);

@@ -330,7 +330,8 @@ def test_scheduling_knobs_do_not_change_a_byte():
     want = render()
     knobs = [{"MSDFHIP_NO_CLASS_SORT": "1"}, {"MSDFHIP_QUERY_BATCH": "5"}, {"MSDFHIP_QUERY_POLICY": "150,0,2147483647,0,4e8"},
              {"MSDFHIP_QUERY_POLICY": "1,128,0,128,0"}, {"MSDFHIP_QUERY_LDS": "700,30"}, {"MSDFHIP_QUERY_LDS": "16,2"}, {"MSDFHIP_SERIAL_CLASSES": "1"}, {"MSDFHIP_SIDE_PRIORITY": "none"},
-             {"MSDFHIP_SIDE_PRIORITY": "high"}, {"MSDFHIP_SHORT_ROUNDS": "0"}, {"MSDFHIP_SHORT_ROUNDS": "100000"}]   # (last two: four tiles / one tile per wavefront in every class launch)
+             {"MSDFHIP_SIDE_PRIORITY": "high"}, {"MSDFHIP_SHORT_ROUNDS": "0"}, {"MSDFHIP_SHORT_ROUNDS": "100000"}, {"MSDFHIP_SHARE_GRID": "0"}, {"MSDFHIP_SHARE_GRID": "3"},
+             {"MSDFHIP_PERSISTENT_ROUNDS": "1", "MSDFHIP_PERSISTENT_GRID": "300"}]   # (last two: four tiles / one tile per wavefront in every class launch)
     for env in knobs:
         os.environ.update(env)
         M.load().msdfhip_reload_tuning()
