@@ -54,8 +54,10 @@ def main():
     per_kernel = {name.split("(")[0].replace("void msdfhip::", ""): round(t/nsteps/1e6, 4) for name, t, _ in rows if t/nsteps > 2000}
     rep = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_bench.json" % tag)))["kernels"]
     dk = {k: v for k, v in rep.items() if like in k}
-    total_ms = sum(v["ms_alone"] for v in dk.values())
-    busy_w = sum(v["valu_busy_frac_calibrated"]*v["ms_alone"] for v in dk.values())/total_ms
+    # VALU busy of the PASS: every class kernel's busy SIMD time (busy fraction x its duration alone, from the serialized counter passes) over the duration
+    # of the pass with the launches concurrent. (Round 3 weighted the per-kernel fractions by their durations alone; since round 4 the global-scratch
+    # class runs as a small persistent grid that is slow BY DESIGN when profiled alone, which that average would count as an idle device.)
+    busy_w = sum(v["valu_busy_frac_calibrated"]*v["ms_alone"] for v in dk.values())/(dist_ns/1e6)
     from msdfgen_amd.build import source_hash
     # fp64 operations the distance kernels actually EXECUTED per step (PMC class counts x 64 lanes, FMA = 2; masked-off lanes included, so an
     # upper bound of the useful ones) over the pass's duration with the three launches concurrent: the achieved fp64 rate, not an estimate
@@ -75,8 +77,8 @@ def main():
            "valu_busy_per_kernel": {k: {"ms_alone": v["ms_alone"], "busy": v["valu_busy_frac_calibrated"], "wait_any": v["wait_any_over_wave_cycles"],
                                         "scalar_cache_miss_rate": v["scalar_cache_miss_rate"], "shader_clock_ghz": v["shader_clock_ghz"]} for k, v in dk.items()},
            "valu_busy_note": "sum over instruction classes of (PMC count x cycles per wave64 instruction measured with tools/valu_calib.hip) / (1024 SIMDs x kernel time x "
-                             "shader clock from GRBM_GUI_ACTIVE); each kernel alone on the device (rocprofv3 serialises kernels under --pmc), time-weighted over the "
-                             "three class kernels; commit %s. Replaces round 2's flat 4 cycles per instruction at 2.4 GHz." % commit}
+                             "shader clock from GRBM_GUI_ACTIVE); per kernel: each alone on the device (rocprofv3 serialises kernels under --pmc); for the pass: the class kernels' busy "
+                             "SIMD time over the pass's duration with the launches concurrent; commit %s." % commit}
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out)[:1500])
 
