@@ -2172,7 +2172,9 @@ struct ArenaLease {
             delete fresh;
             return fail(MSDFHIP_ERR_HIP, "hipStreamCreate failed");
         }
-        if (hipMalloc((void **) &fresh->barrier, 256) != hipSuccess || hipMemset(fresh->barrier, 0, 256) != hipSuccess) {
+        // (zeroed ON THE ARENA'S STREAM: hipMemset runs on the legacy default stream, which a non-blocking stream does not wait for -- the first
+        // k_single_call of a fresh arena could start before it and have its counters zeroed under it; found by the TSan run of tests/sanitize)
+        if (hipMalloc((void **) &fresh->barrier, 256) != hipSuccess || hipMemsetAsync(fresh->barrier, 0, 256, fresh->stream) != hipSuccess) {
             (void) hipGetLastError();
             if (fresh->barrier)
                 hipFree(fresh->barrier);
@@ -2555,8 +2557,13 @@ static int runGroup(ShapeCall *const *calls, int n) {
                 while (hostStatus[2] != sa.doneValue && nowNs() < deadline) { }
                 if (hostStatus[2] != sa.doneValue) {
                     HIPCHK(hipStreamSynchronize(a.stream));
-                    if (hostStatus[2] != sa.doneValue)
-                        return fail(MSDFHIP_ERR_HIP, "k_single_call ended without raising its completion flag");
+                    if (hostStatus[2] != sa.doneValue) {
+                        unsigned counters[32] = { 0 };
+                        (void) hipMemcpy(counters, a.barrier, sizeof(counters), hipMemcpyDeviceToHost);
+                        return fail(MSDFHIP_ERR_HIP, "k_single_call ended without raising its completion flag (flag %u, expected %u; status %u %u; finished-workgroup counter %u, "
+                                    "expected %u + %u; barrier counter %u, base %u)", (unsigned) hostStatus[2], sa.doneValue, (unsigned) hostStatus[0], (unsigned) hostStatus[1],
+                                    counters[16], sa.doneBase, groups, counters[0], sa.barrierBase);
+                    }
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);
                 lease.quiescent = true;
@@ -2568,7 +2575,7 @@ static int runGroup(ShapeCall *const *calls, int n) {
                 // workgroups gave up at a barrier: the counters no longer match the epochs kept here -- start over from fresh ones
                 lease.quiescent = false;
                 HIPCHK(hipStreamSynchronize(a.stream));
-                HIPCHK(hipMemset(a.barrier, 0, 256));
+                HIPCHK(hipMemsetAsync(a.barrier, 0, 256, a.stream));
                 a.barrierEpoch = a.doneCount = 0;
                 return fail(MSDFHIP_ERR_HIP, "k_single_call: a grid barrier timed out (workgroups of one launch not co-resident?)");
             }

@@ -198,13 +198,15 @@ int main(int argc, char **argv) {
                         local[k] = s.co[c0+k]-e0;
                     const int rc = msdfhip_generate(MSDFHIP_MODE_MSDF, px.data(), W, W, W*N, 0, local.data(), nC, &s.points[8*(size_t) e0], &s.types[e0], &s.colors[e0],
                                                     &s.xf[6*(size_t) g], &cfg, NULL);
-                    if (rc != MSDFHIP_OK)
-                        ++errors;
-                    else if (memcmp(px.data(), want.data()+g*tile, sizeof(float)*tile) != 0)
+                    if (rc != MSDFHIP_OK) {
+                        if (++errors == 1)
+                            fprintf(stderr, "4b: msdfhip_generate -> %d: %s\n", rc, msdfhip_last_error());
+                    } else if (memcmp(px.data(), want.data()+g*tile, sizeof(float)*tile) != 0)
                         ++mismatches;
                     if (i%5 == 0) {                                          // a shapeless pass on the fresh tile: must not fail, must stay finite
-                        if (msdfhip_error_correction_shapeless(N, px.data(), W, W, W*N, &s.xf[6*(size_t) g], 1.11111111111111111, i&1) != MSDFHIP_OK)
-                            ++errors;
+                        const int rc2 = msdfhip_error_correction_shapeless(N, px.data(), W, W, W*N, &s.xf[6*(size_t) g], 1.11111111111111111, i&1);
+                        if (rc2 != MSDFHIP_OK && ++errors == 1)
+                            fprintf(stderr, "4b: msdfhip_error_correction_shapeless -> %d: %s\n", rc2, msdfhip_last_error());
                     }
                 }
             });
