@@ -1304,7 +1304,10 @@ int msdfhip_batch_create_prepared(MsdfHipBatch **batch, int n_glyphs, const int3
             PREP_CHK(dev.alloc((void **) &corners.minor, eNorm));
             PREP_CHK(dev.alloc((void **) &corners.color, eNorm));
         }
-        if (n_glyphs)
+        if (n_glyphs && cfg->coloring == 1)                       // edgeColoringSimple: one wavefront per glyph, lanes = edges
+            hipLaunchKernelGGL(k_prep_colour_wave, dim3((unsigned) n_glyphs), dim3(WAVE), 0, 0, norm, (const int32_t *) dGco, (const int32_t *) dCo1, (const int32_t *) dCo2,
+                               n_glyphs, crossThreshold, (const unsigned long long *) dSeeds, (unsigned long long) cfg->seed, fin);
+        else if (n_glyphs)
             hipLaunchKernelGGL(k_prep_colour, dim3((n_glyphs+63)/64), dim3(64), 0, 0, norm, (const int32_t *) dGco, (const int32_t *) dCo1, (const int32_t *) dCo2,
                                n_glyphs, crossThreshold, (const unsigned long long *) dSeeds, (unsigned long long) cfg->seed, fin, cfg->coloring == 2 ? 1 : 0, corners);
         finalCo = co2.data();

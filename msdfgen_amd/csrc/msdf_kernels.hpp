@@ -1762,6 +1762,107 @@ __global__ void k_prep_colour(EdgeArrays norm, const int32_t *gco, const int32_t
     }
 }
 
+// edgeColoringSimple with LANES = EDGES, one wavefront per glyph (round 4; the kernel above is its one-thread-per-glyph form, still used for
+// edgeColoringInkTrap and for contours beyond PREP_WAVE_MAX_EDGES). What is sequential in edge-coloring.cpp:73-141 is only the colour STATE: it
+// advances once per smooth contour, twice per teardrop, once per corner otherwise (switchColor, :53-64) -- a handful of scalar steps per contour,
+// taken by every lane alike. Everything per edge is parallel: the corner test of the junction before edge i (:76-85) reads edges i-1 and i only ->
+// one ballot per 64 edges; an edge's colour is its spline's, and its spline is the number of corners between the contour's first corner and the
+// edge, cyclically -- a prefix population count of the ballots; the teardrop's thirds are a closed form of the edge's position (:101-104).
+enum { PREP_WAVE_MAX_EDGES = 2048 };
+__global__ void __launch_bounds__(WAVE)
+k_prep_colour_wave(EdgeArrays norm, const int32_t *gco, const int32_t *co1, const int32_t *co2, int nGlyphs, double crossThreshold,
+                   const unsigned long long *seeds, unsigned long long seedAll, EdgeArrays out) {
+    __shared__ unsigned long long cornerMask[PREP_WAVE_MAX_EDGES/WAVE];
+    __shared__ unsigned char splineColor[PREP_WAVE_MAX_EDGES];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= nGlyphs)
+        return;
+    unsigned long long seed = seeds ? seeds[g] : seedAll;          // (wave-uniform state: every lane advances its own copy identically)
+    int color = initColor(seed);
+    for (int c = gco[g]; c < gco[g+1]; ++c) {
+        const int ib = co1[c], n = co1[c+1]-ib, ob = co2[c];
+        if (n == 0)
+            continue;
+        if (n > PREP_WAVE_MAX_EDGES) {                              // beyond the LDS tables: the serial form on lane 0, its state broadcast
+            if (lane == 0)
+                colourContour(norm, ib, n, out, ob, crossThreshold, color, seed);
+            color = __shfl(color, 0);
+            seed = (unsigned long long) (unsigned) __shfl((int) (unsigned) seed, 0)|(unsigned long long) (unsigned) __shfl((int) (unsigned) (seed>>32), 0)<<32;
+            continue;
+        }
+        // ---- corners: the junction before edge i
+        int nCorners = 0, first = -1;
+        for (int base = 0; base < n; base += WAVE) {
+            const int i = base+lane;
+            bool corner = false;
+            if (i < n) {
+                const PrepEdge e = loadEdge(norm, ib+i), pe = loadEdge(norm, ib+(i+n-1)%n);
+                corner = isCorner(normalize(edgeDirection(pe, 1), false), normalize(edgeDirection(e, 0), false), crossThreshold);
+            }
+            const unsigned long long mask = __ballot(corner);
+            if (lane == 0)
+                cornerMask[base/WAVE] = mask;
+            if (first < 0 && mask)
+                first = base+__ffsll((long long) mask)-1;
+            nCorners += __popcll(mask);
+        }
+        waveSync();
+        if (nCorners == 0) {                                        // smooth contour (:87-92)
+            switchColor(color, seed);
+            for (int i = lane; i < n; i += WAVE) {
+                PrepEdge e = loadEdge(norm, ib+i);
+                e.color = color;
+                storeEdge(out, ob+i, e);
+            }
+        } else if (nCorners == 1) {                                 // "teardrop" (:93-123)
+            int colors[3];
+            switchColor(color, seed);
+            colors[0] = color;
+            colors[1] = 7;
+            switchColor(color, seed);
+            colors[2] = color;
+            if (n >= 3) {
+                for (int index = lane; index < n; index += WAVE) {
+                    const int i = (index-first+n)%n;                // the edge's position counted from the corner
+                    PrepEdge e = loadEdge(norm, ib+index);
+                    e.color = colors[1+symmetricalTrichotomy(i, n)];
+                    storeEdge(out, ob+index, e);
+                }
+            } else if (lane == 0)
+                teardropSplit(norm, ib, n, out, ob, first, colors);
+        } else {                                                    // multiple corners (:124-140): one colour per spline, then lanes = edges
+            switchColor(color, seed);
+            const int initialColor = color;
+            if (lane == 0)
+                splineColor[0] = (unsigned char) color;
+            for (int spline = 1; spline < nCorners; ++spline) {
+                switchColorBanned(color, seed, (spline == nCorners-1)*initialColor);
+                if (lane == 0)
+                    splineColor[spline] = (unsigned char) color;
+            }
+            waveSync();
+            // corners among edges [0, k): full ballot words below k's, plus the low bits of k's word
+            auto cornersBelow = [&](int k) {
+                int sum = 0;
+                for (int w = 0; w < k/WAVE; ++w)
+                    sum += __popcll(cornerMask[w]);
+                if (k%WAVE)
+                    sum += __popcll(cornerMask[k/WAVE]&((1ull<<(k%WAVE))-1ull));
+                return sum;
+            };
+            const int uptoStart = cornersBelow(first+1);
+            for (int index = lane; index < n; index += WAVE) {
+                const int upto = cornersBelow(index+1);
+                const int spline = index >= first ? upto-uptoStart : nCorners-uptoStart+upto;   // corners in (first, index], cyclically
+                PrepEdge e = loadEdge(norm, ib+index);
+                e.color = splineColor[spline];
+                storeEdge(out, ob+index, e);
+            }
+        }
+        waveSync();                                                 // the LDS tables are the next contour's
+    }
+}
+
 // ------------------------------------------------------------------------------------------- 8-bit atlas output (row f2)
 
 // pixelFloatToByte (core/pixel-conversion.hpp:8-10): byte(~int(255.5f-255.f*clamp(x))), fp32 arithmetic, clamp(NaN) = 0.

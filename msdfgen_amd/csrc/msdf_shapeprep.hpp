@@ -290,6 +290,24 @@ MSDF_HD int colouredCount(const EdgeArrays &a, int b, int n, double crossThresho
     return contourCorners(a, b, n, crossThreshold, none) == 1 ? 3*n : n;
 }
 
+// A one-corner contour of fewer than three edges: every edge split in thirds, colours by thirds (edge-coloring.cpp:106-123).
+MSDF_HD void teardropSplit(const EdgeArrays &in, int ib, int n, const EdgeArrays &out, int ob, int corner, const int colors[3]) {
+    PrepEdge parts[6];
+    splitInThirds(loadEdge(in, ib), parts+3*corner);
+    if (n >= 2) {
+        splitInThirds(loadEdge(in, ib+1), parts+3-3*corner);
+        parts[0].color = parts[1].color = colors[0];
+        parts[2].color = parts[3].color = colors[1];
+        parts[4].color = parts[5].color = colors[2];
+    } else {
+        parts[0].color = colors[0];
+        parts[1].color = colors[1];
+        parts[2].color = colors[2];
+    }
+    for (int i = 0; i < 3*n; ++i)
+        storeEdge(out, ob+i, parts[i]);
+}
+
 // edgeColoringSimple of one contour (edge-coloring.cpp:73-141): input edges [ib, ib+n) of `in`, output edges from `ob` of `out`
 // (colouredCount of them). color / seed: the shape-wide running state.
 MSDF_HD void colourContour(const EdgeArrays &in, int ib, int n, const EdgeArrays &out, int ob, double crossThreshold, int &color, unsigned long long &seed) {
@@ -320,22 +338,8 @@ MSDF_HD void colourContour(const EdgeArrays &in, int ib, int n, const EdgeArrays
                 e.color = colors[1+symmetricalTrichotomy(i, n)];
                 storeEdge(out, ob+index, e);
             }
-        } else {
-            PrepEdge parts[6];
-            splitInThirds(loadEdge(in, ib), parts+3*corner);
-            if (n >= 2) {
-                splitInThirds(loadEdge(in, ib+1), parts+3-3*corner);
-                parts[0].color = parts[1].color = colors[0];
-                parts[2].color = parts[3].color = colors[1];
-                parts[4].color = parts[5].color = colors[2];
-            } else {
-                parts[0].color = colors[0];
-                parts[1].color = colors[1];
-                parts[2].color = colors[2];
-            }
-            for (int i = 0; i < 3*n; ++i)
-                storeEdge(out, ob+i, parts[i]);
-        }
+        } else
+            teardropSplit(in, ib, n, out, ob, corner, colors);
     } else {                                                                          // multiple corners
         // The reference walks from the first corner and switches colour when it reaches the next one (corners[spline+1] == index):
         // with the corners in increasing order that is "edge `index` starts at a corner other than the first", decided on the fly here.

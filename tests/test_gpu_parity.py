@@ -771,6 +771,35 @@ def test_shape_preparation_random_vs_oracle(oracle):
     gb = M.GlyphBatch.from_raw(ShapeBatch.from_shapes(shapes), True, 1, 2.5, seeds=np.array(seeds, np.uint64))
     _same_batch(gb.shapes, ShapeBatch.from_shapes(want), "random shapes, angle 2.5")
     gb.close()
+    # long contours: several 64-edge rounds of the lanes-=-edges colouring kernel (corner ballots, prefix counts across words), smooth / one-corner /
+    # many-corner alike, and one beyond its LDS tables (serial form on lane 0)
+    big, bwant, bseeds = [], [], []
+    for i, (n_edges, wobble, kinds) in enumerate([(70, .05, (2,)), (130, .6, (1, 2)), (200, .9, (1,)), (257, .3, (1, 2, 3)), (64, .5, (1, 2)), (2100, .7, (1, 2))]):
+        s = synth.random_shape(9900+i, n_contours=1+i % 2, edges_per_contour=(n_edges, n_edges), kinds=kinds, wobble=wobble)
+        s.colors[:] = 7
+        big.append(s), bseeds.append(1000+i)
+        fa = oracle.shape_prepare(s, False, 1, 3.0, 1000+i)
+        bwant.append(FlatShape(fa.contour_offsets, fa.points, fa.types, fa.colors))
+    def polygon(pts):                                                          # closed contour of line edges through pts
+        pts = np.asarray(pts, np.float64)
+        e = np.zeros((len(pts), 8))
+        e[:, 0:2], e[:, 2:4] = pts, np.roll(pts, -1, axis=0)
+        return FlatShape(np.array([0, len(pts)], np.int32), e, np.ones(len(pts), np.int32), np.full(len(pts), 7, np.int32))
+    ang = np.linspace(0, 2*np.pi, 200, endpoint=False)
+    ring = np.stack([np.cos(ang), np.sin(ang)], 1)
+    td = np.linspace(0, 2*np.pi, 301, endpoint=False)
+    drop = np.stack([np.cos(td), np.sin(td)*np.sin(td/2)], 1)                  # smooth but for the cusp at t = 0
+    for k, s in enumerate([polygon(ring),                                      # 200-gon, 1.8 degrees per vertex: smooth, no corner
+                           polygon(drop),                                      # ONE corner, 301 edges: a teardrop, coloured in thirds by position (WHITE in the middle)
+                           polygon(np.concatenate([ring[:70], [[2.5, .5]], ring[80:160], [[-.2, -2.5]]]))]):   # two apexes + the two open ends: a few long splines
+        big.append(s), bseeds.append(2000+k)
+        fa = oracle.shape_prepare(s, False, 1, 3.0, 2000+k)
+        bwant.append(FlatShape(fa.contour_offsets, fa.points, fa.types, fa.colors))
+    gb = M.GlyphBatch.from_raw(ShapeBatch.from_shapes(big), False, 1, 3.0, seeds=np.array(bseeds, np.uint64))
+    _same_batch(gb.shapes, ShapeBatch.from_shapes(bwant), "long contours")
+    nchange = [int((np.diff(np.asarray(w.colors).astype(int)) != 0).sum()) for w in bwant]
+    assert max(nchange) >= 20 and nchange[-3] == 0 and nchange[-2] == 2 and 7 in np.asarray(bwant[-2].colors) and 2 <= nchange[-1] <= 8, nchange   # many-corner, smooth, teardrop and few-spline contours were in it
+    gb.close()
     gb = M.GlyphBatch.from_raw(ShapeBatch.from_shapes(shapes[:50]), False, 1, 3.0, seed=77)    # one seed for all, colouring only
     want = [oracle.shape_prepare(s, False, 1, 3.0, 77) for s in shapes[:50]]
     _same_batch(gb.shapes, ShapeBatch.from_shapes([FlatShape(f.contour_offsets, f.points, f.types, f.colors) for f in want]), "colouring only")
