@@ -24,7 +24,7 @@
 // the records written in the digest with hand-placed SCALAR loads, which the compiler's memory model does not cover (it never emits scalar loads of
 // memory the kernel itself writes): the scalar data cache is invalidated explicitly after the digest and after the barrier. The counters are
 // never reset -- each call waits for values above the ones the previous call on the same arena left behind (barrierBase / doneBase).
-// Measured (profiles/r04_host_calls.jsonl): 128 -> 83 us per 64x64 generateMSDF from one host thread, 68 us of it inside the launch
+// Measured (profiles/r04_host_calls.jsonl): 127-135 -> 82-88 us per 64x64 generateMSDF from one host thread, 68-75 us of it inside the launch
 // (digest 8, slowest tile's distance field 33, barrier + slowest sweep 25).
 #pragma once
 
