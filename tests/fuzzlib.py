@@ -7,8 +7,9 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 
-def run(n_shapes, seed, deadline_s=None):
-    """Returns a dict: shapes, groups, values_compared, values_differing_bitwise, max_abs_delta, worst_case, seed."""
+def run(n_shapes, seed, deadline_s=None, single=False):
+    """Returns a dict: shapes, groups, values_compared, values_differing_bitwise, max_abs_delta, worst_case, seed.
+    single: every shape through its own generate*() call (the literal drop-in: one fused launch per call, msdf_single.hpp) instead of one batch per group."""
     import time
     import msdfgen_amd as M
     from msdfgen_amd import synth
@@ -53,9 +54,13 @@ def run(n_shapes, seed, deadline_s=None):
             xfs[:, 4] *= .5
         batch = ShapeBatch.from_shapes(shapes)
         cfg = M.MSDFGeneratorConfig(overlap, M.ErrorCorrectionConfig(ec_mode, ec_dist)) if mode >= 3 else M.GeneratorConfig(overlap)
-        gb = M.GlyphBatch(batch)
-        got = gb.generate(mode, w, h, xfs, config=cfg).cpu().numpy()
-        gb.close()
+        if single:
+            fn = {1: M.generate_sdf, 2: M.generate_psdf, 3: M.generate_msdf, 4: M.generate_mtsdf}[mode]
+            got = np.stack([fn(np.zeros((h, w, M.CHANNELS[mode]), np.float32), shapes[g], M.SDFTransformation.from_xf(xfs[g]), cfg, M.Y_UPWARD) for g in range(n)])
+        else:
+            gb = M.GlyphBatch(batch)
+            got = gb.generate(mode, w, h, xfs, config=cfg).cpu().numpy()
+            gb.close()
         want = list(pool.map(lambda g: orc.generate(shapes[g], mode, w, h, xfs[g], overlap=overlap, ec_mode=ec_mode, ec_dist=ec_dist), range(n)))
         want = np.stack(want)
         bad = got.view(np.uint32) != want.view(np.uint32)
@@ -75,4 +80,4 @@ def run(n_shapes, seed, deadline_s=None):
         groups += 1
     pool.shutdown()
     return {"shapes": done, "groups": groups, "values_compared": total, "values_differing_bitwise": differing, "max_abs_delta": worst,
-            "worst_case": worst_case, "seed": seed, "distinct_mode_combiner_ec_kind": len(seen), "seconds": round(time.time()-t0, 1)}
+            "worst_case": worst_case, "seed": seed, "single_calls": bool(single), "distinct_mode_combiner_ec_kind": len(seen), "seconds": round(time.time()-t0, 1)}

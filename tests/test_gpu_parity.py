@@ -205,6 +205,14 @@ def test_fuzz_sweep_vs_oracle():
     assert r["values_differing_bitwise"] <= r["values_compared"]*1e-6, r   # bit-identical in practice; a last-ulp libm difference may flip a handful
 
 
+def test_fuzz_sweep_single_calls_vs_oracle():
+    """The same generator, every shape through its own generate*() call: the fused one-launch path (msdf_single.hpp) incl. its fall-backs."""
+    import fuzzlib
+    r = fuzzlib.run(1500, 411, deadline_s=60, single=True)
+    print(r)
+    assert r["shapes"] >= 300 and r["max_abs_delta"] <= TOL and r["values_differing_bitwise"] <= r["values_compared"]*1e-6, r
+
+
 def test_degenerate_and_empty_inputs(oracle):
     empty = FlatShape(np.zeros(1, np.int32), np.zeros((0, 8)), np.zeros(0, np.int32), np.zeros(0, np.int32))
     xf = np.array([10., 10., .1, .1, -.2, .2])

@@ -18,9 +18,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", type=int, default=1500)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--single", action="store_true", help="every shape through its own generate*() call (the fused single-call launch) instead of batches")
     args = ap.parse_args()
     import fuzzlib
-    r = fuzzlib.run(args.shapes, args.seed)
+    r = fuzzlib.run(args.shapes, args.seed, single=args.single)
     print(json.dumps(r))
     sys.exit(1 if r["max_abs_delta"] > 1e-5 else 0)
 
