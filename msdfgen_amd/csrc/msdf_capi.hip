@@ -268,6 +268,7 @@ struct MsdfHipBatch {
     mutable bool bucketExternal;      // dBucket / hBucket belong to someone else (the single-shape calls carve them from their arena)
     mutable bool bucketUploaded;
     mutable int nOne, nSmall, smallMaxC, smallMaxE, oneMaxE;
+    mutable int nHuge, restMaxC, restMaxE;   // glyphs whose survivor lists exceed a CU's LDS (list-free kernel, last in dBucket); maxima of the class before them
     mutable float restShare;          // the global-scratch class's share of the batch's modelled cost (glyphCost): sizes its persistent launch
     bool serialClasses;               // launch the glyph classes one after the other on the caller's stream (host-output pipeline: its chunks overlap instead)
     unsigned *overflowOut;            // single-shape host calls: where k_ec_query mirrors the candidate-overflow count (then no k_ec_slow launch)
@@ -282,7 +283,7 @@ struct MsdfHipBatch {
     MsdfHipBatch() : device(0), nGlyphs(0), nContours(0), nEdges(0), maxContours(0), maxEdges(0), ownsInputs(false), dGlyphContourOffsets(NULL),
                      dContourOffsets(NULL), dPoints(NULL), dTypes(NULL), dColors(NULL), dRecs(NULL), dWindings(NULL), dScratch(NULL), scratchFloats(0),
                      dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
-                     smallMaxC(0), smallMaxE(0), oneMaxE(0), restShare(1.f), serialClasses(false), overflowOut(NULL), overflowMirrored(false), hEcOrder(NULL), ecOrderReady(NULL), dEcOrder(NULL), ecOrderTried(false), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
+                     smallMaxC(0), smallMaxE(0), oneMaxE(0), nHuge(0), restMaxC(0), restMaxE(0), restShare(1.f), serialClasses(false), overflowOut(NULL), overflowMirrored(false), hEcOrder(NULL), ecOrderReady(NULL), dEcOrder(NULL), ecOrderTried(false), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
 };
 
 namespace {
@@ -506,22 +507,33 @@ int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
     if (b->bucketUploaded)                                       // an earlier upload from hBucket (same batch, other limit) must have left it
         HIPCHK(hipStreamSynchronize(stream));
     int *order = b->hBucket;
-    int at = 0, nOne = 0, nSmall = 0, smallMaxC = 0, smallMaxE = 0, oneMaxE = 0;
+    int at = 0, nOne = 0, nSmall = 0, smallMaxC = 0, smallMaxE = 0, oneMaxE = 0, restMaxC = 0, restMaxE = 0;
+    // A glyph whose survivor lists do not fit a CU's LDS (edges + 4 contours > ~40 000) takes the list-free kernel -- ALONE: round 3 sent the whole
+    // batch there with it. Such glyphs go last in the list, whatever their contour count; the three classes are formed of the others.
+    const size_t ldsLimit = (size_t) gLdsLimit.load();
+    auto huge = [b, ldsLimit](int g) { return tileListBytes(b->hEdges[g], b->hContours[g], true) > ldsLimit; };
     for (int g = 0; g < b->nGlyphs; ++g)
-        if (b->hContours[g] <= 1) {
+        if (!huge(g) && b->hContours[g] <= 1) {
             order[at++] = g;
             oneMaxE = b->hEdges[g] > oneMaxE ? b->hEdges[g] : oneMaxE;
         }
     nOne = at;
     for (int g = 0; g < b->nGlyphs; ++g)
-        if (b->hContours[g] > 1 && b->hContours[g] <= limit && b->hEdges[g] <= SMALL_MAX_EDGES) {
+        if (!huge(g) && b->hContours[g] > 1 && b->hContours[g] <= limit && b->hEdges[g] <= SMALL_MAX_EDGES) {
             order[at++] = g;
             smallMaxC = b->hContours[g] > smallMaxC ? b->hContours[g] : smallMaxC;
             smallMaxE = b->hEdges[g] > smallMaxE ? b->hEdges[g] : smallMaxE;
         }
     nSmall = at-nOne;
     for (int g = 0; g < b->nGlyphs; ++g)
-        if (b->hContours[g] > 1 && !(b->hContours[g] <= limit && b->hEdges[g] <= SMALL_MAX_EDGES))
+        if (!huge(g) && b->hContours[g] > 1 && !(b->hContours[g] <= limit && b->hEdges[g] <= SMALL_MAX_EDGES)) {
+            order[at++] = g;
+            restMaxC = b->hContours[g] > restMaxC ? b->hContours[g] : restMaxC;
+            restMaxE = b->hEdges[g] > restMaxE ? b->hEdges[g] : restMaxE;
+        }
+    const int nCulled = at;
+    for (int g = 0; g < b->nGlyphs; ++g)
+        if (huge(g))
             order[at++] = g;
     // Heaviest glyphs first inside each class (longest-processing-time order: a launch is ~26 rounds of workgroups, its tail is the last round's
     // heaviest glyph; the output does not depend on the order -- a glyph writes its own tiles).
@@ -530,7 +542,7 @@ int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
         auto heavier = [hE, hC](int x, int y) { return (long long) hE[x]*(hC[x] > 1 ? hC[x] : 1) > (long long) hE[y]*(hC[y] > 1 ? hC[y] : 1); };
         std::stable_sort(order, order+nOne, heavier);
         std::stable_sort(order+nOne, order+nOne+nSmall, heavier);
-        std::stable_sort(order+nOne+nSmall, order+at, heavier);
+        std::stable_sort(order+nOne+nSmall, order+nCulled, heavier);
     }
     {
         const int rcUp = uploadSmall(b->dBucket, b->hBucket, sizeof(int)*(size_t) b->nGlyphs, stream);   // (hBucket is pinned)
@@ -542,11 +554,12 @@ int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
         double all = 0, rest = 0;
         for (int g = 0; g < b->nGlyphs; ++g)
             all += glyphCost(b->hContours[g], b->hEdges[g]);
-        for (int k = nOne+nSmall; k < at; ++k)
+        for (int k = nOne+nSmall; k < nCulled; ++k)
             rest += glyphCost(b->hContours[order[k]], b->hEdges[order[k]]);
         b->restShare = all > 0 ? (float) (rest/all) : 1.f;
     }
     b->bucketLimit = limit, b->nOne = nOne, b->nSmall = nSmall, b->smallMaxC = smallMaxC, b->smallMaxE = smallMaxE, b->oneMaxE = oneMaxE;
+    b->nHuge = at-nCulled, b->restMaxC = restMaxC, b->restMaxE = restMaxE;
     return MSDFHIP_OK;
 }
 
@@ -634,11 +647,12 @@ void destroySideStreams(const MsdfHipBatch *b) {
     b->forkEvent = NULL;
 }
 
-// A batch with a glyph whose survivor lists exceed a CU's LDS: every glyph of it takes the list-free kernel (see k_distance_unculled).
+// The glyphs whose survivor lists exceed a CU's LDS take the list-free kernel (see k_distance_unculled): all of the batch, or those of dGlyphMap.
 template <int SEL, bool OVERLAP>
-int launchUnculled(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, hipStream_t stream) {
+int launchUnculled(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, hipStream_t stream, const int *dGlyphMap = NULL,
+                   int nMapped = 0) {
     const int tilesX = (w+TILE-1)/TILE, tiles = tilesX*((h+TILE-1)/TILE);
-    const size_t items = (size_t) b->nGlyphs*(size_t) tiles;
+    const size_t items = (size_t) (dGlyphMap ? nMapped : b->nGlyphs)*(size_t) tiles;
     if (items == 0)
         return MSDFHIP_OK;
     if (items > 0xfffffff0ull)
@@ -657,20 +671,44 @@ int launchUnculled(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
     HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), stream));
     const BatchView v = viewOf(b);
     hipLaunchKernelGGL((k_distance_unculled<SEL, OVERLAP>), dim3((unsigned) groups), dim3(WAVE), 0, stream, v.nGlyphs, v.glyphContourOffsets, v.contourOffsets, v.recs,
-                       v.windings, dGlyphs, w, h, tilesX, tiles, dst, toScratch, gres, resBytes/sizeof(double), counter, (unsigned) items);
+                       v.windings, dGlyphs, w, h, tilesX, tiles, dst, toScratch, gres, resBytes/sizeof(double), counter, (unsigned) items, dGlyphMap);
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
 }
 
 template <int SEL>
 int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, bool overlap, hipStream_t stream) {
-    if (tileListBytes(b->maxEdges, b->maxContours, true) > (size_t) gLdsLimit.load()) {   // the reference cannot fail on a large shape; neither may this
+    // A glyph whose survivor lists exceed a CU's LDS takes the list-free kernel (the reference cannot fail on a large shape; neither may this) --
+    // alone: in a batch, the OTHER glyphs keep the culled kernels (ensureBuckets puts the oversized ones last in the class list; maxE / maxC below
+    // are the maxima of the rest). Round 3 sent the whole batch through the list-free kernel with it.
+    const bool hugeBatch = tileListBytes(b->maxEdges, b->maxContours, true) > (size_t) gLdsLimit.load();
+    if (hugeBatch && b->nGlyphs == 1) {
         ScopedTimer timer(stream, 0);
         return overlap && b->maxContours > 1 ? launchUnculled<SEL, true>(b, dGlyphs, w, h, dst, toScratch, stream)
                                              : launchUnculled<SEL, false>(b, dGlyphs, w, h, dst, toScratch, stream);
     }
+    int maxE = b->maxEdges, maxC = b->maxContours, nHuge = 0, rc = MSDFHIP_OK;
+    const size_t perContourLds = (size_t) SelTraits<SEL>::NCH*WAVE*sizeof(double);
+    int limitAll = 0;                                            // contours whose combiner scratch fits the per-wavefront LDS budget next to the lists of a SMALL_MAX_EDGES glyph
+    while ((size_t) (limitAll+1)*perContourLds+(size_t) QUAD*tileListBytes(SMALL_MAX_EDGES, limitAll+1, false) <= ldsBudget())
+        ++limitAll;
+    if (hugeBatch) {
+        rc = ensureBuckets(b, limitAll < 1 ? 1 : limitAll, stream);
+        if (rc != MSDFHIP_OK)
+            return rc;
+        nHuge = b->nHuge;
+        maxE = b->oneMaxE > b->smallMaxE ? b->oneMaxE : b->smallMaxE, maxE = b->restMaxE > maxE ? b->restMaxE : maxE;
+        maxC = b->smallMaxC > b->restMaxC ? b->smallMaxC : b->restMaxC, maxC = b->nOne > 0 && maxC < 1 ? 1 : maxC;
+        // (the lists are sized by the two maxima, which may come from different glyphs: if even those do not fit, or nothing is left, the whole batch goes list-free)
+        if (nHuge == b->nGlyphs || tileListBytes(maxE, maxC, true) > (size_t) gLdsLimit.load()) {
+            ScopedTimer timer(stream, 0);
+            return overlap && b->maxContours > 1 ? launchUnculled<SEL, true>(b, dGlyphs, w, h, dst, toScratch, stream)
+                                                 : launchUnculled<SEL, false>(b, dGlyphs, w, h, dst, toScratch, stream);
+        }
+    }
+    const int nCulled = b->nGlyphs-nHuge;
     LdsPlan plan;
-    int rc = planLds(b, SelTraits<SEL>::NCH, overlap, plan);
+    rc = planLds(b, SelTraits<SEL>::NCH, overlap, plan, maxC, maxE);
     if (rc != MSDFHIP_OK)
         return rc;
     ScopedTimer timer(stream, 0);                                // the distance pass of one generate call (one or more launches)
@@ -678,38 +716,40 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     // wavefront instead of four -- four times the wavefronts, a quarter of the serial work each -- with the combiner scratch in the
     // global workspace (single 64x64 glyph: 19 -> 8 us simple, ~100 -> ~30 us overlapping combiner).
     const int tilesAll = ((w+TILE-1)/TILE)*((h+TILE-1)/TILE);
-    const size_t gresAll = (size_t) b->nGlyphs*tilesAll*(size_t) b->maxContours*SelTraits<SEL>::NCH*WAVE*sizeof(double);
-    const bool smallLaunch = (size_t) b->nGlyphs*tilesAll <= (size_t) tuning().smallLaunchTiles && (!overlap || gresAll <= ((size_t) 64<<20));
+    const size_t gresAll = (size_t) b->nGlyphs*tilesAll*(size_t) maxC*SelTraits<SEL>::NCH*WAVE*sizeof(double);
+    const bool smallLaunch = !hugeBatch && (size_t) b->nGlyphs*tilesAll <= (size_t) tuning().smallLaunchTiles && (!overlap || gresAll <= ((size_t) 64<<20));
     LdsPlan single = plan;                                       // one tile per wavefront: one survivor list, scratch (if any) in global memory
     single.globalRes = true;
-    single.bytes = tileListBytes(b->maxEdges, b->maxContours, true);
-    single.resBytes = overlap ? (size_t) b->maxContours*SelTraits<SEL>::NCH*WAVE*sizeof(double) : 0;
-    if (!overlap || b->maxContours <= 1) {
+    single.bytes = tileListBytes(maxE, maxC, true);
+    single.resBytes = overlap ? (size_t) maxC*SelTraits<SEL>::NCH*WAVE*sizeof(double) : 0;
+    if (!overlap || maxC <= 1) {
         if (smallLaunch)
             return launchDistance<SEL, false, true>(b, dGlyphs, w, h, dst, toScratch, single, stream);
         if (overlap) {
-            rc = planLds(b, SelTraits<SEL>::NCH, false, plan);
+            rc = planLds(b, SelTraits<SEL>::NCH, false, plan, maxC, maxE);
             if (rc != MSDFHIP_OK)
                 return rc;
         }
-        return launchDistance<SEL, false, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
+        if (!hugeBatch)
+            return launchDistance<SEL, false, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
+        rc = nCulled > 0 ? launchDistance<SEL, false, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream, b->dBucket, nCulled) : MSDFHIP_OK;
+        if (rc == MSDFHIP_OK)                                    // (the oversized glyphs after the others on the same stream: they share the batch's workspace)
+            rc = overlap && b->maxContours > 1 ? launchUnculled<SEL, true>(b, dGlyphs, w, h, dst, toScratch, stream, b->dBucket+nCulled, nHuge)
+                                               : launchUnculled<SEL, false>(b, dGlyphs, w, h, dst, toScratch, stream, b->dBucket+nCulled, nHuge);
+        return rc;
     }
     if (smallLaunch && b->nGlyphs == 1)
         return launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, single, stream);
-    // how many contours' worth of combiner scratch fit the per-wavefront LDS budget next to the survivor lists of a SMALL_MAX_EDGES glyph
-    const size_t perContour = (size_t) SelTraits<SEL>::NCH*WAVE*sizeof(double);
-    int limit = 0;
-    while ((size_t) (limit+1)*perContour+(size_t) QUAD*tileListBytes(SMALL_MAX_EDGES, limit+1, false) <= plan.ldsBudget)
-        ++limit;
+    const int limit = limitAll;
     if (b->nGlyphs == 1) {                                       // the class is known, no index map
-        if (b->maxContours <= limit && b->maxEdges <= SMALL_MAX_EDGES && !plan.globalRes)
+        if (maxC <= limit && maxE <= SMALL_MAX_EDGES && !plan.globalRes)
             return launchDistance<SEL, true, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
         return launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, single, stream);
     }
     rc = ensureBuckets(b, limit < 1 ? 1 : limit, stream);
     if (rc != MSDFHIP_OK)
         return rc;
-    const int nRest = b->nGlyphs-b->nOne-b->nSmall;
+    const int nRest = nCulled-b->nOne-b->nSmall;
     if (smallLaunch) {
         if (b->nOne > 0) {
             rc = launchDistance<SEL, false, true>(b, dGlyphs, w, h, dst, toScratch, single, stream, b->dBucket, b->nOne);
@@ -745,7 +785,7 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     if (nRest > 0) {                                             // first: few, heavy glyphs -- the longest tail
         LdsPlan rest = plan;                                     // sized for the batch's largest glyph
         rest.globalRes = true;
-        rest.bytes = tileListBytes(b->maxEdges, b->maxContours, true);
+        rest.bytes = tileListBytes(maxE, maxC, true);
         size_t shareGrid = 0;
         if (tuning().shareGridFactor > 0 && concurrent) {
             const size_t slots = (size_t) residentSlots(b->device)*4u*MSDF_DISTANCE_WAVES_PER_SIMD;
@@ -798,6 +838,8 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
         if (rc == MSDFHIP_OK)
             rc = fail(MSDFHIP_ERR_HIP, "joining the glyph-class streams failed: %s", hipGetErrorString(joinError));
     }
+    if (rc == MSDFHIP_OK && nHuge > 0)                           // after the join: the list-free kernel shares the batch's workspace with the global-scratch class
+        rc = launchUnculled<SEL, true>(b, dGlyphs, w, h, dst, toScratch, stream, b->dBucket+nCulled, nHuge);
     return rc;
 }
 

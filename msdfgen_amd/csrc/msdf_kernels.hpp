@@ -1987,7 +1987,9 @@ template <int SEL, bool OVERLAP>
 __global__ void __launch_bounds__(WAVE, 2)
 k_distance_unculled(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const int32_t *__restrict__ contourOffsets, const EdgeRec *__restrict__ recs,
                     const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, int tilesX, int tilesPerGlyph,
-                    float *__restrict__ dst, int toScratch, double *__restrict__ gres, size_t gresStride, unsigned *__restrict__ counter, unsigned items) {
+                    float *__restrict__ dst, int toScratch, double *__restrict__ gres, size_t gresStride, unsigned *__restrict__ counter, unsigned items,
+                    const int *__restrict__ glyphMap) {
+    // glyphMap: the launch covers these glyphs of the batch (the oversized ones of a mixed batch: msdf_capi.hip, ensureBuckets), or NULL = all
     enum { NCH = SelTraits<SEL>::NCH };
     const int lane = threadIdx.x;
     for (;;) {
@@ -1997,7 +1999,8 @@ k_distance_unculled(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets
         item = (unsigned) __builtin_amdgcn_readfirstlane((int) item);
         if (item >= items)
             return;
-        const int g = (int) (item/(unsigned) tilesPerGlyph), tile = (int) (item%(unsigned) tilesPerGlyph);
+        const int slot = (int) (item/(unsigned) tilesPerGlyph), tile = (int) (item%(unsigned) tilesPerGlyph);
+        const int g = glyphMap ? glyphMap[slot] : slot;
         const int c0 = glyphContourOffsets[g], C = glyphContourOffsets[g+1]-c0;
         const int32_t *coff = contourOffsets+c0;
         const EdgeRec *rec = recs+coff[0];

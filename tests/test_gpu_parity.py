@@ -1049,6 +1049,17 @@ def test_shapes_beyond_the_lds_lists_are_rendered_not_refused(oracle):
     close(got[1], oracle.generate(many, 3, 24, 24, xf2), "12 000 contours in a batch")
     close(got[0], oracle.generate(small, 3, 24, 24, xf2), "ordinary glyph next to it")
     assert (bits(got[2]) == bits(got[0])).all()
+    # Only the oversized glyphs take the list-free kernel; the others of the batch keep their classes (one contour / LDS / global workspace):
+    # one glyph of each class next to TWO oversized ones, with the overlapping and with the simple combiner
+    one = FlatShape.from_contours([_ring(.5, .5, .4, 17)])
+    ten = FlatShape.from_contours([_ring(.5+.02*c, .5-.01*c, .45-.04*c, 14+c, phase=.3*c, flip=bool(c % 2)) for c in range(10)])
+    mixed = [ten, many, one, big, small]
+    gb = M.GlyphBatch(ShapeBatch.from_shapes(mixed))
+    for overlap in (True, False):
+        got = gb.generate(3, 24, 24, np.stack([xf2]*len(mixed)), cfg(overlap=overlap)).cpu().numpy()
+        for k, s_ in enumerate(mixed):
+            close(got[k], oracle.generate(s_, 3, 24, 24, xf2, overlap=overlap), "mixed batch with oversized glyphs, glyph %d, overlap %s" % (k, overlap))
+    gb.close()
     huge = grid_of_triangles(21000, 145)
     xf3 = autoframe((0, 0, 1, 1), 16, 16, 2)
     close(gen(3, huge, 16, 16, xf3), oracle.generate(huge, 3, 16, 16, xf3), "21 000 contours msdf + correction")
