@@ -1317,8 +1317,15 @@ int msdfhip_batch_create_prepared(MsdfHipBatch **batch, int n_glyphs, const int3
             PREP_CHK(hipMemcpy(raw.colors, colors, (size_t) nE, hipMemcpyHostToDevice));
         }
     }
-    if (nC)
-        hipLaunchKernelGGL(k_prep_normalize, dim3((nC+127)/128), dim3(128), 0, 0, raw, (const int32_t *) dCo, (const int32_t *) dCo1, nC, cfg->normalize ? 1 : 0, norm);
+    // Every pass below is queued without a host round trip; the coloured offsets come back once, at the end.
+    if (nE1) {
+        int32_t *dCusp = NULL;
+        PREP_CHK(dev.alloc((void **) &dCusp, sizeof(int32_t)*(size_t) (nC+1)));
+        PREP_CHK(hipMemsetAsync(dCusp, 0, sizeof(int32_t)*(size_t) (nC+1), 0));
+        hipLaunchKernelGGL(k_prep_normalize_flat, dim3((nE1+255)/256), dim3(256), 0, 0, raw, (const int32_t *) dCo, (const int32_t *) dCo1, nC, nE1, cfg->normalize ? 1 : 0, norm, dCusp);
+        if (cfg->normalize)
+            hipLaunchKernelGGL(k_prep_normalize_cusps, dim3((nC+127)/128), dim3(128), 0, 0, raw, (const int32_t *) dCo, (const int32_t *) dCo1, nC, norm, (const int32_t *) dCusp);
+    }
     const int32_t *finalCo = co1.data();
     int32_t *dFinalCo = dCo1;
     if (cfg->coloring) {
@@ -1330,28 +1337,33 @@ int msdfhip_batch_create_prepared(MsdfHipBatch **batch, int n_glyphs, const int3
         PREP_CHK(dev.alloc((void **) &fin.colors, eFin));
         if (nC)
             hipLaunchKernelGGL(k_prep_count, dim3((nC+127)/128), dim3(128), 0, 0, norm, (const int32_t *) dCo1, nC, crossThreshold, dCount);
-        std::vector<int32_t> count(nC+1, 0);
-        PREP_CHK(hipMemcpy(count.data(), dCount, sizeof(int32_t)*(size_t) nC, hipMemcpyDeviceToHost));   // synchronizes with the kernels above
-        for (int c = 0; c < nC; ++c)
-            co2[c+1] = co2[c]+count[c];
-        PREP_CHK(hipMemcpy(dCo2, co2.data(), sizeof(int32_t)*(size_t) (nC+1), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_prep_offsets, dim3(1), dim3(256), 0, 0, (const int32_t *) dCount, nC, dCo2);
         if (seeds && n_glyphs) {
             PREP_CHK(dev.alloc((void **) &dSeeds, sizeof(unsigned long long)*(size_t) n_glyphs));
             PREP_CHK(hipMemcpy(dSeeds, seeds, sizeof(unsigned long long)*(size_t) n_glyphs, hipMemcpyHostToDevice));
         }
-        CornerWork corners = { NULL, NULL, NULL, NULL };
-        if (cfg->coloring == 2) {                                 // edgeColoringInkTrap keeps a list of corners per contour (at most one per edge)
-            PREP_CHK(dev.alloc((void **) &corners.index, sizeof(int)*eNorm));
-            PREP_CHK(dev.alloc((void **) &corners.length, sizeof(double)*eNorm));
-            PREP_CHK(dev.alloc((void **) &corners.minor, eNorm));
-            PREP_CHK(dev.alloc((void **) &corners.color, eNorm));
+        // the colouring's per-contour tables live in LDS; a contour beyond PREP_WAVE_MAX_EDGES edges keeps them in global memory, indexed like the edges
+        ColourTables big = { NULL, NULL, NULL, NULL, NULL, NULL };
+        int longest = 0;
+        for (int c = 0; c < nC; ++c)
+            longest = co1[c+1]-co1[c] > longest ? co1[c+1]-co1[c] : longest;
+        if (longest > PREP_WAVE_MAX_EDGES) {
+            PREP_CHK(dev.alloc((void **) &big.cornerMask, sizeof(unsigned long long)*(eNorm/WAVE+(size_t) nC+2)));
+            PREP_CHK(dev.alloc((void **) &big.splineColor, eNorm));
+            if (cfg->coloring == 2) {
+                PREP_CHK(dev.alloc((void **) &big.edgeLength, sizeof(double)*eNorm));
+                PREP_CHK(dev.alloc((void **) &big.cornerLength, sizeof(double)*eNorm));
+                PREP_CHK(dev.alloc((void **) &big.cornerIndex, sizeof(int)*eNorm));
+                PREP_CHK(dev.alloc((void **) &big.minor, eNorm));
+            }
         }
-        if (n_glyphs && cfg->coloring == 1)                       // edgeColoringSimple: one wavefront per glyph, lanes = edges
-            hipLaunchKernelGGL(k_prep_colour_wave, dim3((unsigned) n_glyphs), dim3(WAVE), 0, 0, norm, (const int32_t *) dGco, (const int32_t *) dCo1, (const int32_t *) dCo2,
-                               n_glyphs, crossThreshold, (const unsigned long long *) dSeeds, (unsigned long long) cfg->seed, fin);
+        if (n_glyphs && cfg->coloring == 1)                       // one wavefront per glyph, lanes = edges / corners
+            hipLaunchKernelGGL(k_prep_colour_wave<false>, dim3((unsigned) n_glyphs), dim3(WAVE), 0, 0, norm, (const int32_t *) dGco, (const int32_t *) dCo1, (const int32_t *) dCo2,
+                               n_glyphs, crossThreshold, (const unsigned long long *) dSeeds, (unsigned long long) cfg->seed, fin, big);
         else if (n_glyphs)
-            hipLaunchKernelGGL(k_prep_colour, dim3((n_glyphs+63)/64), dim3(64), 0, 0, norm, (const int32_t *) dGco, (const int32_t *) dCo1, (const int32_t *) dCo2,
-                               n_glyphs, crossThreshold, (const unsigned long long *) dSeeds, (unsigned long long) cfg->seed, fin, cfg->coloring == 2 ? 1 : 0, corners);
+            hipLaunchKernelGGL(k_prep_colour_wave<true>, dim3((unsigned) n_glyphs), dim3(WAVE), 0, 0, norm, (const int32_t *) dGco, (const int32_t *) dCo1, (const int32_t *) dCo2,
+                               n_glyphs, crossThreshold, (const unsigned long long *) dSeeds, (unsigned long long) cfg->seed, fin, big);
+        PREP_CHK(hipMemcpy(co2.data(), dCo2, sizeof(int32_t)*(size_t) (nC+1), hipMemcpyDeviceToHost));   // in stream order after the kernels above
         finalCo = co2.data();
         dFinalCo = dCo2;
     } else

@@ -1725,17 +1725,30 @@ k_sign_correction(BatchView batch, const MsdfHipGlyph *glyphs, int width, int he
 
 // ------------------------------------------------------------------------------------------- shape preparation (row f3)
 
-// Shape::normalize, one thread per contour (msdf_shapeprep.hpp). co: raw contour offsets, co1: offsets after normalize.
-__global__ void k_prep_normalize(EdgeArrays raw, const int32_t *co, const int32_t *co1, int nContours, int doNormalize, EdgeArrays out) {
-    const int c = blockIdx.x*blockDim.x+threadIdx.x;
-    if (c >= nContours)
+// Shape::normalize, lanes = OUTPUT edges of the whole batch (msdf_shapeprep.hpp: normalizeEdgeFlat). co: raw contour offsets, co1: offsets after
+// normalize, nOut = co1[nContours]. cusp[c] (zeroed by the caller) is raised for a contour with a convergent junction: k_prep_normalize_cusps redoes it.
+__global__ void k_prep_normalize_flat(EdgeArrays raw, const int32_t *co, const int32_t *co1, int nContours, int nOut, int doNormalize, EdgeArrays out, int32_t *cusp) {
+    const int slot = blockIdx.x*blockDim.x+threadIdx.x;
+    if (slot >= nOut)
         return;
-    const int b = co[c], n = co[c+1]-b;
-    if (doNormalize)
-        normalizeContour(raw, b, n, out, co1[c]);
-    else
-        for (int i = 0; i < n; ++i)
-            storeEdge(out, co1[c]+i, loadEdge(raw, b+i));
+    int lo = 0, hi = nContours-1;                                   // last contour c with co1[c] <= slot (skips empty contours)
+    while (lo < hi) {
+        const int mid = (lo+hi+1)>>1;
+        if (co1[mid] <= slot)
+            lo = mid;
+        else
+            hi = mid-1;
+    }
+    const int ib = co[lo], ob = co1[lo];
+    if (normalizeEdgeFlat(raw, ib, co[lo+1]-ib, out, ob, slot-ob, doNormalize != 0))
+        cusp[lo] = 1;                                               // (every writer stores the same value)
+}
+
+// The sequential cusp repair (Shape.cpp:74-90) of the contours the pass above flagged -- none in any font we have; one thread per contour.
+__global__ void k_prep_normalize_cusps(EdgeArrays raw, const int32_t *co, const int32_t *co1, int nContours, EdgeArrays out, const int32_t *cusp) {
+    const int c = blockIdx.x*blockDim.x+threadIdx.x;
+    if (c < nContours && cusp[c])
+        normalizeContour(raw, co[c], co[c+1]-co[c], out, co1[c]);
 }
 
 // Edges per contour after edgeColoringSimple (a one-corner contour with fewer than three edges is split), one thread per contour.
@@ -1745,121 +1758,81 @@ __global__ void k_prep_count(EdgeArrays norm, const int32_t *co1, int nContours,
         count[c] = colouredCount(norm, co1[c], co1[c+1]-co1[c], crossThreshold);
 }
 
-// edgeColoringSimple / edgeColoringInkTrap, one thread per glyph: the colour / seed state runs through the glyph's contours
-// (edge-coloring.cpp:68-72, :151-155).
-__global__ void k_prep_colour(EdgeArrays norm, const int32_t *gco, const int32_t *co1, const int32_t *co2, int nGlyphs, double crossThreshold,
-                              const unsigned long long *seeds, unsigned long long seedAll, EdgeArrays out, int inkTrap, CornerWork corners) {
-    const int g = blockIdx.x*blockDim.x+threadIdx.x;
-    if (g >= nGlyphs)
-        return;
-    unsigned long long seed = seeds ? seeds[g] : seedAll;
-    int color = initColor(seed);
-    for (int c = gco[g]; c < gco[g+1]; ++c) {
-        if (inkTrap)
-            colourContourInkTrap(norm, co1[c], co1[c+1]-co1[c], out, co2[c], crossThreshold, color, seed, corners, co1[c]);
-        else
-            colourContour(norm, co1[c], co1[c+1]-co1[c], out, co2[c], crossThreshold, color, seed);
+// co2 = exclusive prefix of the counts above (co2[nContours] = total): one workgroup, a contiguous chunk per thread -- the offsets stay on the
+// device between the passes (until round 4 the host took the counts back in the middle of the call and returned the prefix).
+__global__ void __launch_bounds__(256) k_prep_offsets(const int32_t *count, int nContours, int32_t *co2) {
+    __shared__ int sums[256];
+    const int t = threadIdx.x, chunk = (nContours+255)/256;
+    const int lo = t*chunk < nContours ? t*chunk : nContours, hi = lo+chunk < nContours ? lo+chunk : nContours;
+    int sum = 0;
+    for (int i = lo; i < hi; ++i)
+        sum += count[i];
+    sums[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int k = 0; k < 256; ++k) {
+            const int v = sums[k];
+            sums[k] = run;
+            run += v;
+        }
+        co2[nContours] = run;
+    }
+    __syncthreads();
+    int run = sums[t];
+    for (int i = lo; i < hi; ++i) {
+        co2[i] = run;
+        run += count[i];
     }
 }
 
-// edgeColoringSimple with LANES = EDGES, one wavefront per glyph (round 4; the kernel above is its one-thread-per-glyph form, still used for
-// edgeColoringInkTrap and for contours beyond PREP_WAVE_MAX_EDGES). What is sequential in edge-coloring.cpp:73-141 is only the colour STATE: it
-// advances once per smooth contour, twice per teardrop, once per corner otherwise (switchColor, :53-64) -- a handful of scalar steps per contour,
-// taken by every lane alike. Everything per edge is parallel: the corner test of the junction before edge i (:76-85) reads edges i-1 and i only ->
-// one ballot per 64 edges; an edge's colour is its spline's, and its spline is the number of corners between the contour's first corner and the
-// edge, cyclically -- a prefix population count of the ballots; the teardrop's thirds are a closed form of the edge's position (:101-104).
+// The wave context of colourContourWave (msdf_shapeprep.hpp) on the device: one lane each; tests/hostemu's loops over 64.
+struct WaveCtx {
+    int lane;
+    template <class F> __device__ void lanes(F f) const { f(lane); }
+    template <class P> __device__ unsigned long long ballot(P pred) const { return __ballot(pred(lane)); }
+    template <class F> __device__ void leader(F f) const { if (lane == 0) f(); }
+    __device__ void sync() const {                                  // tables in LDS or (contours beyond PREP_WAVE_MAX_EDGES) in global memory
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
+
+// edgeColoringSimple / edgeColoringInkTrap, one wavefront per glyph, lanes = edges / corners (colourContourWave): the colour / seed state runs
+// through the glyph's contours (edge-coloring.cpp:68-72, :151-155) as wave-uniform values. Contours of up to PREP_WAVE_MAX_EDGES edges keep
+// their tables in LDS; longer ones in `big` (global, indexed like the edges; allocated only when the batch has such a contour).
 enum { PREP_WAVE_MAX_EDGES = 2048 };
+template <bool INKTRAP>
 __global__ void __launch_bounds__(WAVE)
 k_prep_colour_wave(EdgeArrays norm, const int32_t *gco, const int32_t *co1, const int32_t *co2, int nGlyphs, double crossThreshold,
-                   const unsigned long long *seeds, unsigned long long seedAll, EdgeArrays out) {
+                   const unsigned long long *seeds, unsigned long long seedAll, EdgeArrays out, ColourTables big) {
+    enum { INK_EDGES = INKTRAP ? (int) PREP_WAVE_MAX_EDGES : 1 };
     __shared__ unsigned long long cornerMask[PREP_WAVE_MAX_EDGES/WAVE];
     __shared__ unsigned char splineColor[PREP_WAVE_MAX_EDGES];
-    const int g = blockIdx.x, lane = threadIdx.x;
+    __shared__ double edgeLength[INK_EDGES], cornerLength[INK_EDGES];
+    __shared__ int cornerIndex[INK_EDGES];
+    __shared__ unsigned char minor[INK_EDGES];
+    const int g = blockIdx.x;
     if (g >= nGlyphs)
         return;
+    WaveCtx ctx;
+    ctx.lane = threadIdx.x;
     unsigned long long seed = seeds ? seeds[g] : seedAll;          // (wave-uniform state: every lane advances its own copy identically)
     int color = initColor(seed);
     for (int c = gco[g]; c < gco[g+1]; ++c) {
         const int ib = co1[c], n = co1[c+1]-ib, ob = co2[c];
-        if (n == 0)
-            continue;
-        if (n > PREP_WAVE_MAX_EDGES) {                              // beyond the LDS tables: the serial form on lane 0, its state broadcast
-            if (lane == 0)
-                colourContour(norm, ib, n, out, ob, crossThreshold, color, seed);
-            color = __shfl(color, 0);
-            seed = (unsigned long long) (unsigned) __shfl((int) (unsigned) seed, 0)|(unsigned long long) (unsigned) __shfl((int) (unsigned) (seed>>32), 0)<<32;
-            continue;
+        if (n <= PREP_WAVE_MAX_EDGES) {
+            ColourTables lds;
+            lds.cornerMask = cornerMask, lds.splineColor = splineColor, lds.edgeLength = edgeLength, lds.cornerLength = cornerLength;
+            lds.cornerIndex = cornerIndex, lds.minor = minor;
+            colourContourWave<INKTRAP>(ctx, lds, norm, ib, n, out, ob, crossThreshold, color, seed);
+        } else {
+            ColourTables t;                                         // (ib/64 + c: the ballot words of consecutive contours never overlap)
+            t.cornerMask = big.cornerMask+ib/WAVE+c, t.splineColor = big.splineColor+ib, t.edgeLength = big.edgeLength+ib;
+            t.cornerLength = big.cornerLength+ib, t.cornerIndex = big.cornerIndex+ib, t.minor = big.minor+ib;
+            colourContourWave<INKTRAP>(ctx, t, norm, ib, n, out, ob, crossThreshold, color, seed);
         }
-        // ---- corners: the junction before edge i
-        int nCorners = 0, first = -1;
-        for (int base = 0; base < n; base += WAVE) {
-            const int i = base+lane;
-            bool corner = false;
-            if (i < n) {
-                const PrepEdge e = loadEdge(norm, ib+i), pe = loadEdge(norm, ib+(i+n-1)%n);
-                corner = isCorner(normalize(edgeDirection(pe, 1), false), normalize(edgeDirection(e, 0), false), crossThreshold);
-            }
-            const unsigned long long mask = __ballot(corner);
-            if (lane == 0)
-                cornerMask[base/WAVE] = mask;
-            if (first < 0 && mask)
-                first = base+__ffsll((long long) mask)-1;
-            nCorners += __popcll(mask);
-        }
-        waveSync();
-        if (nCorners == 0) {                                        // smooth contour (:87-92)
-            switchColor(color, seed);
-            for (int i = lane; i < n; i += WAVE) {
-                PrepEdge e = loadEdge(norm, ib+i);
-                e.color = color;
-                storeEdge(out, ob+i, e);
-            }
-        } else if (nCorners == 1) {                                 // "teardrop" (:93-123)
-            int colors[3];
-            switchColor(color, seed);
-            colors[0] = color;
-            colors[1] = 7;
-            switchColor(color, seed);
-            colors[2] = color;
-            if (n >= 3) {
-                for (int index = lane; index < n; index += WAVE) {
-                    const int i = (index-first+n)%n;                // the edge's position counted from the corner
-                    PrepEdge e = loadEdge(norm, ib+index);
-                    e.color = colors[1+symmetricalTrichotomy(i, n)];
-                    storeEdge(out, ob+index, e);
-                }
-            } else if (lane == 0)
-                teardropSplit(norm, ib, n, out, ob, first, colors);
-        } else {                                                    // multiple corners (:124-140): one colour per spline, then lanes = edges
-            switchColor(color, seed);
-            const int initialColor = color;
-            if (lane == 0)
-                splineColor[0] = (unsigned char) color;
-            for (int spline = 1; spline < nCorners; ++spline) {
-                switchColorBanned(color, seed, (spline == nCorners-1)*initialColor);
-                if (lane == 0)
-                    splineColor[spline] = (unsigned char) color;
-            }
-            waveSync();
-            // corners among edges [0, k): full ballot words below k's, plus the low bits of k's word
-            auto cornersBelow = [&](int k) {
-                int sum = 0;
-                for (int w = 0; w < k/WAVE; ++w)
-                    sum += __popcll(cornerMask[w]);
-                if (k%WAVE)
-                    sum += __popcll(cornerMask[k/WAVE]&((1ull<<(k%WAVE))-1ull));
-                return sum;
-            };
-            const int uptoStart = cornersBelow(first+1);
-            for (int index = lane; index < n; index += WAVE) {
-                const int upto = cornersBelow(index+1);
-                const int spline = index >= first ? upto-uptoStart : nCorners-uptoStart+upto;   // corners in (first, index], cyclically
-                PrepEdge e = loadEdge(norm, ib+index);
-                e.color = splineColor[spline];
-                storeEdge(out, ob+index, e);
-            }
-        }
-        waveSync();                                                 // the LDS tables are the next contour's
     }
 }
 

@@ -78,27 +78,39 @@ MSDF_HD PrepEdge mkEdge(int type, int color, V2 a, V2 b, V2 c, V2 d) {
     return e;
 }
 
-MSDF_HD void splitInThirds(const PrepEdge &e, PrepEdge *part) {                       // edge-segments.cpp:508-527
+// The k-th part (0, 1, 2) of EdgeSegment::splitInThirds (edge-segments.cpp:508-527); no array, so that a lane can take one part.
+MSDF_HD PrepEdge splitThird(const PrepEdge &e, int k) {
     const V2 *p = e.p;
     const V2 z = mk(0, 0);
     if (e.type == 1) {
-        part[0] = mkEdge(1, e.color, p[0], edgePoint(e, 1/3.), z, z);
-        part[1] = mkEdge(1, e.color, edgePoint(e, 1/3.), edgePoint(e, 2/3.), z, z);
-        part[2] = mkEdge(1, e.color, edgePoint(e, 2/3.), p[1], z, z);
-    } else if (e.type == 2) {
-        part[0] = mkEdge(2, e.color, p[0], vmix(p[0], p[1], 1/3.), edgePoint(e, 1/3.), z);
-        part[1] = mkEdge(2, e.color, edgePoint(e, 1/3.), vmix(vmix(p[0], p[1], 5/9.), vmix(p[1], p[2], 4/9.), .5), edgePoint(e, 2/3.), z);
-        part[2] = mkEdge(2, e.color, edgePoint(e, 2/3.), vmix(p[1], p[2], 2/3.), p[2], z);
-    } else {
-        part[0] = mkEdge(3, e.color, p[0], veq(p[0], p[1]) ? p[0] : vmix(p[0], p[1], 1/3.),
-                         vmix(vmix(p[0], p[1], 1/3.), vmix(p[1], p[2], 1/3.), 1/3.), edgePoint(e, 1/3.));
-        part[1] = mkEdge(3, e.color, edgePoint(e, 1/3.),
-                         vmix(vmix(vmix(p[0], p[1], 1/3.), vmix(p[1], p[2], 1/3.), 1/3.), vmix(vmix(p[1], p[2], 1/3.), vmix(p[2], p[3], 1/3.), 1/3.), 2/3.),
-                         vmix(vmix(vmix(p[0], p[1], 2/3.), vmix(p[1], p[2], 2/3.), 2/3.), vmix(vmix(p[1], p[2], 2/3.), vmix(p[2], p[3], 2/3.), 2/3.), 1/3.),
-                         edgePoint(e, 2/3.));
-        part[2] = mkEdge(3, e.color, edgePoint(e, 2/3.), vmix(vmix(p[1], p[2], 2/3.), vmix(p[2], p[3], 2/3.), 2/3.),
-                         veq(p[2], p[3]) ? p[3] : vmix(p[2], p[3], 2/3.), p[3]);
+        if (k == 0)
+            return mkEdge(1, e.color, p[0], edgePoint(e, 1/3.), z, z);
+        if (k == 1)
+            return mkEdge(1, e.color, edgePoint(e, 1/3.), edgePoint(e, 2/3.), z, z);
+        return mkEdge(1, e.color, edgePoint(e, 2/3.), p[1], z, z);
     }
+    if (e.type == 2) {
+        if (k == 0)
+            return mkEdge(2, e.color, p[0], vmix(p[0], p[1], 1/3.), edgePoint(e, 1/3.), z);
+        if (k == 1)
+            return mkEdge(2, e.color, edgePoint(e, 1/3.), vmix(vmix(p[0], p[1], 5/9.), vmix(p[1], p[2], 4/9.), .5), edgePoint(e, 2/3.), z);
+        return mkEdge(2, e.color, edgePoint(e, 2/3.), vmix(p[1], p[2], 2/3.), p[2], z);
+    }
+    if (k == 0)
+        return mkEdge(3, e.color, p[0], veq(p[0], p[1]) ? p[0] : vmix(p[0], p[1], 1/3.),
+                      vmix(vmix(p[0], p[1], 1/3.), vmix(p[1], p[2], 1/3.), 1/3.), edgePoint(e, 1/3.));
+    if (k == 1)
+        return mkEdge(3, e.color, edgePoint(e, 1/3.),
+                      vmix(vmix(vmix(p[0], p[1], 1/3.), vmix(p[1], p[2], 1/3.), 1/3.), vmix(vmix(p[1], p[2], 1/3.), vmix(p[2], p[3], 1/3.), 1/3.), 2/3.),
+                      vmix(vmix(vmix(p[0], p[1], 2/3.), vmix(p[1], p[2], 2/3.), 2/3.), vmix(vmix(p[1], p[2], 2/3.), vmix(p[2], p[3], 2/3.), 2/3.), 1/3.),
+                      edgePoint(e, 2/3.));
+    return mkEdge(3, e.color, edgePoint(e, 2/3.), vmix(vmix(p[1], p[2], 2/3.), vmix(p[2], p[3], 2/3.), 2/3.),
+                  veq(p[2], p[3]) ? p[3] : vmix(p[2], p[3], 2/3.), p[3]);
+}
+
+MSDF_HD void splitInThirds(const PrepEdge &e, PrepEdge *part) {
+    for (int k = 0; k < 3; ++k)
+        part[k] = splitThird(e, k);
 }
 
 MSDF_HD void deconvergeEdge(PrepEdge &e, int param, V2 vector) {                      // Shape.cpp:44-62
@@ -237,6 +249,28 @@ MSDF_HD void normalizeContour(const EdgeArrays &in, int ib, int n, const EdgeArr
         }
         prev = i;
     }
+}
+
+// Shape::normalize with LANES = EDGES over the whole batch (round 4). What is sequential in Shape.cpp:74-90 is only the cusp repair: junction i
+// reads edge i-1 as junction i-1 left it. A junction that is NOT convergent modifies nothing, so as long as no junction of a contour is convergent
+// ON THE RAW EDGES the sequential pass modifies nothing either (induction from junction 0, which reads raw edges) -- and cusps are rare (none in
+// 8 192 DejaVu glyphs). Pass 1, one lane per OUTPUT edge: copy (or the lane's third of a single-edge contour, Shape.cpp:67-73) and the convergence
+// test of the junction before it; a contour with a convergent junction is flagged and redone by normalizeContour (pass 2, one lane per flagged contour).
+MSDF_HD bool junctionConvergent(const PrepEdge &pe, const PrepEdge &ce) {
+    const V2 prevDir = normalize(edgeDirection(pe, 1), false);
+    const V2 curDir = normalize(edgeDirection(ce, 0), false);
+    return dot(prevDir, curDir) < MSDF_CORNER_DOT_EPSILON-1;
+}
+
+// Output edge `i` of a contour of n raw edges at `ib` -> slot ob+i. Returns true if the junction before edge i is convergent.
+MSDF_HD bool normalizeEdgeFlat(const EdgeArrays &in, int ib, int n, const EdgeArrays &out, int ob, int i, bool doNormalize) {
+    if (doNormalize && n == 1) {
+        storeEdge(out, ob+i, splitThird(loadEdge(in, ib), i));
+        return false;
+    }
+    const PrepEdge ce = loadEdge(in, ib+i);
+    storeEdge(out, ob+i, ce);
+    return doNormalize && junctionConvergent(loadEdge(in, ib+(i+n-1)%n), ce);
 }
 
 // ---- edgeColoringSimple
@@ -444,6 +478,179 @@ MSDF_HD void colourContourInkTrap(const EdgeArrays &in, int ib, int n, const Edg
         e.color = color;
         storeEdge(out, ob+index, e);
     }
+}
+
+// ---- edgeColoringSimple / edgeColoringInkTrap with LANES = EDGES (and lanes = corners), one wavefront per glyph (round 4).
+// What is sequential in edge-coloring.cpp is only the colour STATE: it advances once per smooth contour, twice per teardrop, once per (major)
+// corner otherwise (switchColor, :53-64) -- a handful of wave-uniform scalar steps per contour. Everything per edge is parallel:
+//   * the corner test of the junction before edge i (:76-85, :159-170) reads edges i-1 and i only -> one ballot per 64 edges;
+//   * an edge's colour is its spline's, and its spline is the number of corners between the contour's first corner and the edge, cyclically --
+//     a prefix population count of the ballots (:128-139, :248-256); the teardrop's thirds are a closed form of the edge's position (:101-104);
+//   * ink trap: prevEdgeLengthEstimate of corner k is the reference's running sum over the edges of the spline before it -- one LANE PER CORNER
+//     adds its spline's edge lengths (computed with lanes = edges) in edge order, so every sum rounds as the reference's; the minor test (:222-228)
+//     reads three lengths; a minor corner's colour (:241-247) is (previous corner's & next corner's) ^ 7 -- its neighbours are always major
+//     (minor[i] needs length[i+1] < length[i+2], minor[i+1] the opposite), so that step is parallel over corners as well.
+// The driver is written against a wave context (lanes / ballot / leader / sync): the kernel's runs one lane each, tests/hostemu's loops over 64 --
+// the same source is checked against the oracle in the GPU-less container.
+enum { PREP_WAVE = 64 };
+
+struct ColourTables {
+    unsigned long long *cornerMask;    // [ceil(n / 64)] ballots of the corner test
+    unsigned char *splineColor;        // [n] colour per spline (ink trap: EdgeColoringInkTrapCorner::color)
+    double *edgeLength;                // ink trap: [n] estimateEdgeLength per edge
+    double *cornerLength;              //           [n] prevEdgeLengthEstimate per corner
+    int *cornerIndex;                  //           [n] edge index of the k-th corner
+    unsigned char *minor;              //           [n]
+};
+
+// corners among edges [0, k): full ballot words below k's, plus the low bits of k's word
+MSDF_HD int cornersBelow(const unsigned long long *mask, int k) {
+    int sum = 0;
+    for (int w = 0; w < k/PREP_WAVE; ++w)
+        sum += __builtin_popcountll(mask[w]);
+    if (k%PREP_WAVE)
+        sum += __builtin_popcountll(mask[k/PREP_WAVE]&((1ull<<(k%PREP_WAVE))-1ull));
+    return sum;
+}
+
+MSDF_HD int pick3(int a, int b, int c, int k) { return k == 0 ? a : k == 1 ? b : c; }
+
+// One contour: input edges [ib, ib+n) of `in`, output edges from `ob` of `out`; color / seed: the shape-wide running state (identical in every lane).
+template <bool INKTRAP, class Ctx>
+MSDF_HD void colourContourWave(const Ctx &ctx, const ColourTables &t, const EdgeArrays &in, int ib, int n, const EdgeArrays &out, int ob, double crossThreshold,
+                               int &color, unsigned long long &seed) {
+    if (n == 0)
+        return;
+    // ---- corners: the junction before edge i
+    int nCorners = 0, first = -1;
+    for (int base = 0; base < n; base += PREP_WAVE) {
+        const unsigned long long mask = ctx.ballot([&](int lane) {
+            const int i = base+lane;
+            if (i >= n)
+                return false;
+            const PrepEdge e = loadEdge(in, ib+i), pe = loadEdge(in, ib+(i+n-1)%n);
+            return isCorner(normalize(edgeDirection(pe, 1), false), normalize(edgeDirection(e, 0), false), crossThreshold);
+        });
+        ctx.leader([&]() { t.cornerMask[base/PREP_WAVE] = mask; });
+        if (first < 0 && mask)
+            first = base+__builtin_ctzll(mask);
+        nCorners += __builtin_popcountll(mask);
+    }
+    ctx.sync();
+    if (nCorners == 0) {                                                              // smooth contour (:87-92, :174-179)
+        switchColor(color, seed);
+        const int c = color;
+        ctx.lanes([&](int lane) {
+            for (int i = lane; i < n; i += PREP_WAVE) {
+                PrepEdge e = loadEdge(in, ib+i);
+                e.color = c;
+                storeEdge(out, ob+i, e);
+            }
+        });
+    } else if (nCorners == 1) {                                                       // "teardrop" (:93-123, :180-213)
+        switchColor(color, seed);
+        const int c0 = color, c1 = 7;
+        switchColor(color, seed);
+        const int c2 = color;
+        if (n >= 3)
+            ctx.lanes([&](int lane) {
+                for (int index = lane; index < n; index += PREP_WAVE) {
+                    const int i = (index-first+n)%n;                                  // the edge's position counted from the corner
+                    PrepEdge e = loadEdge(in, ib+index);
+                    e.color = pick3(c0, c1, c2, 1+symmetricalTrichotomy(i, n));
+                    storeEdge(out, ob+index, e);
+                }
+            });
+        else                                                                          // fewer than three edges: thirds of each, a lane per part (teardropSplit)
+            ctx.lanes([&](int lane) {
+                if (lane < 3*n) {
+                    const int src = n == 2 ? (lane/3 == first ? 0 : 1) : 0;           // the corner's edge comes first
+                    PrepEdge part = splitThird(loadEdge(in, ib+src), lane%3);
+                    part.color = pick3(c0, c1, c2, n >= 2 ? lane/2 : lane);
+                    storeEdge(out, ob+lane, part);
+                }
+            });
+    } else {                                                                          // multiple corners: one colour per spline, then lanes = edges
+        if (!INKTRAP) {                                                               // (:124-140)
+            switchColor(color, seed);
+            const int initialColor = color;
+            ctx.leader([&]() { t.splineColor[0] = (unsigned char) initialColor; });
+            for (int spline = 1; spline < nCorners; ++spline) {
+                switchColorBanned(color, seed, (spline == nCorners-1)*initialColor);
+                const int c = color;
+                ctx.leader([&]() { t.splineColor[spline] = (unsigned char) c; });
+            }
+            ctx.sync();
+        } else {                                                                      // (:214-247)
+            const int cornerCount = nCorners;
+            ctx.lanes([&](int lane) {                                                 // lanes = edges: length estimates; the position of the k-th corner
+                for (int i = lane; i < n; i += PREP_WAVE) {
+                    t.edgeLength[i] = estimateEdgeLength(loadEdge(in, ib+i));
+                    if (t.cornerMask[i/PREP_WAVE]>>(i%PREP_WAVE)&1ull)
+                        t.cornerIndex[cornersBelow(t.cornerMask, i)] = i;
+                }
+            });
+            ctx.sync();
+            ctx.lanes([&](int lane) {                                                 // lanes = corners: the running sum of the spline before the corner, in edge order
+                for (int k = lane; k < cornerCount; k += PREP_WAVE) {
+                    double length = 0;
+                    for (int i = k ? t.cornerIndex[k-1] : 0; i < t.cornerIndex[k]; ++i)
+                        length += t.edgeLength[i];
+                    if (k == 0 && cornerCount > 3) {                                  // corners[0].prevEdgeLengthEstimate += splineLength (:220)
+                        double tail = 0;
+                        for (int i = t.cornerIndex[cornerCount-1]; i < n; ++i)
+                            tail += t.edgeLength[i];
+                        length += tail;
+                    }
+                    t.cornerLength[k] = length;
+                }
+            });
+            ctx.sync();
+            int majorCornerCount = cornerCount;
+            for (int base = 0; base < cornerCount; base += PREP_WAVE) {               // lanes = corners (:221-228)
+                const unsigned long long mask = ctx.ballot([&](int lane) {
+                    const int i = base+lane;
+                    if (i >= cornerCount)
+                        return false;
+                    const double a = t.cornerLength[i], b = t.cornerLength[(i+1)%cornerCount], c = t.cornerLength[(i+2)%cornerCount];
+                    const bool minor = cornerCount > 3 && a > b && b < c;
+                    t.minor[i] = (unsigned char) minor;
+                    return minor;
+                });
+                majorCornerCount -= __builtin_popcountll(mask);
+            }
+            ctx.sync();
+            int initialColor = 0;
+            for (int i = 0; i < cornerCount; ++i)                                     // the colour state: one step per major corner (:229-240)
+                if (!t.minor[i]) {
+                    --majorCornerCount;
+                    switchColorBanned(color, seed, !majorCornerCount*initialColor);
+                    const int c = color;
+                    ctx.leader([&]() { t.splineColor[i] = (unsigned char) c; });
+                    if (!initialColor)
+                        initialColor = color;
+                }
+            ctx.sync();
+            ctx.lanes([&](int lane) {                                                 // lanes = minor corners: between two major ones (:241-247)
+                for (int i = lane; i < cornerCount; i += PREP_WAVE)
+                    if (t.minor[i])
+                        t.splineColor[i] = (unsigned char) ((t.splineColor[(i+cornerCount-1)%cornerCount]&t.splineColor[(i+1)%cornerCount])^7);
+            });
+            ctx.sync();
+            color = t.splineColor[cornerCount-1];                                     // the walk (:248-256) ends in the last corner's spline
+        }
+        const int uptoStart = cornersBelow(t.cornerMask, first+1);
+        ctx.lanes([&](int lane) {
+            for (int index = lane; index < n; index += PREP_WAVE) {
+                const int upto = cornersBelow(t.cornerMask, index+1);
+                const int spline = index >= first ? upto-uptoStart : nCorners-uptoStart+upto;   // corners in (first, index], cyclically
+                PrepEdge e = loadEdge(in, ib+index);
+                e.color = t.splineColor[spline];
+                storeEdge(out, ob+index, e);
+            }
+        });
+    }
+    ctx.sync();                                                                       // the tables are the next contour's
 }
 
 } // namespace msdfhip

@@ -97,7 +97,9 @@ class Emu:
         self.lib.emu_psdf_cooperative(int(overlap)+2*int(slotted), *args, len(pts), _p(pts, C.c_double), _p(out, C.c_double))
         return out
 
-    def shape_prepare(self, s, normalize=True, coloring=1, angle=3.0, seed=0):
+    def shape_prepare(self, s, normalize=True, coloring=1, angle=3.0, seed=0, wave=False):
+        """wave: the lanes = edges / corners forms the kernels run since round 4 (emu_shape_prepare_wave), else the serial ones;
+        with wave, self.cusp_contours = the contours the flat normalize pass handed to the serial cusp repair."""
         from msdfgen_amd.shape import FlatShape
         keep, args = self._shape(s)
         ne = int(np.asarray(s.contour_offsets)[-1])
@@ -105,6 +107,13 @@ class Emu:
         pts = np.zeros((max(3*ne, 1), 8))
         types = np.zeros(max(3*ne, 1), np.uint8)
         colors = np.zeros(max(3*ne, 1), np.uint8)
+        if wave:
+            flagged = C.c_int(0)
+            self.lib.emu_shape_prepare_wave.restype = C.c_int
+            n = self.lib.emu_shape_prepare_wave(*args, int(normalize), int(coloring), C.c_double(angle), C.c_ulonglong(int(seed)), _p(offs, C.c_int32),
+                                                _p(pts, C.c_double), _p(types, C.c_uint8), _p(colors, C.c_uint8), C.byref(flagged))
+            self.cusp_contours = flagged.value
+            return FlatShape(offs, pts[:n], types[:n].astype(np.int32), colors[:n].astype(np.int32))
         self.lib.emu_shape_prepare.restype = C.c_int
         n = self.lib.emu_shape_prepare(*args, int(normalize), int(coloring), C.c_double(angle), C.c_ulonglong(int(seed)), _p(offs, C.c_int32), _p(pts, C.c_double),
                                        _p(types, C.c_uint8), _p(colors, C.c_uint8))

@@ -567,6 +567,84 @@ extern "C" int emu_shape_prepare(int nC, const int32_t *co, const double *points
     return outCo[nC];
 }
 
+// The wave context of colourContourWave (msdf_shapeprep.hpp) for the host: the 64 lanes one after the other between two sync points
+// (the kernel's WaveCtx in msdf_kernels.hpp runs one lane each).
+struct EmuWaveCtx {
+    template <class F> void lanes(F f) const { for (int l = 0; l < 64; ++l) f(l); }
+    template <class P> unsigned long long ballot(P pred) const {
+        unsigned long long m = 0;
+        for (int l = 0; l < 64; ++l)
+            if (pred(l))
+                m |= 1ull<<l;
+        return m;
+    }
+    template <class F> void leader(F f) const { f(); }
+    void sync() const { }
+};
+
+// Mirrors the round-4 form of msdfhip_batch_create_prepared for one shape: k_prep_normalize_flat (a "lane" per OUTPUT edge) + k_prep_normalize_cusps
+// (flagged contours redone serially) -> k_prep_count -> k_prep_offsets -> k_prep_colour_wave<coloring == 2> (colourContourWave with the wave
+// context above; tableCap = the kernel's PREP_WAVE_MAX_EDGES is irrelevant here, the tables are sized for the shape). cuspContours: flagged contours.
+extern "C" int emu_shape_prepare_wave(int nC, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors, int doNormalize,
+                                      int coloring, double angleThreshold, unsigned long long seed, int32_t *outCo, double *outPoints,
+                                      uint8_t *outTypes, uint8_t *outColors, int *cuspContours) {
+    EdgeArrays raw = { const_cast<double *>(points), const_cast<uint8_t *>(types), const_cast<uint8_t *>(colors) };
+    std::vector<int32_t> co1(nC+1, 0), cusp(nC+1, 0);
+    for (int c = 0; c < nC; ++c)
+        co1[c+1] = co1[c]+(doNormalize ? normalizedCount(co[c+1]-co[c]) : co[c+1]-co[c]);
+    const int nE1 = co1[nC];
+    std::vector<double> p1((size_t) 8*(nE1+1));
+    std::vector<uint8_t> t1(nE1+1), c1(nE1+1);
+    EdgeArrays norm = { p1.data(), t1.data(), c1.data() };
+    for (int slot = 0; slot < nE1; ++slot) {                                          // k_prep_normalize_flat
+        int lo = 0, hi = nC-1;
+        while (lo < hi) {
+            const int mid = (lo+hi+1)>>1;
+            if (co1[mid] <= slot) lo = mid; else hi = mid-1;
+        }
+        if (normalizeEdgeFlat(raw, co[lo], co[lo+1]-co[lo], norm, co1[lo], slot-co1[lo], doNormalize != 0))
+            cusp[lo] = 1;
+    }
+    int flagged = 0;
+    for (int c = 0; c < nC; ++c)                                                      // k_prep_normalize_cusps
+        if (doNormalize && cusp[c]) {
+            normalizeContour(raw, co[c], co[c+1]-co[c], norm, co1[c]);
+            ++flagged;
+        }
+    if (cuspContours)
+        *cuspContours = flagged;
+    EdgeArrays out = { outPoints, outTypes, outColors };
+    if (!coloring) {
+        for (int c = 0; c <= nC; ++c)
+            outCo[c] = co1[c];
+        for (int e = 0; e < nE1; ++e)
+            storeEdge(out, e, loadEdge(norm, e));
+        return nE1;
+    }
+    const double crossThreshold = sin(angleThreshold);
+    outCo[0] = 0;
+    for (int c = 0; c < nC; ++c)                                                      // k_prep_count + k_prep_offsets
+        outCo[c+1] = outCo[c]+colouredCount(norm, co1[c], co1[c+1]-co1[c], crossThreshold);
+    int longest = 1;
+    for (int c = 0; c < nC; ++c)
+        longest = std::max(longest, co1[c+1]-co1[c]);
+    std::vector<unsigned long long> mask((size_t) longest/64+2);
+    std::vector<unsigned char> splineColor(longest), minor(longest);
+    std::vector<double> edgeLength(longest), cornerLength(longest);
+    std::vector<int> cornerIndex(longest);
+    ColourTables t = { mask.data(), splineColor.data(), edgeLength.data(), cornerLength.data(), cornerIndex.data(), minor.data() };
+    EmuWaveCtx ctx;
+    int color = initColor(seed);
+    for (int c = 0; c < nC; ++c) {
+        // (stale table contents from the previous contour stay in place, as in LDS)
+        if (coloring == 2)
+            colourContourWave<true>(ctx, t, norm, co1[c], co1[c+1]-co1[c], out, outCo[c], crossThreshold, color, seed);
+        else
+            colourContourWave<false>(ctx, t, norm, co1[c], co1[c+1]-co1[c], out, outCo[c], crossThreshold, color, seed);
+    }
+    return outCo[nC];
+}
+
 // Mirrors k_sdf_error_lines + k_sdf_error_sum: a "lane" per scanline (lists with stride 1 here), then the sequential sum per glyph.
 extern "C" double emu_estimate_sdf_error(int N, const float *px, int w, int h, int yDown, int nC, const int32_t *co, const double *points,
                                          const uint8_t *types, const uint8_t *colors, const double *xf, int scanlinesPerRow, int fillRule) {

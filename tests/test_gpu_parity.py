@@ -808,6 +808,24 @@ def test_shape_preparation_random_vs_oracle(oracle):
     nchange = [int((np.diff(np.asarray(w.colors).astype(int)) != 0).sum()) for w in bwant]
     assert max(nchange) >= 20 and nchange[-3] == 0 and nchange[-2] == 2 and 7 in np.asarray(bwant[-2].colors) and 2 <= nchange[-1] <= 8, nchange   # many-corner, smooth, teardrop and few-spline contours were in it
     gb.close()
+    # edgeColoringInkTrap on the same long contours (lanes = corners: spline lengths, minor corners; the 2 100-edge one keeps its tables in global memory)
+    iwant = [oracle.shape_prepare(s, False, 2, 3.0, int(sd)) for s, sd in zip(big, bseeds)]
+    gb = M.GlyphBatch.from_raw(ShapeBatch.from_shapes(big), False, 2, 3.0, seeds=np.array(bseeds, np.uint64))
+    _same_batch(gb.shapes, ShapeBatch.from_shapes([FlatShape(f.contour_offsets, f.points, f.types, f.colors) for f in iwant]), "long contours, ink trap")
+    gb.close()
+    assert sum(int((np.asarray(a.colors) != np.asarray(b.colors)).any()) for a, b in zip(iwant, bwant)) >= 3    # minor corners were in it
+    # shapes built for the preparation passes (tests/test_shape_prep_oracle.py): contours of hundreds of edges, > 64 corners, CUSPS (normalize's
+    # serial repair next to the lanes-=-edges pass), one- and two-edge contours (split in thirds) -- normalize x {keep, simple, ink trap}
+    from test_shape_prep_oracle import prep_stress_shapes
+    stress = prep_stress_shapes(41, 120)
+    sseeds = np.arange(5000, 5000+len(stress), dtype=np.uint64)
+    for normalize in (True, False):
+        for coloring, angle in ((0, 3.0), (1, 3.0), (2, 3.0), (1, .05), (2, 1.0)):
+            want = [oracle.shape_prepare(s, normalize, coloring, angle, int(sd)) for s, sd in zip(stress, sseeds)]
+            gb = M.GlyphBatch.from_raw(ShapeBatch.from_shapes(stress), normalize, coloring, angle, seeds=sseeds)
+            _same_batch(gb.shapes, ShapeBatch.from_shapes([FlatShape(f.contour_offsets, f.points, f.types, f.colors) for f in want]),
+                        "stress shapes, normalize %s colouring %d angle %g" % (normalize, coloring, angle))
+            gb.close()
     gb = M.GlyphBatch.from_raw(ShapeBatch.from_shapes(shapes[:50]), False, 1, 3.0, seed=77)    # one seed for all, colouring only
     want = [oracle.shape_prepare(s, False, 1, 3.0, 77) for s in shapes[:50]]
     _same_batch(gb.shapes, ShapeBatch.from_shapes([FlatShape(f.contour_offsets, f.points, f.types, f.colors) for f in want]), "colouring only")

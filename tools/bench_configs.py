@@ -109,12 +109,14 @@ def main():
                          z["raw_colors"].astype(np.int32), np.zeros(len(z["names"]), bool), [str(n) for n in z["names"]])
         big = raw.select([i % 283 for i in range(8192)])              # the font glyphs of the fixture, tiled
         M.GlyphBatch.from_raw(big).close()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            M.GlyphBatch.from_raw(big, True, 1, 3.0, seed=0).close()
-        dt = (time.perf_counter()-t0)/5
-        print(json.dumps({"config": "prep: Shape::normalize + edgeColoringSimple + digest of 8192 raw glyphs (%d edges) via msdfhip_batch_create_prepared, host arrays in, "
-                                    "prepared shapes read back" % big.n_edges, "ms_per_call": round(1e3*dt, 3), "glyphs_per_s": round(8192/dt)}), flush=True)
+        for coloring, name in ((1, "edgeColoringSimple"), (2, "edgeColoringInkTrap")):
+            M.GlyphBatch.from_raw(big, True, coloring, 3.0, seed=0).close()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                M.GlyphBatch.from_raw(big, True, coloring, 3.0, seed=0).close()
+            dt = (time.perf_counter()-t0)/5
+            print(json.dumps({"config": "prep: Shape::normalize + %s + digest of 8192 raw glyphs (%d edges) via msdfhip_batch_create_prepared, host arrays in, "
+                                        "prepared shapes read back" % (name, big.n_edges), "ms_per_call": round(1e3*dt, 3), "glyphs_per_s": round(8192/dt)}), flush=True)
     zd = np.load(os.path.join(ROOT, "tests", "golden", "dejavu8192.npz"))
     dj = ShapeBatch(zd["glyph_contour_offsets"].astype(np.int32), zd["contour_offsets"].astype(np.int32), zd["points"], zd["types"].astype(np.int32),
                     zd["colors"].astype(np.int32), np.zeros(len(zd["names"]), bool), [str(n) for n in zd["names"]])
