@@ -107,28 +107,28 @@ def step_ms(M, torch, lib, dev, stream, batch, xfs, w, h, cfg, steps, warmup=2):
 
 
 def strong_scaling_one_gpu(M, torch, lib, dev, stream, cfg, steps=6, parts=(2, 4, 8), only=None):
-    """Strong scaling of config 4 REHEARSED ON ONE GPU: the 8 192-glyph set cut into N contiguous shards of equal modelled cost
-    (msdfgen_amd.shard, what `--strong --gpus N` gives rank r), every shard timed ALONE on this device.  efficiency(N) = T(whole set) /
-    (N x max_r T(shard r)) -- what N such GPUs would deliver relative to N times one GPU, PCIe / host effects aside."""
-    from msdfgen_amd.shard import partition_contiguous, glyph_costs
+    """Strong scaling of config 4 REHEARSED ON ONE GPU: the 8 192-glyph set cut into N shards (msdfgen_amd.shard, what `--strong --gpus N` gives
+    rank r), every shard timed ALONE on this device.  efficiency(N) = T(whole set) / (N x max_r T(shard r)) -- what N such GPUs would deliver
+    relative to N times one GPU, PCIe / host effects aside.  Two cuts: "dealt" (the default of --strong: glyphs in order of modelled cost dealt
+    out in a snake, every shard the same mix) and "contiguous" (ranges of equal modelled cost, rounds 3-4)."""
+    from msdfgen_amd.shard import shard_indices
     res = {}
     for name, (batch, xfs) in config4_sets().items():
         if only and name != only:
             continue
         whole, kd, kc = step_ms(M, torch, lib, dev, stream, batch, xfs, 48, 48, cfg, steps)
-        costs = glyph_costs(batch, 48, 48)
         row = {"ms_whole_set": round(whole, 3), "glyphs_per_s_1gpu": round(batch.n_glyphs/whole*1e3), "kernel_ms": {"distance": round(kd, 3), "error_correction": round(kc, 3)}}
-        for n in parts:
-            b = partition_contiguous(costs, n)
-            t = []
-            for r in range(n):
-                lo, hi = int(b[r]), int(b[r+1])
-                t.append(step_ms(M, torch, lib, dev, stream, batch.select(range(lo, hi)), xfs[lo:hi], 48, 48, cfg, steps)[0])
-            row["x%d" % n] = {"efficiency": round(whole/(n*max(t)), 3), "ms_per_shard": [round(v, 3) for v in t], "glyphs_per_shard": [int(b[r+1]-b[r]) for r in range(n)],
-                              "projected_glyphs_per_s": round(batch.n_glyphs/max(t)*1e3)}
+        for cut in ("dealt", "contiguous"):
+            for n in parts:
+                lists = shard_indices(batch, n, 48, 48, cut)
+                t = [step_ms(M, torch, lib, dev, stream, batch.select(ix), xfs[ix], 48, 48, cfg, steps)[0] for ix in lists]
+                row[("x%d" if cut == "dealt" else "contiguous_x%d") % n] = {
+                    "efficiency": round(whole/(n*max(t)), 3), "ms_per_shard": [round(v, 3) for v in t], "glyphs_per_shard": [len(ix) for ix in lists],
+                    "projected_glyphs_per_s": round(batch.n_glyphs/max(t)*1e3)}
         res[name] = row
     res["note"] = ("BASELINE config 4 as stated (ONE 8192-glyph 48x48 msdf atlas over N GPUs), rehearsed on one GPU: every shard timed alone on this device; "
-                   "efficiency = T(8192) / (N * max_r T(shard r)); measured multi-GPU: bench.py --strong --gpus N")
+                   "efficiency = T(8192) / (N * max_r T(shard r)); xN = dealt cut (default of --strong), contiguous_xN = ranges of equal modelled cost; "
+                   "measured multi-GPU: bench.py --strong --gpus N")
     return res
 
 
@@ -367,11 +367,12 @@ def mock_rank(args, rank, world):
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     if args.strong:                                                  # ONE set cut into `world` shards (total work fixed)
-        from msdfgen_amd.shard import partition_contiguous, glyph_costs
+        from msdfgen_amd.shard import shard_indices
         whole, wxf = config4_sets()[args.strong_set]
-        bounds = partition_contiguous(glyph_costs(whole, 48, 48), world)
-        lo, hi = int(bounds[rank]), int(bounds[rank+1])
-        sub = whole.select(range(lo, hi))
+        lists = shard_indices(whole, world, 48, 48, args.strong_cut)
+        lo, hi = 0, len(lists[rank])
+        bounds = np.concatenate([[0], np.cumsum([len(ix) for ix in lists])])
+        sub = whole.select(lists[rank])
     else:
         batch, xfs, _ = load_dejavu()
         sub, sx, (lo, hi), bounds = rank_shard(batch, xfs, args.glyphs, world, rank, args.size, args.size)
@@ -406,6 +407,8 @@ def main():
     ap.add_argument("--strong", action="store_true", help="BASELINE config 4 as stated: ONE 8192-glyph 48x48 msdf atlas (--strong-set) glyph-sharded over "
                                                            "--gpus ranks (strong scaling: total work fixed); with --gpus 1 also the one-GPU rehearsal of the N-way splits")
     ap.add_argument("--strong-set", default="cjk_like", choices=["cjk_like", "dejavu"])
+    ap.add_argument("--strong-cut", default="dealt", choices=["dealt", "contiguous"],
+                    help="--strong: glyphs in order of modelled cost dealt out to the ranks (every shard the same mix), or contiguous ranges of equal modelled cost")
     ap.add_argument("--inprocess", action="store_true", help="one process drives all --gpus devices through msdfhip_generate_sharded (end to end; prints its own JSON line)")
     args = ap.parse_args()
 
@@ -447,12 +450,12 @@ def main():
     w = h = args.size
     if args.strong:
         # config 4 as BASELINE states it: ONE 8 192-glyph set, 48x48, cut into `world` contiguous shards of equal modelled cost (total work fixed)
-        from msdfgen_amd.shard import partition_contiguous, glyph_costs
+        from msdfgen_amd.shard import shard_indices
         w = h = 48
         whole, wxf = config4_sets()[args.strong_set]
-        shard_bounds = partition_contiguous(glyph_costs(whole, w, h), world)
-        lo, hi = int(shard_bounds[rank]), int(shard_bounds[rank+1])
-        batch, xfs = whole.select(range(lo, hi)), wxf[lo:hi]
+        mine = shard_indices(whole, world, w, h, args.strong_cut)[rank]
+        lo, hi = int(mine[0]) if len(mine) else 0, int(mine[-1])+1 if len(mine) else 0
+        batch, xfs = whole.select(mine), wxf[mine]
     else:
         dejavu, xf64, bounds = load_dejavu()
         if w != 64:
@@ -482,15 +485,18 @@ def main():
             "value": total_glyphs/elapsed, "unit": "glyphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3*elapsed/args.steps, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("STRONG scaling, BASELINE config 4: ONE 8192-glyph set (%s) msdf 48x48 cut into %d contiguous shards of equal modelled cost, "
+            "config": {"workload": ("STRONG scaling, BASELINE config 4: ONE 8192-glyph set (%s) msdf 48x48 cut into %d shards (%s), "
                                     "library-default config; step = digest + distance field + error correction of the rank's shard, HBM resident; value = 8192 glyphs / slowest rank"
-                                    % (args.strong_set, world)) if args.strong else "msdf %dx%d tiles, %d DISTINCT glyphs per GPU per step = the first 8192 glyphs with outlines of DejaVuSans + DejaVuSans-Bold "
+                                    % (args.strong_set, world, "glyphs in order of modelled cost dealt out to the ranks" if args.strong_cut == "dealt" else "contiguous ranges of equal modelled cost")) if args.strong else "msdf %dx%d tiles, %d DISTINCT glyphs per GPU per step = the first 8192 glyphs with outlines of DejaVuSans + DejaVuSans-Bold "
                                    "(%.1f edges, %.2f contours per glyph; tests/golden/dejavu8192.npz, every tile pinned to the compiled reference); "
                                    "overlapSupport=true, error correction EDGE_PRIORITY+CHECK_DISTANCE_AT_EDGE (library defaults); "
                                    "step = digest + distance field + error correction, inputs/outputs resident in HBM" % (
                                        w, h, args.glyphs, batch.n_edges/batch.n_glyphs, batch.n_contours/batch.n_glyphs),
                        "glyphs_per_gpu": batch.n_glyphs if args.strong else args.glyphs, "tile": [w, h], "mode": "msdf",
-                       "parallelism": "glyph-sharded x%d into ranges of equal modelled cost (msdfgen_amd.shard), no collective; rank 0 owns glyphs [%d, %d) of %d%s" % (
+                       "parallelism": ("glyph-sharded x%d, dealt by modelled cost (msdfgen_amd.shard.partition_dealt), no collective; rank 0 owns %d glyphs of 8192%s" % (
+                           world, batch.n_glyphs, " -- REHEARSAL: all ranks on one GPU, gloo" if args.same_device else ""))
+                       if args.strong and args.strong_cut == "dealt" else
+                       "glyph-sharded x%d into ranges of equal modelled cost (msdfgen_amd.shard), no collective; rank 0 owns glyphs [%d, %d) of %d%s" % (
                            world, lo, hi, 8192 if args.strong else world*args.glyphs, " -- REHEARSAL: all ranks on one GPU, gloo" if args.same_device else "")},
             "roofline": {"bound": "hbm", "kernel": "k_distance<3,...> distance pass (msdf; three launches: 1-contour glyphs / combiner scratch in LDS / in the global workspace)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS,

@@ -63,6 +63,58 @@ def test_two_rank_glyph_sharding_and_gather():
     assert abs(work[0]-work[1]) <= max(edges)+1
 
 
+def _worker_dealt(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from msdfgen_amd.shape import ShapeBatch
+    from msdfgen_amd.shard import shard_indices, gather_tiles_indexed
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = np.load(os.path.join(GOLDEN, "latin.npz"))
+    batch = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
+                       z["colors"].astype(np.int32), z["inverse_y"], [str(n) for n in z["names"]])
+    lists = shard_indices(batch, world, 64, 64, "dealt")
+    mine = lists[rank]
+    sub = batch.select(mine)
+    tiles = torch.zeros((len(mine), 4, 4, 3))
+    for i, g in enumerate(mine):
+        tiles[i, ..., 0] = int(g)
+        tiles[i, ..., 1] = sub.shape(i).n_edges
+    atlas = gather_tiles_indexed(tiles, lists)
+    q.put((rank, [int(g) for g in mine], atlas[:, 0, 0, 0].tolist(), atlas[:, 0, 0, 1].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_dealt_sharding_and_indexed_gather():
+    """The strong-scaling cut (msdfgen_amd.shard.partition_dealt): the ranks' index lists partition the atlas, carry the same modelled cost to within
+    one glyph, and gather_tiles_indexed puts the tiles back in atlas order on every rank (three gloo ranks: uneven list lengths)."""
+    from msdfgen_amd.shard import partition_dealt
+    world = 3
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_dealt, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    z = np.load(os.path.join(GOLDEN, "latin.npz"))
+    co, gco = z["contour_offsets"], z["glyph_contour_offsets"]
+    edges = (co[gco[1:]]-co[gco[:-1]]).tolist()
+    owned = sorted(g for r in results for g in r[1])
+    assert owned == list(range(94)) and {len(r[1]) for r in results} <= {31, 32}
+    for r in results:
+        assert r[1] == sorted(r[1]) and r[2] == list(range(94)) and r[3] == edges
+    rng = np.random.default_rng(3)
+    costs = rng.lognormal(0, 1.2, 8192)
+    lists = partition_dealt(costs, 8)
+    sums = np.array([costs[ix].sum() for ix in lists])
+    assert sorted(np.concatenate(lists).tolist()) == list(range(8192)) and sums.max()-sums.min() <= costs.max()
+    assert [ix.tolist() for ix in partition_dealt(costs, 8)] == [ix.tolist() for ix in lists]                 # deterministic
+    assert [len(ix) for ix in partition_dealt(costs[:5], 8)] == [1, 1, 1, 1, 1, 0, 0, 0]                        # fewer glyphs than ranks
+
+
 def test_bench_gpus_2_spawns_two_ranks():
     """`python bench.py --gpus 2` outside torchrun must launch two ranks itself (--gpus was parsed and ignored). --mock runs the
     N > 1 control path on CPU: gloo ranks, the real shard computation on the bench workload, barrier + gather, rank 0 prints one line."""
@@ -87,7 +139,7 @@ def test_bench_gpus_2_spawns_two_ranks():
 
 
 def test_bench_strong_scaling_mode_cuts_one_set():
-    """`bench.py --strong --gpus N` = BASELINE config 4 as stated: ONE 8 192-glyph 48x48 set cut into N contiguous shards of equal modelled cost
+    """`bench.py --strong --gpus N` = BASELINE config 4 as stated: ONE 8 192-glyph 48x48 set cut into N shards (dealt by modelled cost, or contiguous ranges of equal modelled cost
     (total work fixed; the default mode gives every rank a full set). Control path on CPU (--mock, gloo)."""
     import json
     import subprocess
@@ -95,9 +147,12 @@ def test_bench_strong_scaling_mode_cuts_one_set():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     for name in ("dejavu", "cjk_like"):
-        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mock", "--strong", "--strong-set", name], capture_output=True, text=True,
-                           timeout=300, env=env)
-        assert p.returncode == 0, p.stderr[-2000:]
-        r = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")][0]
-        assert r["scaling"] == "strong" and r["bounds"][0] == 0 and r["bounds"][-1] == 8192 and sum(r["glyphs_per_rank"]) == 8192
-        assert all(g > 2000 for g in r["glyphs_per_rank"]), r
+        for cut in ("dealt", "contiguous"):
+            p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mock", "--strong", "--strong-set", name, "--strong-cut", cut],
+                               capture_output=True, text=True, timeout=300, env=env)
+            assert p.returncode == 0, p.stderr[-2000:]
+            r = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")][0]
+            assert r["scaling"] == "strong" and r["bounds"][0] == 0 and r["bounds"][-1] == 8192 and sum(r["glyphs_per_rank"]) == 8192
+            assert all(g > 2000 for g in r["glyphs_per_rank"]), r
+            if cut == "dealt":                                                    # every shard the same mix: glyph and edge counts agree closely
+                assert abs(r["glyphs_per_rank"][0]-r["glyphs_per_rank"][1]) <= 1 and abs(r["edges_per_rank"][0]-r["edges_per_rank"][1]) < .02*sum(r["edges_per_rank"]), r
