@@ -2498,6 +2498,10 @@ static int runGroup(ShapeCall *const *calls, int n) {
     const bool resInLds = overlapEff && resLdsForm <= (size_t) 60*1024;
     const size_t listLds = resInLds ? resLdsForm : tileListBytes(maxE, maxC, true);
     size_t lds = listLds;
+    {
+        const size_t digestLds = (((size_t) maxC+3)/2+WAVE)*sizeof(double);   // the digest phase: contour offsets + the 64 shoelace terms of the windings
+        lds = lds > digestLds ? lds : digestLds;
+    }
     if (correct) {
         lds = lds > ecFastLdsBytes(maxE, channels) ? lds : ecFastLdsBytes(maxE, channels);
         lds = lds > queryLds ? lds : queryLds;

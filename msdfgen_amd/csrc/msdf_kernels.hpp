@@ -45,14 +45,34 @@ struct BatchView {
 
 // ------------------------------------------------------------------------------------------------------------- prep
 
-// The first edgeBlocks workgroups digest one edge per thread; the workgroups after them compute one contour winding per thread
-// (k_windings' job, folded into the same launch: the single-shape entry points are launch-latency bound).
+// The wave context of contourWindingsWave (msdf_prep.hpp) and colourContourWave (msdf_shapeprep.hpp) on the device: one lane each; tests/hostemu's
+// loops over 64.
+struct WaveCtx {
+    int lane;
+    template <class F> __device__ void lanes(F f) const { f(lane); }
+    template <class P> __device__ unsigned long long ballot(P pred) const { return __ballot(pred(lane)); }
+    template <class F> __device__ void leader(F f) const { if (lane == 0) f(); }
+    __device__ void sync() const {                                  // tables in LDS or (contours beyond PREP_WAVE_MAX_EDGES) in global memory
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
+
+// The first edgeBlocks workgroups digest one edge per thread; the workgroups after them compute the contour windings, 64 contours per wavefront
+// with lanes = edges (contourWindingsWave; k_windings' job, folded into the same launch: the single-shape entry points are launch-latency bound).
+// blockDim.x = 256.
 __global__ void k_prep_records(EdgeRec *recs, int nEdges, int nContours, const int32_t *contourOffsets,
                                const double *points, const uint8_t *types, const uint8_t *colors, int8_t *windings, int edgeBlocks) {
     if ((int) blockIdx.x >= edgeBlocks) {
-        const int c = ((int) blockIdx.x-edgeBlocks)*blockDim.x+threadIdx.x;
-        if (c < nContours)
-            windings[c] = (int8_t) contourWinding(c, contourOffsets, points, types, colors);
+        __shared__ double terms[4][64];
+        const int wave = threadIdx.x>>6;
+        const int cBegin = ((int) blockIdx.x-edgeBlocks)*256+64*wave;
+        if (cBegin < nContours) {
+            WaveCtx ctx;
+            ctx.lane = threadIdx.x&63;
+            contourWindingsWave(ctx, terms[wave], cBegin, cBegin+64 < nContours ? cBegin+64 : nContours, contourOffsets, points, types, colors, windings);
+        }
         return;
     }
     int slot = blockIdx.x*blockDim.x+threadIdx.x;
@@ -1785,19 +1805,6 @@ __global__ void __launch_bounds__(256) k_prep_offsets(const int32_t *count, int 
         run += count[i];
     }
 }
-
-// The wave context of colourContourWave (msdf_shapeprep.hpp) on the device: one lane each; tests/hostemu's loops over 64.
-struct WaveCtx {
-    int lane;
-    template <class F> __device__ void lanes(F f) const { f(lane); }
-    template <class P> __device__ unsigned long long ballot(P pred) const { return __ballot(pred(lane)); }
-    template <class F> __device__ void leader(F f) const { if (lane == 0) f(); }
-    __device__ void sync() const {                                  // tables in LDS or (contours beyond PREP_WAVE_MAX_EDGES) in global memory
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-};
 
 // edgeColoringSimple / edgeColoringInkTrap, one wavefront per glyph, lanes = edges / corners (colourContourWave): the colour / seed state runs
 // through the glyph's contours (edge-coloring.cpp:68-72, :151-155) as wave-uniform values. Contours of up to PREP_WAVE_MAX_EDGES edges keep

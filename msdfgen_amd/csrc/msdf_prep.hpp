@@ -53,9 +53,9 @@ MSDF_HD V2 rawPoint(const RawEdge &e, double t) {                             //
 MSDF_HD void st(double *dst, V2 v) { dst[0] = v.x, dst[1] = v.y; }
 
 // Builds the record of edge `cur` whose cyclic neighbours in its contour are `prev` and `next`.
-MSDF_HD void buildRecord(EdgeRec &r, const RawEdge &prev, const RawEdge &cur, const RawEdge &next, int contour) {
+__attribute__((always_inline)) MSDF_HD void buildRecord(EdgeRec &r, const RawEdge &prev, const RawEdge &cur, const RawEdge &next, int contour) {
     st(r.p0, cur.p[0]);
-    st(r.pe, cur.p[cur.type]);                                               // point(1): the last control point
+    st(r.pe, cur.type == 1 ? cur.p[1] : cur.type == 2 ? cur.p[2] : cur.p[3]);  // point(1): the last control point (selected, not indexed: the edge stays in registers)
     st(r.p1, cur.type >= 2 ? cur.p[1] : mk(0, 0));
     st(r.p2, cur.type == 3 ? cur.p[2] : mk(0, 0));
     r.pad_[0] = r.pad_[1] = 0;
@@ -112,10 +112,12 @@ MSDF_HD void buildRecord(EdgeRec &r, const RawEdge &prev, const RawEdge &cur, co
         st(r.k+2, 6*br);
     }
     V2 lo = cur.p[0], hi = cur.p[0];                                          // culling aids: control-point box, an on-curve sample
-    for (int i = 1; i <= cur.type; ++i) {
-        lo = mk(dmin(lo.x, cur.p[i].x), dmin(lo.y, cur.p[i].y));
-        hi = mk(dmax(hi.x, cur.p[i].x), dmax(hi.y, cur.p[i].y));
-    }
+    MSDF_UNROLL
+    for (int i = 1; i <= 3; ++i)
+        if (i <= cur.type) {
+            lo = mk(dmin(lo.x, cur.p[i].x), dmin(lo.y, cur.p[i].y));
+            hi = mk(dmax(hi.x, cur.p[i].x), dmax(hi.y, cur.p[i].y));
+        }
     st(r.lo, lo);
     st(r.hi, hi);
     st(r.mid, rawPoint(cur, .5));
@@ -145,7 +147,8 @@ MSDF_HD void buildRecord(EdgeRec &r, const RawEdge &prev, const RawEdge &cur, co
 // Record slot r (global, = contour start + visit position) -> natural edge index. Visit order: last, first, ..., last-1.
 MSDF_HD int visitToEdge(int start, int n, int v) { return start+(v == 0 ? n-1 : v-1); }
 
-MSDF_HD void prepRecord(EdgeRec *recs, int slot, int contour, const int32_t *contourOffsets, const double *points, const uint8_t *types, const uint8_t *colors) {
+// (always inlined: as a call it cost its callers an 84-168 B stack frame in scratch memory -- the only scratch of the digest kernels)
+__attribute__((always_inline)) MSDF_HD void prepRecord(EdgeRec *recs, int slot, int contour, const int32_t *contourOffsets, const double *points, const uint8_t *types, const uint8_t *colors) {
     const int start = contourOffsets[contour], n = contourOffsets[contour+1]-start;
     const int e = visitToEdge(start, n, slot-start);
     const int prev = start+(e-start+n-1)%n, next = start+(e-start+1)%n;
@@ -182,6 +185,69 @@ MSDF_HD int contourWinding(int contour, const int32_t *contourOffsets, const dou
         }
     }
     return (0 < total)-(total < 0);
+}
+
+// Contour::winding of the contours [cBegin, cEnd) by ONE wavefront (round 4). The shoelace sum of a contour (Contour.cpp:72-79) is a serial
+// floating-point sum whose sign is the result, so its ORDER is kept; what a lane per contour made serial as well were the LOADS -- one dependent
+// memory round trip per edge (a 160-edge contour: ~60 us, the duration of the whole digest launch of 8 192 glyphs; in the single-shape kernel most
+// of the digest phase). Here the terms shoelace(point_{i-1}(0), point_i(0)) are computed with lanes = edges, 64 per round over the edges of all the
+// contours at once, and one wave-uniform pass adds them in edge order, closing a contour whenever its last edge has been added (`terms`: 64 doubles
+// the lanes share). Contours of fewer than three edges use other sample points (:59-71): they keep contourWinding, a lane each.
+// Written against a wave context (lanes / leader / sync) like colourContourWave (msdf_shapeprep.hpp): tests/hostemu runs the same source.
+template <class Ctx>
+MSDF_HD void contourWindingsWave(const Ctx &ctx, double *terms, int cBegin, int cEnd, const int32_t *contourOffsets, const double *points, const uint8_t *types,
+                                 const uint8_t *colors, int8_t *windings) {
+    if (cBegin >= cEnd)
+        return;
+    const int e0 = contourOffsets[cBegin], e1 = contourOffsets[cEnd];
+    int c = cBegin, cFirstEdge = e0, cEndEdge = contourOffsets[cBegin+1];             // the contour the ordered pass is in
+    double total = 0;
+    for (int base = e0; base < e1; base += 64) {
+        ctx.lanes([&](int lane) {
+            const int i = base+lane;
+            double term = 0;
+            if (i < e1) {
+                int lo = cBegin, hi = cEnd-1;                                         // last contour with contourOffsets[c] <= i (skips empty contours)
+                while (lo < hi) {
+                    const int mid = (lo+hi+1)>>1;
+                    if (contourOffsets[mid] <= i)
+                        lo = mid;
+                    else
+                        hi = mid-1;
+                }
+                const int b = contourOffsets[lo], e = contourOffsets[lo+1];
+                if (e-b >= 3)
+                    term = shoelace(rawPoint(loadRaw(points, types, colors, i == b ? e-1 : i-1), 0), rawPoint(loadRaw(points, types, colors, i), 0));
+            }
+            terms[lane] = term;
+        });
+        ctx.sync();
+        const int count = e1-base < 64 ? e1-base : 64;
+        for (int k = 0; k < count; ++k) {
+            while (cEndEdge <= base+k) {                                              // the contours that ended before this edge (empty ones among them)
+                if (cEndEdge-cFirstEdge >= 3) {
+                    const int8_t w = (int8_t) ((0 < total)-(total < 0));
+                    const int at = c;
+                    ctx.leader([&]() { windings[at] = w; });
+                }
+                total = 0;
+                ++c;
+                cFirstEdge = cEndEdge, cEndEdge = contourOffsets[c+1];                // (c < cEnd: the edge base+k belongs to a contour of the range)
+            }
+            total += terms[k];
+        }
+        ctx.sync();
+    }
+    if (cEndEdge-cFirstEdge >= 3) {                                                   // the contour the last edge belonged to
+        const int8_t w = (int8_t) ((0 < total)-(total < 0));
+        const int at = c;
+        ctx.leader([&]() { windings[at] = w; });
+    }
+    ctx.lanes([&](int lane) {                                                         // fewer than three edges (none included): a lane each
+        for (int k = cBegin+lane; k < cEnd; k += 64)
+            if (contourOffsets[k+1]-contourOffsets[k] < 3)
+                windings[k] = (int8_t) contourWinding(k, contourOffsets, points, types, colors);
+    });
 }
 
 } // namespace msdfhip

@@ -202,8 +202,11 @@ k_single_call(SingleArgs a) {
             }
             prepRecord(recs, slot, lo, coLds, srcPoints, srcTypes, srcColors);
         }
-        for (int c = lane; c < a.nContours; c += WAVE)
-            windings[c] = (int8_t) contourWinding(c, coLds, srcPoints, srcTypes, srcColors);
+        {                                                           // lanes = edges, the sums in edge order (msdf_prep.hpp); its 64 terms follow the offsets in LDS
+            WaveCtx ctx;
+            ctx.lane = lane;
+            contourWindingsWave(ctx, smemSingle+(a.nContours+2+1)/2, 0, a.nContours, coLds, srcPoints, srcTypes, srcColors, windings);
+        }
         // the area is this wavefront's own: its stores only have to have LEFT the wavefront (they are written through to the XCD's L2, which
         // also backs the scalar cache) before the phases below read them back; no other workgroup is involved
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -22,6 +22,22 @@ using namespace msdfhip;
 
 static long g_lastDeferred = 0;
 
+// The wave context of contourWindingsWave (msdf_prep.hpp) and colourContourWave (msdf_shapeprep.hpp) for the host: the 64 lanes one after the other between two sync points
+// (the kernel's WaveCtx in msdf_kernels.hpp runs one lane each).
+struct EmuWaveCtx {
+    template <class F> void lanes(F f) const { for (int l = 0; l < 64; ++l) f(l); }
+    template <class P> unsigned long long ballot(P pred) const {
+        unsigned long long m = 0;
+        for (int l = 0; l < 64; ++l)
+            if (pred(l))
+                m |= 1ull<<l;
+        return m;
+    }
+    template <class F> void leader(F f) const { f(); }
+    void sync() const { }
+};
+
+
 namespace {
 
 struct Digest {
@@ -240,6 +256,18 @@ void emu_windings(int nC, const int32_t *co, const double *points, const uint8_t
     Digest d = digest(nC, co, points, types, colors);
     for (int c = 0; c < nC; ++c)
         out[c] = d.windings[c];
+}
+
+// The winding part of k_prep_records as it runs since round 4: 64 contours per "wavefront", lanes = edges, the sums in edge order
+// (contourWindingsWave with the 64-lane context above).
+void emu_windings_wave(int nC, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors, int32_t *out) {
+    std::vector<int8_t> w((size_t) nC+1, (int8_t) 99);
+    EmuWaveCtx ctx;
+    double terms[64];
+    for (int cBegin = 0; cBegin < nC; cBegin += 64)
+        contourWindingsWave(ctx, terms, cBegin, std::min(cBegin+64, nC), co, points, types, colors, w.data());
+    for (int c = 0; c < nC; ++c)
+        out[c] = w[c];
 }
 
 void emu_shape_distance(int sel, int overlap, int nC, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors,
@@ -566,21 +594,6 @@ extern "C" int emu_shape_prepare(int nC, const int32_t *co, const double *points
     }
     return outCo[nC];
 }
-
-// The wave context of colourContourWave (msdf_shapeprep.hpp) for the host: the 64 lanes one after the other between two sync points
-// (the kernel's WaveCtx in msdf_kernels.hpp runs one lane each).
-struct EmuWaveCtx {
-    template <class F> void lanes(F f) const { for (int l = 0; l < 64; ++l) f(l); }
-    template <class P> unsigned long long ballot(P pred) const {
-        unsigned long long m = 0;
-        for (int l = 0; l < 64; ++l)
-            if (pred(l))
-                m |= 1ull<<l;
-        return m;
-    }
-    template <class F> void leader(F f) const { f(); }
-    void sync() const { }
-};
 
 // Mirrors the round-4 form of msdfhip_batch_create_prepared for one shape: k_prep_normalize_flat (a "lane" per OUTPUT edge) + k_prep_normalize_cusps
 // (flagged contours redone serially) -> k_prep_count -> k_prep_offsets -> k_prep_colour_wave<coloring == 2> (colourContourWave with the wave

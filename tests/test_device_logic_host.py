@@ -73,6 +73,52 @@ def test_windings_and_queries(emu, oracle, latin):
             assert_bit_equal(emu.shape_distance(s, sel, ov, z["oneshot_pts"]), z["oneshot_%d_%d" % (sel, ov)], "sel %d ov %d" % (sel, ov))
 
 
+def winding_stress_shapes(seed):
+    """Shapes for Contour::winding: contours of hundreds of edges, > 64 contours per shape with empty / one-edge / two-edge ones in between, and
+    contours of (almost) no area, where the order of the shoelace sum decides the sign."""
+    from test_shape_prep_oracle import prep_stress_shapes
+    shapes = prep_stress_shapes(77, 60)
+    rng = np.random.default_rng(seed)
+    for k in range(30):                                                   # many contours of random lengths 0 .. 70, random orientation
+        contours = []
+        for c in range(int(rng.integers(60, 200))):
+            n = int(rng.choice([0, 1, 2, 3, 4, 5, 9, 33, 63, 64, 65, 70]))
+            cx, cy, r = rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(.01, .5)
+            ang = np.sort(rng.uniform(0, 2*np.pi, max(n, 1)))[::(1 if rng.random() < .5 else -1)]
+            pts = [(cx+r*np.cos(a), cy+r*np.sin(a)) for a in ang]
+            if n == 1:
+                contours.append([(7, pts[0], (cx+r, cy+r), (cx-r, cy+r), pts[0])])
+            elif n == 2:
+                contours.append([(7, pts[0], (cx, cy+r), pts[1]), (7, pts[1], (cx, cy-r), pts[0])])
+            else:
+                contours.append([(7, pts[i], pts[(i+1) % n]) if rng.random() < .7 else (7, pts[i], (cx, cy), pts[(i+1) % n]) for i in range(n)])
+        shapes.append(FlatShape.from_contours(contours))
+    for k in range(40):                                                   # out and back along (almost) the same path: the terms cancel to rounding
+        n = int(rng.integers(3, 90))
+        xs = np.sort(rng.uniform(0, 1, n))
+        eps = float(rng.choice([0., 1e-17, 1e-13, -1e-15]))
+        path = [(x, .3*x+eps*np.sin(40*x)) for x in xs]+[(x, .3*x) for x in xs[::-1][1:-1]]
+        shapes.append(FlatShape.from_contours([[(7, path[i], path[(i+1) % len(path)]) for i in range(len(path))]]))
+    return shapes
+
+
+def test_wave_form_of_the_contour_windings_matches_oracle(emu, oracle, latin):
+    """Round 4: the digest kernels compute Contour::winding with lanes = edges and a wave-uniform pass that adds the shoelace terms in edge order
+    (msdf_prep.hpp: contourWindingsWave), 64 contours per wavefront in k_prep_records, all of a shape's in k_single_call. The same source with a
+    64-lane context on the host against the oracle: fonts, contours of hundreds of edges, > 64 contours per shape (several wavefronts, contours
+    ending at and across the 64-edge rounds), empty / one-edge / two-edge contours in between, and contours of (almost) no area, where the
+    ORDER of the sum decides the sign."""
+    batch, _, _ = latin
+    shapes = [batch.shape(g) for g in range(batch.n_glyphs)]+winding_stress_shapes(12)
+    zero = both = 0
+    for s in shapes:
+        want = oracle.windings(s)
+        assert (emu.windings(s, wave=True) == want).all(), (s.n_contours, s.n_edges)
+        zero += int((want == 0).sum())
+        both += int((want > 0).any() and (want < 0).any())
+    assert zero >= 10 and both >= 30
+
+
 def test_degenerate_inputs(emu, oracle):
     empty = FlatShape(np.zeros(1, np.int32), np.zeros((0, 8)), np.zeros(0, np.int32), np.zeros(0, np.int32))
     xf = np.array([10., 10., .1, .1, -.2, .2])
@@ -85,7 +131,7 @@ def test_degenerate_inputs(emu, oracle):
         [(0, (.2, .2), (.8, .2)), (6, (.8, .2), (.8, .2)), (3, (.8, .2), (.5, .9)), (5, (.5, .9), (.2, .2))],
     ])
     xf = autoframe((0, 0, 2, 1.5), 20, 16, 2)
-    assert (emu.windings(s) == oracle.windings(s)).all()
+    assert (emu.windings(s) == oracle.windings(s)).all() and (emu.windings(s, wave=True) == oracle.windings(s)).all()
     for mode in (1, 2, 3, 4):
         for ov in (True, False):
             assert_bit_equal(emu.generate(s, mode, 20, 16, xf, overlap=ov), oracle.generate(s, mode, 20, 16, xf, overlap=ov), "degenerate mode %d" % mode)

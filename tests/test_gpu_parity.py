@@ -737,6 +737,20 @@ def test_shape_preparation_on_device_matches_reference_fixture(oracle):
     gb.close()
 
 
+def test_contour_windings_of_the_digest_kernels_vs_oracle(oracle):
+    """Contour::winding as the digest computes it since round 4 (lanes = edges, ordered sums; msdf_prep.hpp: contourWindingsWave): a batch of shapes
+    with long contours, > 64 contours, empty / short contours and contours of almost no area through k_prep_records (64 contours per wavefront, the
+    ranges cut across glyphs), and each of the first 40 alone (its own upload)."""
+    from test_device_logic_host import winding_stress_shapes
+    shapes = winding_stress_shapes(12)
+    want = [oracle.windings(s) for s in shapes]
+    gb = M.GlyphBatch(ShapeBatch.from_shapes(shapes))
+    assert (gb.windings() == np.concatenate(want)).all()
+    gb.close()
+    for s, w in zip(shapes[:40], want[:40]):
+        assert (M.contour_windings(s) == w).all()
+
+
 def test_backtracking_curves_follow_the_host_build_with_the_devices_own_transcendentals(oracle):
     """synthetic-2 / -10 (excluded above): a quadratic that runs out and straight back over itself. The sign of its distance is last-ulp noise
     of acos / cos in solveCubicNormed, where the kernels use their own < 1 ulp implementations (msdf_device.hpp) and the reference glibc's.
