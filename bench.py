@@ -109,8 +109,8 @@ def step_ms(M, torch, lib, dev, stream, batch, xfs, w, h, cfg, steps, warmup=2):
 def strong_scaling_one_gpu(M, torch, lib, dev, stream, cfg, steps=6, parts=(2, 4, 8), only=None):
     """Strong scaling of config 4 REHEARSED ON ONE GPU: the 8 192-glyph set cut into N shards (msdfgen_amd.shard, what `--strong --gpus N` gives
     rank r), every shard timed ALONE on this device.  efficiency(N) = T(whole set) / (N x max_r T(shard r)) -- what N such GPUs would deliver
-    relative to N times one GPU, PCIe / host effects aside.  Two cuts: "dealt" (the default of --strong: glyphs in order of modelled cost dealt
-    out in a snake, every shard the same mix) and "contiguous" (ranges of equal modelled cost, rounds 3-4)."""
+    relative to N times one GPU, PCIe / host effects aside.  xN: contiguous ranges of equal modelled cost (the default of --strong); dealt_x8: the
+    8-way cut with the glyphs dealt out by modelled cost (--strong-cut dealt: every shard the same mix -- measured no better)."""
     from msdfgen_amd.shard import shard_indices
     res = {}
     for name, (batch, xfs) in config4_sets().items():
@@ -118,16 +118,15 @@ def strong_scaling_one_gpu(M, torch, lib, dev, stream, cfg, steps=6, parts=(2, 4
             continue
         whole, kd, kc = step_ms(M, torch, lib, dev, stream, batch, xfs, 48, 48, cfg, steps)
         row = {"ms_whole_set": round(whole, 3), "glyphs_per_s_1gpu": round(batch.n_glyphs/whole*1e3), "kernel_ms": {"distance": round(kd, 3), "error_correction": round(kc, 3)}}
-        for cut in ("dealt", "contiguous"):
-            for n in parts:
-                lists = shard_indices(batch, n, 48, 48, cut)
-                t = [step_ms(M, torch, lib, dev, stream, batch.select(ix), xfs[ix], 48, 48, cfg, steps)[0] for ix in lists]
-                row[("x%d" if cut == "dealt" else "contiguous_x%d") % n] = {
-                    "efficiency": round(whole/(n*max(t)), 3), "ms_per_shard": [round(v, 3) for v in t], "glyphs_per_shard": [len(ix) for ix in lists],
-                    "projected_glyphs_per_s": round(batch.n_glyphs/max(t)*1e3)}
+        for cut, n in [("contiguous", n) for n in parts]+[("dealt", 8)]:
+            lists = shard_indices(batch, n, 48, 48, cut)
+            t = [step_ms(M, torch, lib, dev, stream, batch.select(ix), xfs[ix], 48, 48, cfg, steps)[0] for ix in lists]
+            row[("x%d" if cut == "contiguous" else "dealt_x%d") % n] = {
+                "efficiency": round(whole/(n*max(t)), 3), "ms_per_shard": [round(v, 3) for v in t], "glyphs_per_shard": [len(ix) for ix in lists],
+                "projected_glyphs_per_s": round(batch.n_glyphs/max(t)*1e3)}
         res[name] = row
     res["note"] = ("BASELINE config 4 as stated (ONE 8192-glyph 48x48 msdf atlas over N GPUs), rehearsed on one GPU: every shard timed alone on this device; "
-                   "efficiency = T(8192) / (N * max_r T(shard r)); xN = dealt cut (default of --strong), contiguous_xN = ranges of equal modelled cost; "
+                   "efficiency = T(8192) / (N * max_r T(shard r)); xN = contiguous ranges of equal modelled cost (default of --strong), dealt_x8 = glyphs dealt out by modelled cost; "
                    "measured multi-GPU: bench.py --strong --gpus N")
     return res
 
@@ -407,8 +406,8 @@ def main():
     ap.add_argument("--strong", action="store_true", help="BASELINE config 4 as stated: ONE 8192-glyph 48x48 msdf atlas (--strong-set) glyph-sharded over "
                                                            "--gpus ranks (strong scaling: total work fixed); with --gpus 1 also the one-GPU rehearsal of the N-way splits")
     ap.add_argument("--strong-set", default="cjk_like", choices=["cjk_like", "dejavu"])
-    ap.add_argument("--strong-cut", default="dealt", choices=["dealt", "contiguous"],
-                    help="--strong: glyphs in order of modelled cost dealt out to the ranks (every shard the same mix), or contiguous ranges of equal modelled cost")
+    ap.add_argument("--strong-cut", default="contiguous", choices=["contiguous", "dealt"],
+                    help="--strong: contiguous ranges of equal modelled cost, or glyphs in order of modelled cost dealt out to the ranks (every shard the same mix)")
     ap.add_argument("--inprocess", action="store_true", help="one process drives all --gpus devices through msdfhip_generate_sharded (end to end; prints its own JSON line)")
     args = ap.parse_args()
 

@@ -59,19 +59,30 @@ struct WaveCtx {
     }
 };
 
-// The first edgeBlocks workgroups digest one edge per thread; the workgroups after them compute the contour windings, 64 contours per wavefront
-// with lanes = edges (contourWindingsWave; k_windings' job, folded into the same launch: the single-shape entry points are launch-latency bound).
-// blockDim.x = 256.
+// The first edgeBlocks workgroups digest one edge per thread; the workgroups after them compute the contour windings (k_windings' job, folded
+// into the same launch: the single-shape entry points are launch-latency bound): a lane per contour, except that contours of at least
+// PREP_WINDING_WAVE_MIN_EDGES edges -- whose serial walk by one lane would be the tail of the whole launch -- are taken by their wavefront together,
+// lanes = edges (contourWindingsWave). (All of a wavefront's 64 contours that way was measured SLOWER than a lane each: 0.154 vs 0.097 ms on the bench
+// workload -- ten rounds of loads and ~600 ordered additions per wavefront where most contours have ten edges.) blockDim.x = 256.
 __global__ void k_prep_records(EdgeRec *recs, int nEdges, int nContours, const int32_t *contourOffsets,
                                const double *points, const uint8_t *types, const uint8_t *colors, int8_t *windings, int edgeBlocks) {
     if ((int) blockIdx.x >= edgeBlocks) {
         __shared__ double terms[4][64];
-        const int wave = threadIdx.x>>6;
+        const int wave = threadIdx.x>>6, lane = threadIdx.x&63;
         const int cBegin = ((int) blockIdx.x-edgeBlocks)*256+64*wave;
-        if (cBegin < nContours) {
-            WaveCtx ctx;
-            ctx.lane = threadIdx.x&63;
-            contourWindingsWave(ctx, terms[wave], cBegin, cBegin+64 < nContours ? cBegin+64 : nContours, contourOffsets, points, types, colors, windings);
+        if (cBegin >= nContours)
+            return;
+        const int c = cBegin+lane;
+        const bool isLong = c < nContours && contourOffsets[c+1]-contourOffsets[c] >= PREP_WINDING_WAVE_MIN_EDGES;
+        if (c < nContours && !isLong)
+            windings[c] = (int8_t) contourWinding(c, contourOffsets, points, types, colors);
+        unsigned long long longMask = __ballot(isLong);
+        WaveCtx ctx;
+        ctx.lane = lane;
+        while (longMask) {
+            const int k = __builtin_ctzll(longMask);
+            longMask &= longMask-1;
+            contourWindingsWave(ctx, terms[wave], cBegin+k, cBegin+k+1, contourOffsets, points, types, colors, windings);
         }
         return;
     }

@@ -1,5 +1,5 @@
 """Glyph-sharded multi-GPU execution: one process per GPU, a static split of the glyph list (contiguous ranges of equal modelled cost; for
-strong scaling of ONE atlas optionally dealt: partition_dealt), no data-path collective.
+strong scaling of ONE atlas optionally dealt out by cost: partition_dealt), no data-path collective.
 
 Glyphs are independent units, so rank r simply renders glyphs [bounds[r], bounds[r+1]) on its own GPU.  The split is
 balanced by a per-glyph cost model fitted to measured kernel times (COST_MODEL below).  Outputs are byte-identical for any world size because no
@@ -61,10 +61,11 @@ def partition_contiguous(costs: Sequence[float], parts: int) -> np.ndarray:
 
 def partition_dealt(costs: Sequence[float], parts: int):
     """`parts` index lists (each ascending) that are statistically THE SAME shard: the glyphs in order of modelled cost, dealt out like cards in a
-    snake (0 .. N-1, N-1 .. 0, ...). For STRONG scaling of one atlas: a contiguous cut of a font balances the modelled sums but not what the model
-    does not see -- a 1 000-glyph launch ends with its heaviest glyphs, and a font's blocks differ (measured on the 8-way cut of the DejaVu set:
-    0.77 .. 1.21 ms per shard at equal modelled cost); dealt shards each get every N-th glyph of every weight. The output is a permutation
-    of the atlas order: `gather_tiles_indexed` puts the tiles back. Deterministic (stable sort)."""
+    snake (0 .. N-1, N-1 .. 0, ...). An alternative to the contiguous cut for STRONG scaling of one atlas (bench.py --strong-cut dealt): every shard
+    gets every N-th glyph of every weight, whatever the font's blocks look like. Measured on one MI355X (8-way cut of the 8 192-glyph DejaVu set,
+    every shard alone): 0.90-1.22 ms per shard against 0.83-1.23 ms for the contiguous cut -- the spread between 1 000-glyph shards is NOT their
+    content, so the contiguous cut stays the default. The output is a permutation of the atlas order: `gather_tiles_indexed` puts
+    the tiles back. Deterministic (stable sort)."""
     costs = np.asarray(costs, np.float64)
     order = np.argsort(-costs, kind="stable")
     k = np.arange(len(order))

@@ -37,11 +37,15 @@ class Emu:
         c8 = np.ascontiguousarray(s.colors, np.uint8)
         return (co, pts, t8, c8), (s.n_contours, _p(co, C.c_int32), _p(pts, C.c_double), _p(t8, C.c_uint8), _p(c8, C.c_uint8))
 
-    def windings(self, s, wave=False):
-        """wave: the form the digest kernels run since round 4 (contourWindingsWave: lanes = edges, ordered sums), else a contour per lane."""
+    def windings(self, s, wave=None):
+        """wave: the forms the digest kernels run since round 4 (contourWindingsWave: lanes = edges, ordered sums) -- "single" = k_single_call's (all
+        contours in one cooperative walk), "batch" = k_prep_records' (a lane per contour, long contours by the wavefront together); None: a contour per lane."""
         keep, args = self._shape(s)
         out = np.zeros(max(s.n_contours, 1), np.int32)
-        (self.lib.emu_windings_wave if wave else self.lib.emu_windings)(*args, _p(out, C.c_int32))
+        if wave:
+            self.lib.emu_windings_wave(*args, _p(out, C.c_int32), {"single": 0, "batch": 1}[wave])
+        else:
+            self.lib.emu_windings(*args, _p(out, C.c_int32))
         return out[:s.n_contours]
 
     def shape_distance(self, s, sel, overlap, pts):

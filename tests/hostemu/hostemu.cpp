@@ -258,14 +258,31 @@ void emu_windings(int nC, const int32_t *co, const double *points, const uint8_t
         out[c] = d.windings[c];
 }
 
-// The winding part of k_prep_records as it runs since round 4: 64 contours per "wavefront", lanes = edges, the sums in edge order
-// (contourWindingsWave with the 64-lane context above).
-void emu_windings_wave(int nC, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors, int32_t *out) {
+// The windings as the digest kernels compute them since round 4 (contourWindingsWave with the 64-lane context above). form 0: k_single_call -- all
+// contours of the shape in one cooperative walk; form 1: k_prep_records -- 64 contours per "wavefront", a lane each (contourWinding) except the long
+// ones, which the wavefront walks together one after the other.
+void emu_windings_wave(int nC, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors, int32_t *out, int form) {
     std::vector<int8_t> w((size_t) nC+1, (int8_t) 99);
     EmuWaveCtx ctx;
     double terms[64];
-    for (int cBegin = 0; cBegin < nC; cBegin += 64)
-        contourWindingsWave(ctx, terms, cBegin, std::min(cBegin+64, nC), co, points, types, colors, w.data());
+    if (form == 0)
+        contourWindingsWave(ctx, terms, 0, nC, co, points, types, colors, w.data());
+    else
+        for (int cBegin = 0; cBegin < nC; cBegin += 64) {
+            unsigned long long longMask = 0;
+            for (int lane = 0; lane < 64 && cBegin+lane < nC; ++lane) {
+                const int c = cBegin+lane;
+                if (co[c+1]-co[c] >= PREP_WINDING_WAVE_MIN_EDGES)
+                    longMask |= 1ull<<lane;
+                else
+                    w[c] = (int8_t) contourWinding(c, co, points, types, colors);
+            }
+            while (longMask) {
+                const int k = __builtin_ctzll(longMask);
+                longMask &= longMask-1;
+                contourWindingsWave(ctx, terms, cBegin+k, cBegin+k+1, co, points, types, colors, w.data());
+            }
+        }
     for (int c = 0; c < nC; ++c)
         out[c] = w[c];
 }

@@ -104,7 +104,7 @@ def winding_stress_shapes(seed):
 
 def test_wave_form_of_the_contour_windings_matches_oracle(emu, oracle, latin):
     """Round 4: the digest kernels compute Contour::winding with lanes = edges and a wave-uniform pass that adds the shoelace terms in edge order
-    (msdf_prep.hpp: contourWindingsWave), 64 contours per wavefront in k_prep_records, all of a shape's in k_single_call. The same source with a
+    (msdf_prep.hpp: contourWindingsWave): all of a shape's contours in k_single_call, the long ones in k_prep_records (a lane per contour otherwise). The same source with a
     64-lane context on the host against the oracle: fonts, contours of hundreds of edges, > 64 contours per shape (several wavefronts, contours
     ending at and across the 64-edge rounds), empty / one-edge / two-edge contours in between, and contours of (almost) no area, where the
     ORDER of the sum decides the sign."""
@@ -113,7 +113,8 @@ def test_wave_form_of_the_contour_windings_matches_oracle(emu, oracle, latin):
     zero = both = 0
     for s in shapes:
         want = oracle.windings(s)
-        assert (emu.windings(s, wave=True) == want).all(), (s.n_contours, s.n_edges)
+        for form in ("single", "batch"):
+            assert (emu.windings(s, wave=form) == want).all(), (form, s.n_contours, s.n_edges)
         zero += int((want == 0).sum())
         both += int((want > 0).any() and (want < 0).any())
     assert zero >= 10 and both >= 30
@@ -131,7 +132,7 @@ def test_degenerate_inputs(emu, oracle):
         [(0, (.2, .2), (.8, .2)), (6, (.8, .2), (.8, .2)), (3, (.8, .2), (.5, .9)), (5, (.5, .9), (.2, .2))],
     ])
     xf = autoframe((0, 0, 2, 1.5), 20, 16, 2)
-    assert (emu.windings(s) == oracle.windings(s)).all() and (emu.windings(s, wave=True) == oracle.windings(s)).all()
+    assert (emu.windings(s) == oracle.windings(s)).all() and (emu.windings(s, wave="single") == oracle.windings(s)).all() and (emu.windings(s, wave="batch") == oracle.windings(s)).all()
     for mode in (1, 2, 3, 4):
         for ov in (True, False):
             assert_bit_equal(emu.generate(s, mode, 20, 16, xf, overlap=ov), oracle.generate(s, mode, 20, 16, xf, overlap=ov), "degenerate mode %d" % mode)

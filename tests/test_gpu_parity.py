@@ -739,8 +739,8 @@ def test_shape_preparation_on_device_matches_reference_fixture(oracle):
 
 def test_contour_windings_of_the_digest_kernels_vs_oracle(oracle):
     """Contour::winding as the digest computes it since round 4 (lanes = edges, ordered sums; msdf_prep.hpp: contourWindingsWave): a batch of shapes
-    with long contours, > 64 contours, empty / short contours and contours of almost no area through k_prep_records (64 contours per wavefront, the
-    ranges cut across glyphs), and each of the first 40 alone (its own upload)."""
+    with long contours, > 64 contours, empty / short contours and contours of almost no area through k_prep_records (a lane per contour, the long
+    ones by their wavefront together), and each of the first 40 alone (its own upload)."""
     from test_device_logic_host import winding_stress_shapes
     shapes = winding_stress_shapes(12)
     want = [oracle.windings(s) for s in shapes]
