@@ -705,8 +705,31 @@ extern "C" double emu_estimate_sdf_error(int N, const float *px, int w, int h, i
 // each contour's survivors nearest-first (order = 1: ascending cullUpperDistance at the tile centre) instead of in visit order.
 // out[0] = evaluations, out[1] = survivors of the tile cull, out[2] = tiles, out[3] = contour walks (tile x contour with >= 1 survivor),
 // out[4] = evaluations repeated by the second walks of the overlapping combiner, out[5] = tiles x passes that take a second walk.
+// STUDY ONLY (order & 0x100): a tighter lower bound of the distance to a QUADRATIC edge -- the curve lies in its control box AND in the slab between
+// its chord and the parallel through its apex (normal offset dot(p1-p0, n)/2), so the distance is at least the larger of the two bounds.
+static bool relevantWithSlab(const Selector<3> &s, const EdgeRec &e, V2 o) {
+    double bound2;
+    bool box = selEdgeRelevantBox(s, e, o, bound2);
+    if (box && e.type == 2) {
+        const V2 ch = e.PE()-e.P0();
+        const double len = sqrt(dot(ch, ch));
+        if (len > 0) {
+            const V2 n = mk(-ch.y/len, ch.x/len);
+            const double sp = dot(o-e.P0(), n), apex = .5*dot(e.P1()-e.P0(), n);
+            const double lo = apex < 0 ? apex : 0, hi = apex > 0 ? apex : 0;
+            double ds = lo-sp > sp-hi ? lo-sp : sp-hi;
+            ds = ds > 0 ? ds*(1-1e-9) : 0;
+            if (ds*ds > bound2)
+                box = false;
+        }
+    }
+    return box || selEdgeRelevantWedges<3>(e, o, bound2);
+}
+
 extern "C" void emu_wave_cost(int w, int h, int nC, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors,
                               const double *xf, int overlap, int order, long *out) {
+    const bool slab = (order&0x100) != 0;
+    order &= 0xff;
     Digest d = digest(nC, co, points, types, colors);
     Xform t = { xf[0], xf[1], xf[2], xf[3], xf[4], xf[5] };
     for (int ty = 0; ty < (h+7)/8; ++ty)
@@ -761,7 +784,7 @@ extern "C" void emu_wave_cost(int w, int h, int nC, const int32_t *co, const dou
                     int relevant = 0;
                     for (int l = 0; l < 64; ++l) {
                         const V2 p = unproject(t, mk(tx*8+(l&7)+.5, ty*8+(l>>3)+.5));
-                        relevant += selEdgeRelevant(sel[l], d.recs[i], p);
+                        relevant += slab ? relevantWithSlab(sel[l], d.recs[i], p) : selEdgeRelevant(sel[l], d.recs[i], p);
                     }
                     if (!relevant)
                         continue;

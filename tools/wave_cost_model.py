@@ -1,6 +1,6 @@
 """CPU cost model of k_distance's phase 2 (tools only): wave-level (tile, edge) evaluations with the product's cull + per-texel wave vote,
 through tests/hostemu's emu_wave_cost.  order: 0 visit order, 1 fully sorted nearest-first, 2 nearest moved to the front,
-16 / 64 sorted within phase-1 chunks of that many edges.
+16 / 64 sorted within phase-1 chunks of that many edges; + 256: STUDY of a tighter relevance bound for quadratic edges (chord-to-apex slab, hostemu.cpp: relevantWithSlab).
 
     python tools/wave_cost_model.py
 """
