@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MSDFHIP_ABI_VERSION 4
+#define MSDFHIP_ABI_VERSION 5
 
 /* mode: which generator (msdfgen.h:46-56) */
 #define MSDFHIP_MODE_SDF   1 /* generateSDF   msdfgen.h:47  (TrueDistanceSelector)          1 channel  */
@@ -225,6 +225,36 @@ int msdfhip_batch_generate_host(const MsdfHipBatch *batch, int mode, int width, 
  * `atlas`. The copy back is a quarter of the float tiles'. */
 int msdfhip_batch_generate_bytes_host(const MsdfHipBatch *batch, int mode, int width, int height, const MsdfHipGlyph *glyphs,
                                       uint8_t *atlas, size_t atlas_bytes, const MsdfHipConfig *cfg);
+/* STREAMED generation: shapes in, host bitmaps out, with everything in between overlapped -- SURVEY.md 8(d)'s end-to-end metric (host flatten + H2D +
+ * kernels incl. error correction + D2H into caller bitmaps) as ONE pipelined call. The two-step form above (msdfhip_batch_create, then
+ * msdfhip_batch_generate_host) flattens everything, uploads and digests everything, and only then starts the chunk pipeline; here the glyph list is cut
+ * into the pipeline's chunks first and the library's host threads flatten chunk k+1 / k+2 straight into pinned staging WHILE chunk k is uploaded, digested and
+ * rendered and chunk k-1 is copied back. Replaces a caller loop of generate*() calls over a list of shapes (core/msdfgen.cpp:52-76, README.md:133,
+ * main.cpp:1243-1275); the C++ shim's msdfgen_hip::generate*Batch() are built on it.
+ *
+ * MsdfHipShapeSource: how the library reads the caller's shape objects (for msdfgen: `const Shape &`, core/Shape.h:15-58 -- contours[i].edges[j]->type(),
+ * controlPoints(), color; core/edge-segments.h:28-31). Both callbacks are called from several library threads at once, each glyph exactly once per pass;
+ * they must only READ the shapes.
+ *   count(user, glyph, &n_contours, &n_edges)   cheap first pass over the whole list (sizes the chunks and the staging)
+ *   fill(user, glyph, edge_base, contour_end, points, types, colors)
+ *        contour_end int32[n_contours]: edge_base + the index one past contour c's last edge (edges of the glyph numbered from 0 in Shape order)
+ *        points double[n_edges*8], types uint8[n_edges] (1 linear, 2 quadratic, 3 cubic), colors uint8[n_edges]: as for msdfhip_generate above
+ *   The arrays handed to fill ARE the pinned staging: what fill writes is what the device reads, there is no intermediate copy.
+ * device: -1 = the process default. glyphs / out / atlas / stencil / cfg: exactly as msdfhip_batch_generate_host / _bytes_host (exactly one of out, atlas). */
+typedef struct MsdfHipShapeSource {
+    void *user;
+    void (*count)(void *user, int glyph, int32_t *n_contours, int32_t *n_edges);
+    void (*fill)(void *user, int glyph, int32_t edge_base, int32_t *contour_end, double *points, uint8_t *types, uint8_t *colors);
+} MsdfHipShapeSource;
+int msdfhip_generate_stream(int device, int mode, int width, int height, int n_glyphs, const MsdfHipShapeSource *source, const MsdfHipGlyph *glyphs,
+                            float *out, size_t out_floats, uint8_t *atlas, size_t atlas_bytes, uint8_t *stencil, const MsdfHipConfig *cfg);
+/* The same pipeline over HOST CSR arrays (the arguments of msdfhip_batch_create): upload and digest go chunk by chunk under the kernels instead of in front. */
+int msdfhip_generate_stream_csr(int device, int mode, int width, int height, int n_glyphs, const int32_t *glyph_contour_offsets, const int32_t *contour_offsets,
+                                const double *points, const uint8_t *types, const uint8_t *colors, const MsdfHipGlyph *glyphs,
+                                float *out, size_t out_floats, uint8_t *atlas, size_t atlas_bytes, uint8_t *stencil, const MsdfHipConfig *cfg);
+/* Host threads of the streamed generator's flatten pool, incl. the calling thread (0 = the usable cores -- affinity mask and cgroup quota --, at most 32; also
+ * MSDFHIP_HOST_THREADS). The pool is created on first use: returns 0 when the value was taken, else the size of the pool that already exists. */
+int msdfhip_set_host_threads(int threads);
 /* Glyphs per pipeline chunk (0 = automatic: about 96 MB of float tiles). */
 int msdfhip_set_pipeline_chunk(int glyphs_per_chunk);
 /* Pinned (page-locked, portable across devices) host memory for outputs of the two functions above. */
@@ -321,6 +351,13 @@ int msdfhip_debug_wait_profile(unsigned long long *out24, int reset);
  * digest | its own distance tile | waiting for all tiles (grid barrier) | its own correction sweep | waiting for all sweeps | distance checks,
  * out8[7] = start of workgroup 0 to the last workgroup's end. Diagnostics (tools/host_call_latency.py). */
 int msdfhip_debug_single_call_phases(double *out8, int reset);
+
+/* The one-launch form of a single-shape call (k_single_call) needs all its workgroups resident at once. Calls that would not fit next to the fused
+ * launches already in flight take the batched launch sequence instead (*refused); a launch that still finds the device occupied -- a persistent
+ * kernel of another thread or process holds the slots -- gives up at its grid barrier after a bounded wait (*barrier_timeouts) and is rerun through the
+ * batched sequence, as is one that ended without its completion flag (*lost_flags). The caller's generate*() succeeds either way
+ * (core/msdfgen.cpp:78-106 cannot fail); these counters only say how often the slow road was taken since the last reset. Any pointer may be NULL. */
+int msdfhip_single_call_fallbacks(unsigned long long *barrier_timeouts, unsigned long long *lost_flags, unsigned long long *refused, int reset);
 
 #ifdef __cplusplus
 }

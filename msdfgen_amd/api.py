@@ -600,3 +600,30 @@ def generate_sharded(devices, shapes: ShapeBatch, mode, width, height, xfs, out=
                                                     out.ctypes.data if out is not None else None, out.size if out is not None else 0,
                                                     atlas.ctypes.data if atlas is not None else None, atlas.size if atlas is not None else 0, C.byref(cfg)))
     return out if out is not None else atlas
+
+
+def generate_stream(shapes: ShapeBatch, mode, width, height, xfs, out=None, atlas=None, out_offsets=None, row_stride=None, config=None, stencil=None,
+                    y_orientation=Y_UPWARD, device=-1):
+    """msdfhip_generate_stream_csr: host CSR arrays in, host tiles (float32 `out`) or an 8-bit `atlas` out, as ONE pipelined call -- the glyph list is cut
+    into chunks and chunk k+1's staging + upload + digest run under chunk k's kernels and chunk k-1's copy back (SURVEY.md 8d's end-to-end metric;
+    msdfgen_hip::generate*Batch() of the C++ shim is the same pipeline fed from msdfgen::Shape objects)."""
+    n = CHANNELS[mode]
+    tile = width*height*n
+    if out is None and atlas is None:
+        out = np.zeros((shapes.n_glyphs, height, width, n), np.float32)
+    d = _descriptors_host(shapes, xfs, np.arange(shapes.n_glyphs, dtype=np.int64)*tile if out_offsets is None else out_offsets,
+                          width*n if row_stride is None else row_stride, y_orientation)
+    cfg = _c_config(config if config is not None else (MSDFGeneratorConfig() if mode >= 3 else GeneratorConfig()), y_orientation)
+    gco = np.ascontiguousarray(shapes.glyph_contour_offsets, np.int32)
+    co = np.ascontiguousarray(shapes.contour_offsets, np.int32)
+    pts = np.ascontiguousarray(shapes.points, np.float64).reshape(-1, 8)
+    types = np.ascontiguousarray(shapes.types, np.uint8)
+    colors = np.ascontiguousarray(shapes.colors, np.uint8)
+    if stencil is not None:
+        assert stencil.dtype == np.uint8 and stencil.flags.c_contiguous and stencil.size >= shapes.n_glyphs*width*height
+    _lib.check(_lib.load().msdfhip_generate_stream_csr(int(device), mode, width, height, shapes.n_glyphs, _lib.ptr(gco, _lib._ip), _lib.ptr(co, _lib._ip),
+                                                       _lib.ptr(pts, _lib._dp), _lib.ptr(types, _lib._bp), _lib.ptr(colors, _lib._bp), d.ctypes.data,
+                                                       out.ctypes.data if out is not None else None, out.size if out is not None else 0,
+                                                       atlas.ctypes.data if atlas is not None else None, atlas.size if atlas is not None else 0,
+                                                       stencil.ctypes.data if stencil is not None else None, C.byref(cfg)))
+    return out if out is not None else atlas

@@ -13,10 +13,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <sched.h>
 
 #include "msdf_kernels.hpp"
 #include "msdf_single.hpp"
@@ -76,6 +81,11 @@ struct Tuning {
     long shortRounds;                // MSDFHIP_SHORT_ROUNDS        LDS-class launches of fewer rounds of four-tile wavefronts take one tile per wavefront
     long smallLaunchTiles;           // MSDFHIP_SMALL_LAUNCH_TILES  launches of at most this many tiles take one tile per wavefront (latency-shaped form)
     char devices[256];               // MSDFHIP_DEVICES             "all" | "0,1,..." devices the single-shape front door spreads over
+    int smallMaxEdges;               // MSDFHIP_SMALL_MAX_EDGES     glyphs of the LDS-scratch class have at most this many edges (128)
+    int ldsClassTpw;                 // MSDFHIP_LDS_CLASS_TPW       tiles per wavefront of the LDS-scratch class: 4 (default; 1 in short launches) or always 1
+    int hostThreads;                 // MSDFHIP_HOST_THREADS        host threads of the streamed generator's flatten pool (0 = the usable cores, at most 32); read when the pool is created
+    long singleSpinLimit;            // MSDFHIP_SINGLE_SPIN_LIMIT   tests: iterations k_single_call's grid barrier waits before it gives up (0 = scaled with the shape)
+    bool singleVerbose;              // MSDFHIP_SINGLE_VERBOSE      report abandoned fused launches on stderr
 };
 // Published through an atomic pointer: msdfhip_reload_tuning() builds a fresh table and swaps it in while launch paths on other threads keep
 // reading the one they loaded. Superseded tables stay alive -- a thread may still hold a reference -- in gTuningTables (a few hundred bytes per
@@ -120,6 +130,11 @@ void readTuning() {
     t.smallLaunchTiles = (env = getenv("MSDFHIP_SMALL_LAUNCH_TILES")) ? atol(env) : 8192;
     if ((env = getenv("MSDFHIP_DEVICES")))
         snprintf(t.devices, sizeof(t.devices), "%s", env);
+    t.smallMaxEdges = (env = getenv("MSDFHIP_SMALL_MAX_EDGES")) && atoi(env) > 0 ? atoi(env) : 128;
+    t.ldsClassTpw = (env = getenv("MSDFHIP_LDS_CLASS_TPW")) && atoi(env) == 1 ? 1 : 4;
+    t.hostThreads = (env = getenv("MSDFHIP_HOST_THREADS")) && atoi(env) > 0 ? atoi(env) : 0;
+    t.singleSpinLimit = (env = getenv("MSDFHIP_SINGLE_SPIN_LIMIT")) && atol(env) > 0 ? atol(env) : 0;
+    t.singleVerbose = getenv("MSDFHIP_SINGLE_VERBOSE") != NULL;
     gTuningTables.push_back(&t);                                 // (callers hold gTuningMutex)
     gTuning.store(&t, std::memory_order_release);
 }
@@ -314,7 +329,7 @@ int digest(MsdfHipBatch *b, hipStream_t stream) {
 // LDS plan for a launch: bytes of dynamic LDS, the stride of the per-tile survivor lists, and where the combiner scratch lives.
 struct LdsPlan { size_t bytes; bool globalRes; size_t resBytes, ldsBudget, idxBytes; int listStride; };
 const size_t GRES_WORKSPACE_CAP = (size_t) 1<<30;   // bound of the global combiner scratch; larger launches are chunked
-const int SMALL_MAX_EDGES = 128;                    // glyphs of the LDS-scratch class have at most this many edges (bounds their survivor lists)
+const int SMALL_MAX_EDGES = 128;                    // cost model only: the edge bound of the LDS-scratch class (tuning().smallMaxEdges is what the launches use)
 const int COST_LDS_MAX_CONTOURS = 7;                // cost model only: the LDS class's contour bound at the default LDS budget, msdf (ensureBuckets derives the real one per launch)
 
 // SIMDs of a device (4 per compute unit): the number of wavefronts of a W-waves-per-SIMD kernel it holds at once is residentSlots()*W.
@@ -486,7 +501,8 @@ static double glyphCost(int contours, int edges) {
 //   rest   more: per-contour distances in the global workspace.
 int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(b->scratchMutex);
-    if (b->bucketLimit == limit && b->dBucket)
+    const int bucketKey = limit+(tuning().smallMaxEdges<<12);    // what the class lists depend on
+    if (b->bucketLimit == bucketKey && b->dBucket)
         return MSDFHIP_OK;
     if ((b->hContours.empty() || b->hEdges.empty()) && b->nGlyphs > 0) {   // batch created from device arrays: read the offsets back once
         std::vector<int32_t> gco((size_t) b->nGlyphs+1), co((size_t) b->nContours+1);
@@ -511,6 +527,7 @@ int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
     // A glyph whose survivor lists do not fit a CU's LDS (edges + 4 contours > ~40 000) takes the list-free kernel -- ALONE: round 3 sent the whole
     // batch there with it. Such glyphs go last in the list, whatever their contour count; the three classes are formed of the others.
     const size_t ldsLimit = (size_t) gLdsLimit.load();
+    const int smallMaxEdges = tuning().smallMaxEdges;
     auto huge = [b, ldsLimit](int g) { return tileListBytes(b->hEdges[g], b->hContours[g], true) > ldsLimit; };
     for (int g = 0; g < b->nGlyphs; ++g)
         if (!huge(g) && b->hContours[g] <= 1) {
@@ -519,14 +536,14 @@ int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
         }
     nOne = at;
     for (int g = 0; g < b->nGlyphs; ++g)
-        if (!huge(g) && b->hContours[g] > 1 && b->hContours[g] <= limit && b->hEdges[g] <= SMALL_MAX_EDGES) {
+        if (!huge(g) && b->hContours[g] > 1 && b->hContours[g] <= limit && b->hEdges[g] <= smallMaxEdges) {
             order[at++] = g;
             smallMaxC = b->hContours[g] > smallMaxC ? b->hContours[g] : smallMaxC;
             smallMaxE = b->hEdges[g] > smallMaxE ? b->hEdges[g] : smallMaxE;
         }
     nSmall = at-nOne;
     for (int g = 0; g < b->nGlyphs; ++g)
-        if (!huge(g) && b->hContours[g] > 1 && !(b->hContours[g] <= limit && b->hEdges[g] <= SMALL_MAX_EDGES)) {
+        if (!huge(g) && b->hContours[g] > 1 && !(b->hContours[g] <= limit && b->hEdges[g] <= smallMaxEdges)) {
             order[at++] = g;
             restMaxC = b->hContours[g] > restMaxC ? b->hContours[g] : restMaxC;
             restMaxE = b->hEdges[g] > restMaxE ? b->hEdges[g] : restMaxE;
@@ -558,7 +575,7 @@ int ensureBuckets(const MsdfHipBatch *b, int limit, hipStream_t stream) {
             rest += glyphCost(b->hContours[order[k]], b->hEdges[order[k]]);
         b->restShare = all > 0 ? (float) (rest/all) : 1.f;
     }
-    b->bucketLimit = limit, b->nOne = nOne, b->nSmall = nSmall, b->smallMaxC = smallMaxC, b->smallMaxE = smallMaxE, b->oneMaxE = oneMaxE;
+    b->bucketLimit = bucketKey, b->nOne = nOne, b->nSmall = nSmall, b->smallMaxC = smallMaxC, b->smallMaxE = smallMaxE, b->oneMaxE = oneMaxE;
     b->nHuge = at-nCulled, b->restMaxC = restMaxC, b->restMaxE = restMaxE;
     return MSDFHIP_OK;
 }
@@ -690,7 +707,8 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     int maxE = b->maxEdges, maxC = b->maxContours, nHuge = 0, rc = MSDFHIP_OK;
     const size_t perContourLds = (size_t) SelTraits<SEL>::NCH*WAVE*sizeof(double);
     int limitAll = 0;                                            // contours whose combiner scratch fits the per-wavefront LDS budget next to the lists of a SMALL_MAX_EDGES glyph
-    while ((size_t) (limitAll+1)*perContourLds+(size_t) QUAD*tileListBytes(SMALL_MAX_EDGES, limitAll+1, false) <= ldsBudget())
+    const int smallMaxEdges = tuning().smallMaxEdges, classTpw = tuning().ldsClassTpw == 1 ? 1 : (int) QUAD;
+    while ((size_t) (limitAll+1)*perContourLds+(size_t) classTpw*tileListBytes(smallMaxEdges, limitAll+1, false) <= ldsBudget())
         ++limitAll;
     if (hugeBatch) {
         rc = ensureBuckets(b, limitAll < 1 ? 1 : limitAll, stream);
@@ -742,7 +760,7 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
         return launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, single, stream);
     const int limit = limitAll;
     if (b->nGlyphs == 1) {                                       // the class is known, no index map
-        if (maxC <= limit && maxE <= SMALL_MAX_EDGES && !plan.globalRes)
+        if (maxC <= limit && maxE <= smallMaxEdges && !plan.globalRes)
             return launchDistance<SEL, true, false>(b, dGlyphs, w, h, dst, toScratch, plan, stream);
         return launchDistance<SEL, true, true>(b, dGlyphs, w, h, dst, toScratch, single, stream);
     }
@@ -798,7 +816,7 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
         // A launch of few rounds of wavefronts (a shard of an atlas: BASELINE config 4 over 8 GPUs leaves 1 024 glyphs per device) ends when its
         // last wavefronts do, and a wavefront of four tiles is four times as long: below shortRounds rounds the class takes one tile per wavefront.
         const size_t slots = (size_t) residentSlots(b->device)*4u*MSDF_DISTANCE_WAVES_PER_SIMD;
-        const bool shortLaunch = (size_t) b->nSmall*(size_t) ((tilesAll+QUAD-1)/QUAD) < (size_t) tuning().shortRounds*slots;
+        const bool shortLaunch = classTpw == 1 || (size_t) b->nSmall*(size_t) ((tilesAll+QUAD-1)/QUAD) < (size_t) tuning().shortRounds*slots;
         LdsPlan small;
         rc = planLds(b, SelTraits<SEL>::NCH, true, small, b->smallMaxC, b->smallMaxE, shortLaunch ? 1 : (int) QUAD);
         if (rc == MSDFHIP_OK)
@@ -1678,6 +1696,13 @@ struct PipeSlot {
     int pendingFirst, pendingCount;   // the chunk waiting in pinnedTiles for its scatter
     int viewCap;                      // glyphs the view's per-glyph work buffers (class lists, correction constants) were sized for
     MsdfHipBatch view;                // glyph range of the parent batch + this slot's own work buffers
+    // streamed calls (msdfhip_generate_stream): the chunk's own inputs
+    char *pinnedIn;                   // pinned staging the host threads flatten the chunk's shapes into: [gco | co | points | types | colors]
+    size_t pinnedInCap;
+    char *devIn;                      // the same on the device, followed by the chunk's records and windings
+    size_t devInCap;
+    hipEvent_t inputsUploaded;        // the chunk's upload has left pinnedIn
+    bool inputsInFlight;
 };
 
 // The slots of a pipeline in flight. Pipelines live in a process-wide pool per device (like the arenas of the single-shape calls):
@@ -1728,6 +1753,7 @@ struct PipeLease {
             PipeSlot &s = fresh->slot[k];
             s.stream = NULL, s.done = NULL, s.kernelsDone = NULL, s.busy = false, s.dev = NULL, s.devCap = 0, s.pinnedGlyphs = NULL, s.pinnedGlyphCap = 0, s.viewCap = 0;
             s.pinnedTiles = NULL, s.pinnedTilesCap = 0, s.pendingFirst = 0, s.pendingCount = 0;
+            s.pinnedIn = NULL, s.pinnedInCap = 0, s.devIn = NULL, s.devInCap = 0, s.inputsUploaded = NULL, s.inputsInFlight = false;
         }
         for (int k = 0; k < PIPE_SLOTS; ++k) {                   // a half-built pipe never reaches the pool
             hipError_t e = k == 0 ? hipStreamCreateWithFlags(&fresh->compute, hipStreamNonBlocking) : hipSuccess;
@@ -1737,6 +1763,8 @@ struct PipeLease {
                 e = hipEventCreateWithFlags(&fresh->slot[k].done, hipEventDisableTiming);
             if (e == hipSuccess)
                 e = hipEventCreateWithFlags(&fresh->slot[k].kernelsDone, hipEventDisableTiming);
+            if (e == hipSuccess)
+                e = hipEventCreateWithFlags(&fresh->slot[k].inputsUploaded, hipEventDisableTiming);
             if (e != hipSuccess) {
                 (void) hipGetLastError();
                 destroyPipe(fresh);
@@ -1785,6 +1813,308 @@ static int fetchGlyphCounts(const MsdfHipBatch *b) {             // device-array
 
 static std::atomic<int> gPipeChunkGlyphs(0);                     // 0 = automatic (about 96 MB of float tiles per chunk)
 
+struct Carver {                                                  // 256-byte aligned sub-allocation inside an arena
+    size_t off;
+    Carver() : off(0) { }
+    size_t take(size_t bytes) { const size_t at = off; off += (bytes+255)/256*256; return at; }
+};
+
+// ---- host threads of the streamed generator (msdfhip_generate_stream): a small persistent pool that flattens the NEXT chunk's shapes into pinned staging
+// while the device works on the chunks before it. Jobs are index ranges; whoever waits for a job helps to finish it. Created on first use, lives as long
+// as the process (reachable through gHostPool; its idle threads sleep on a condition variable).
+static int usableCores() {
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0)
+        n = CPU_COUNT(&set);
+    if (n <= 0)
+        n = (int) std::thread::hardware_concurrency();
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {       // cgroup v2 quota: "max 100000" or "<quota> <period>"
+        long long quota = 0, period = 0;
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+            const int q = (int) ((quota+period-1)/period);
+            n = q < n ? q : n;
+        }
+        fclose(f);
+    }
+    return n < 1 ? 1 : n;
+}
+
+struct HostJob {
+    std::function<void(int)> fn;
+    int count;
+    std::atomic<int> next, done;
+    std::mutex m;
+    std::condition_variable cv;
+    HostJob() : count(0), next(0), done(0) { }
+};
+
+class HostPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<HostJob> > queue;
+    std::vector<std::thread> workers;
+    static void runItems(HostJob &job) {
+        for (int i; (i = job.next.fetch_add(1)) < job.count; ) {
+            job.fn(i);
+            if (job.done.fetch_add(1)+1 == job.count) {
+                std::lock_guard<std::mutex> lock(job.m);
+                job.cv.notify_all();
+            }
+        }
+    }
+    void loop() {
+        for (;;) {
+            std::shared_ptr<HostJob> job;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                for (;;) {
+                    while (!queue.empty() && queue.front()->next.load() >= queue.front()->count)
+                        queue.pop_front();                       // all its items are taken: nothing left to start
+                    if (!queue.empty())
+                        break;
+                    cv.wait(lock);
+                }
+                job = queue.front();
+            }
+            runItems(*job);
+        }
+    }
+public:
+    explicit HostPool(int threads) {
+        for (int t = 0; t < threads; ++t) {
+            workers.push_back(std::thread([this]() { loop(); }));
+            workers.back().detach();
+        }
+    }
+    int threads() const { return (int) workers.size(); }
+    std::shared_ptr<HostJob> submit(int count, std::function<void(int)> fn) {
+        std::shared_ptr<HostJob> job = std::make_shared<HostJob>();
+        job->fn = fn, job->count = count;
+        if (count > 0) {
+            std::lock_guard<std::mutex> lock(mu);
+            queue.push_back(job);
+            cv.notify_all();
+        }
+        return job;
+    }
+    static void wait(HostJob &job) {                             // the waiting thread takes items too
+        runItems(job);
+        std::unique_lock<std::mutex> lock(job.m);
+        while (job.done.load() < job.count)
+            job.cv.wait(lock);
+    }
+};
+static std::mutex gHostPoolMutex;
+static HostPool *gHostPool = NULL;
+static std::atomic<int> gHostThreads(0);                         // msdfhip_set_host_threads / MSDFHIP_HOST_THREADS; 0 = the usable cores (at most 32)
+static HostPool &hostPool() {
+    std::lock_guard<std::mutex> lock(gHostPoolMutex);
+    if (!gHostPool) {
+        int n = gHostThreads.load();
+        if (n <= 0)
+            n = tuning().hostThreads > 0 ? tuning().hostThreads : usableCores();
+        n = n > 32 ? 32 : n;
+        gHostPool = new HostPool(n > 1 ? n-1 : 0);               // the caller's thread works too
+    }
+    return *gHostPool;
+}
+
+// Where the chunks of a host-output call come from. A resident batch (msdfhip_batch_generate_host): a chunk is a view of the batch's arrays. A shape
+// source (msdfhip_generate_stream): a chunk is flattened by the host threads into the slot's pinned staging, uploaded and digested on the slot's stream
+// -- while the device works on the chunks before it.
+struct ChunkFeeder {
+    virtual ~ChunkFeeder() { }
+    virtual int begin(PipeSlot *slots, const std::vector<int> &lengths) = 0;
+    virtual int prepare(PipeSlot &p, int slot, size_t chunkIndex, int g0, int n, hipStream_t stream) = 0;
+};
+
+struct ResidentFeeder : ChunkFeeder {
+    const MsdfHipBatch *b;
+    explicit ResidentFeeder(const MsdfHipBatch *batch) : b(batch) { }
+    int begin(PipeSlot *, const std::vector<int> &) { return MSDFHIP_OK; }
+    int prepare(PipeSlot &p, int, size_t, int g0, int n, hipStream_t) {
+        sliceBatch(b, p.view, g0, n);
+        return MSDFHIP_OK;
+    }
+};
+
+// The shapes of a streamed call, as counted up front (one cheap pass over the caller's objects: contours per glyph, edges per glyph).
+struct StreamFeeder : ChunkFeeder {
+    const MsdfHipShapeSource *src;
+    int nG;
+    std::vector<int> hContours, hEdges;                          // per glyph
+    std::vector<long long> contourBase, edgeBase;                // prefix sums over the whole list (nG+1)
+    std::vector<int> chunkStart, chunkLen;
+    std::vector<std::shared_ptr<HostJob> > jobs;                 // flatten job of chunk k
+    std::vector<int> badType;                                    // per chunk: a glyph whose fill produced an edge type outside 1..3 (-1: none)
+    PipeSlot *slots;
+    enum { GRAIN = 32 };                                         // glyphs per flatten item
+
+    StreamFeeder(const MsdfHipShapeSource *source, int n) : src(source), nG(n), slots(NULL) { }
+
+    int count() {                                                // parallel over the glyphs; then the prefix sums
+        hContours.assign((size_t) nG, 0), hEdges.assign((size_t) nG, 0);
+        const int items = (nG+255)/256;
+        std::atomic<int> bad(-1);
+        std::shared_ptr<HostJob> job = hostPool().submit(items, [this, &bad](int it) {
+            const int g1 = (it+1)*256 < nG ? (it+1)*256 : nG;
+            for (int g = it*256; g < g1; ++g) {
+                int32_t c = 0, e = 0;
+                src->count(src->user, g, &c, &e);
+                if (c < 0 || e < 0 || (c == 0 && e != 0))
+                    bad.store(g);
+                hContours[(size_t) g] = c, hEdges[(size_t) g] = e;
+            }
+        });
+        HostPool::wait(*job);
+        if (bad.load() >= 0)
+            return fail(MSDFHIP_ERR_INVALID, "shape source: glyph %d reports %d contours / %d edges", bad.load(), hContours[(size_t) bad.load()], hEdges[(size_t) bad.load()]);
+        contourBase.assign((size_t) nG+1, 0), edgeBase.assign((size_t) nG+1, 0);
+        for (int g = 0; g < nG; ++g) {
+            contourBase[(size_t) g+1] = contourBase[(size_t) g]+hContours[(size_t) g];
+            edgeBase[(size_t) g+1] = edgeBase[(size_t) g]+hEdges[(size_t) g];
+        }
+        return MSDFHIP_OK;
+    }
+
+    // layout of a chunk's inputs inside a slot's staging / device input area (offsets from the area's start)
+    struct Layout { size_t gco, co, points, types, colors, bytes; };
+    static Layout layout(size_t n, size_t nC, size_t nE) {
+        Carver c;
+        Layout l;
+        l.gco = c.take((n+1)*sizeof(int32_t)), l.co = c.take((nC+1)*sizeof(int32_t)), l.points = c.take((nE ? nE : 1)*8*sizeof(double));
+        l.types = c.take(nE ? nE : 1), l.colors = c.take(nE ? nE : 1), l.bytes = c.off;
+        return l;
+    }
+
+    void flattenItem(size_t ci, int item) {
+        const int g0 = chunkStart[ci], n = chunkLen[ci];
+        PipeSlot &p = slots[ci%PIPE_SLOTS];
+        const long long c0 = contourBase[(size_t) g0], e0 = edgeBase[(size_t) g0];
+        const Layout l = layout((size_t) n, (size_t) (contourBase[(size_t) g0+n]-c0), (size_t) (edgeBase[(size_t) g0+n]-e0));
+        int32_t *gco = reinterpret_cast<int32_t *>(p.pinnedIn+l.gco), *co = reinterpret_cast<int32_t *>(p.pinnedIn+l.co);
+        double *points = reinterpret_cast<double *>(p.pinnedIn+l.points);
+        uint8_t *types = reinterpret_cast<uint8_t *>(p.pinnedIn+l.types), *colors = reinterpret_cast<uint8_t *>(p.pinnedIn+l.colors);
+        const int first = item*GRAIN, last = first+GRAIN < n ? first+GRAIN : n;
+        if (item == 0)
+            gco[0] = 0, co[0] = 0;
+        for (int k = first; k < last; ++k) {
+            const int g = g0+k;
+            const int32_t cRel = (int32_t) (contourBase[(size_t) g]-c0), eRel = (int32_t) (edgeBase[(size_t) g]-e0);
+            const int nC = hContours[(size_t) g], nE = hEdges[(size_t) g];
+            gco[k+1] = cRel+nC;
+            if (nC > 0) {
+                src->fill(src->user, g, eRel, co+cRel+1, points+(size_t) eRel*8, types+eRel, colors+eRel);
+                bool ok = co[cRel+nC] == eRel+nE;                // the source must deliver what it counted
+                for (int c = 0; c < nC && ok; ++c)
+                    ok = co[cRel+1+c] >= (c ? co[cRel+c] : eRel);
+                for (int e = 0; e < nE && ok; ++e)
+                    ok = types[eRel+e] >= 1 && types[eRel+e] <= 3;
+                if (!ok)
+                    badType[ci] = g;                             // (any thread may write it: one int, the value only says which glyph to name)
+            }
+        }
+    }
+
+    void startFlatten(size_t ci) {
+        if (ci >= chunkLen.size() || jobs[ci])
+            return;
+        const int items = (chunkLen[ci]+GRAIN-1)/GRAIN;
+        jobs[ci] = hostPool().submit(items, [this, ci](int item) { flattenItem(ci, item); });
+    }
+
+    int begin(PipeSlot *pipeSlots, const std::vector<int> &lengths) {
+        slots = pipeSlots;
+        chunkStart.clear(), chunkLen = lengths;
+        int g = 0;
+        size_t needIn = 0, needC = 0, needE = 0;
+        for (size_t ci = 0; ci < lengths.size(); g += lengths[ci], ++ci) {
+            chunkStart.push_back(g);
+            const size_t nC = (size_t) (contourBase[(size_t) g+lengths[ci]]-contourBase[(size_t) g]), nE = (size_t) (edgeBase[(size_t) g+lengths[ci]]-edgeBase[(size_t) g]);
+            if (nE > 0x7fffffffull/8 || nC > 0x7fffffffull/8)
+                return fail(MSDFHIP_ERR_INVALID, "a pipeline chunk of %d glyphs holds %zu edges / %zu contours: beyond the 32-bit offsets of a batch", lengths[ci], nE, nC);
+            const Layout l = layout((size_t) lengths[ci], nC, nE);
+            needIn = l.bytes > needIn ? l.bytes : needIn, needC = nC > needC ? nC : needC, needE = nE > needE ? nE : needE;
+        }
+        jobs.assign(lengths.size(), std::shared_ptr<HostJob>());
+        badType.assign(lengths.size(), -1);
+        const size_t recBytes = (sizeof(EdgeRec)*(needE ? needE : 1)+255)/256*256, devNeed = needIn+recBytes+(needC ? needC : 1)+256;
+        for (int k = 0; k < PIPE_SLOTS; ++k) {                   // every slot can take the largest chunk (grown once, kept with the pooled pipe)
+            PipeSlot &p = slots[k];
+            if (p.pinnedInCap < needIn) {
+                if (p.pinnedIn)
+                    HIPCHK(pinnedFree(p.pinnedIn));
+                p.pinnedIn = NULL, p.pinnedInCap = 0;
+                const size_t cap = needIn+needIn/4+4096;
+                HIPCHK(pinnedAlloc((void **) &p.pinnedIn, cap));
+                p.pinnedInCap = cap;
+            }
+            if (p.devInCap < devNeed) {
+                HIPCHK(hipStreamSynchronize(p.stream));
+                if (p.devIn)
+                    HIPCHK(hipFree(p.devIn));
+                p.devIn = NULL, p.devInCap = 0;
+                const size_t cap = devNeed+devNeed/4+4096;
+                HIPCHK(hipMalloc((void **) &p.devIn, cap));
+                p.devInCap = cap;
+            }
+            p.inputsInFlight = false;
+        }
+        for (size_t ci = 0; ci < lengths.size() && ci < 2; ++ci)     // two chunks ahead of the device from the start
+            startFlatten(ci);
+        return MSDFHIP_OK;
+    }
+
+    int prepare(PipeSlot &p, int slot, size_t ci, int g0, int n, hipStream_t stream) {
+        HostPool::wait(*jobs[ci]);
+        if (badType[ci] >= 0)
+            return fail(MSDFHIP_ERR_INVALID, "shape source: glyph %d did not deliver the contours / edges it counted, or an edge type outside 1..3", badType[ci]);
+        // the chunk after the next one goes into the staging of the slot that chunk ci-1... no: of chunk ci+2-PIPE_SLOTS -- its upload must have left it
+        const size_t ahead = ci+2;
+        if (ahead < chunkLen.size()) {
+            PipeSlot &q = slots[ahead%PIPE_SLOTS];
+            if (&q != &p && q.inputsInFlight) {
+                HIPCHK(hipEventSynchronize(q.inputsUploaded));
+                q.inputsInFlight = false;
+            }
+            if (&q != &p)
+                startFlatten(ahead);
+        }
+        const size_t nC = (size_t) (contourBase[(size_t) g0+n]-contourBase[(size_t) g0]), nE = (size_t) (edgeBase[(size_t) g0+n]-edgeBase[(size_t) g0]);
+        const Layout l = layout((size_t) n, nC, nE);
+        HIPCHK(hipMemcpyAsync(p.devIn, p.pinnedIn, l.bytes, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipEventRecord(p.inputsUploaded, stream));
+        p.inputsInFlight = true;
+        MsdfHipBatch &v = p.view;
+        v.device = currentDevice();
+        v.nGlyphs = n, v.nContours = (int) nC, v.nEdges = (int) nE;
+        v.ownsInputs = false;
+        v.dGlyphContourOffsets = reinterpret_cast<int32_t *>(p.devIn+l.gco), v.dContourOffsets = reinterpret_cast<int32_t *>(p.devIn+l.co);
+        v.dPoints = reinterpret_cast<double *>(p.devIn+l.points), v.dTypes = reinterpret_cast<uint8_t *>(p.devIn+l.types), v.dColors = reinterpret_cast<uint8_t *>(p.devIn+l.colors);
+        const size_t recOff = (l.bytes+255)/256*256;
+        v.dRecs = reinterpret_cast<EdgeRec *>(p.devIn+recOff);
+        v.dWindings = reinterpret_cast<int8_t *>(p.devIn+recOff+(sizeof(EdgeRec)*(nE ? nE : 1)+255)/256*256);
+        v.hContours.assign(hContours.begin()+g0, hContours.begin()+g0+n);
+        v.hEdges.assign(hEdges.begin()+g0, hEdges.begin()+g0+n);
+        int maxC = 0, maxE = 0;
+        for (int g = 0; g < n; ++g) {
+            maxC = v.hContours[(size_t) g] > maxC ? v.hContours[(size_t) g] : maxC;
+            maxE = v.hEdges[(size_t) g] > maxE ? v.hEdges[(size_t) g] : maxE;
+        }
+        v.maxContours = maxC, v.maxEdges = maxE;
+        v.bucketLimit = -1;
+        v.serialClasses = true;
+        if (ahead >= chunkLen.size() || &slots[ahead%PIPE_SLOTS] == &p) {
+            // (PIPE_SLOTS == 2 would put chunk ci+2 into THIS slot's staging: it is flattened when this chunk's upload has left it, see below)
+        }
+        return digest(&v, stream);
+    }
+
+    // chunk ci+2 shares the staging of chunk ci when there are only two slots; with three (the build's value) the look-ahead above never lands on the same slot
+    static_assert(PIPE_SLOTS >= 3, "StreamFeeder flattens two chunks ahead: it needs three staging areas");
+};
+
 // Rows of the chunk waiting in the slot's pinned staging -> the caller's rectangles (any offsets / strides; nothing else is touched).
 static void scatterPending(PipeSlot &p, const MsdfHipGlyph *glyphs, char *dst, size_t elem, int w, int h, int N) {
     const size_t rowBytes = (size_t) w*N*elem, tileBytes = rowBytes*h;
@@ -1799,25 +2129,29 @@ static void scatterPending(PipeSlot &p, const MsdfHipGlyph *glyphs, char *dst, s
 
 // out != NULL: float tiles into the caller's bitmaps (glyphs[g].out_offset / row_stride in floats). atlas != NULL: pixelFloatToByte
 // + blit into the caller's 8-bit atlas (out_offset / row_stride in bytes). Exactly one of the two.
-static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const MsdfHipGlyph *glyphs, float *out, size_t outFloats, uint8_t *atlas,
-                       size_t atlasBytes, uint8_t *stencil, const MsdfHipConfig *cfg) {
-    if (!b || !glyphs || (!out && !atlas) || mode < 1 || mode > 4 || w < 0 || h < 0)
+// b: a resident batch (its chunks are views of it), or NULL with `feeder` = a shape source whose chunks are flattened, uploaded and digested as they come.
+static int runPipeline(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, int nGlyphs, int mode, int w, int h, const MsdfHipGlyph *glyphs, float *out, size_t outFloats,
+                       uint8_t *atlas, size_t atlasBytes, uint8_t *stencil, const MsdfHipConfig *cfg) {
+    if ((!b && !feeder) || !glyphs || (!out && !atlas) || mode < 1 || mode > 4 || w < 0 || h < 0)
         return fail(MSDFHIP_ERR_INVALID, "bad arguments to the host-output generator");
     int rc = checkConfig(cfg);
     if (rc != MSDFHIP_OK)
         return rc;
-    rc = ensureDevice(b->device);
+    rc = ensureDevice(b ? b->device : device);
     if (rc != MSDFHIP_OK)
         return rc;
-    const int nG = b->nGlyphs, N = channelsOf(mode);
+    const int nG = b ? b->nGlyphs : nGlyphs, N = channelsOf(mode);
     if (nG == 0 || w == 0 || h == 0)
         return MSDFHIP_OK;
     PipeLease lease;
-    rc = lease.take(b->device);
-    if (rc == MSDFHIP_OK)
+    rc = lease.take(currentDevice());
+    if (rc == MSDFHIP_OK && b)
         rc = fetchGlyphCounts(b);
     if (rc != MSDFHIP_OK)
         return rc;
+    ResidentFeeder resident(b);
+    if (!feeder)
+        feeder = &resident;
     PipeSlot *pipe = lease.p->slot;
     const size_t texels = (size_t) w*h, tile = texels*N;         // floats per tile; also bytes per 8-bit tile
     const size_t total = out ? outFloats : atlasBytes, elem = out ? sizeof(float) : 1;
@@ -1912,6 +2246,9 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
     // kernels of the next ones, and the kernels of two consecutive chunks overlap each other (a 2 048-glyph step alone leaves the device
     // half empty in its tails: serialising the chunks' kernels on one stream was measured, 17 instead of 12 ms). THREE slots: with two, the
     // device idled 0.8 ms per chunk while a copy held the slot the next chunk needed (MSDFHIP_PIPELINE_TRACE, profiles/r03_ab_notes.md).
+    rc = feeder->begin(pipe, lengths);
+    if (rc != MSDFHIP_OK)
+        return rc;
     int slot = 0, g0 = 0;
     for (size_t ci = 0; ci < lengths.size() && rc == MSDFHIP_OK; g0 += lengths[ci], ++ci, slot = (slot+1)%PIPE_SLOTS) {
         const int n = lengths[ci];
@@ -1927,7 +2264,6 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
                 scatterPending(p, glyphs, dstBytes, elem, w, h, N);
             p.pendingCount = 0;
         }
-        sliceBatch(b, p.view, g0, n);
         if (tracing) {
             TraceEvents te;
             hipEventCreate(&te.start), hipEventCreate(&te.kernels), hipEventCreate(&te.copied);
@@ -1935,6 +2271,9 @@ static int runPipeline(const MsdfHipBatch *b, int mode, int w, int h, const Msdf
             hipEventRecord(te.start, compute);
             trace.push_back(te);
         }
+        rc = feeder->prepare(p, slot, ci, g0, n, compute);       // a view of the resident batch, or: flattened shapes -> upload -> digest on the chunk's stream
+        if (rc != MSDFHIP_OK)
+            break;
         MsdfHipGlyph *dGlyphs = reinterpret_cast<MsdfHipGlyph *>(p.dev+offGlyphs);
         float *dTiles = reinterpret_cast<float *>(p.dev+offTiles);
         uint8_t *dStencil = wantStencil ? reinterpret_cast<uint8_t *>(p.dev+offStencil) : NULL;
@@ -2062,14 +2401,93 @@ int msdfhip_batch_generate_host(const MsdfHipBatch *b, int mode, int w, int h, c
                                 uint8_t *stencil, const MsdfHipConfig *cfg) {
     if (!out)
         return fail(MSDFHIP_ERR_INVALID, "NULL argument");
-    return runPipeline(b, mode, w, h, glyphs, out, outFloats, NULL, 0, stencil, cfg);
+    if (!b)
+        return fail(MSDFHIP_ERR_INVALID, "NULL argument");
+    return runPipeline(b, NULL, -1, 0, mode, w, h, glyphs, out, outFloats, NULL, 0, stencil, cfg);
 }
 
 int msdfhip_batch_generate_bytes_host(const MsdfHipBatch *b, int mode, int w, int h, const MsdfHipGlyph *glyphs, uint8_t *atlas, size_t atlasBytes,
                                       const MsdfHipConfig *cfg) {
     if (!atlas)
         return fail(MSDFHIP_ERR_INVALID, "NULL argument");
-    return runPipeline(b, mode, w, h, glyphs, NULL, 0, atlas, atlasBytes, NULL, cfg);
+    if (!b)
+        return fail(MSDFHIP_ERR_INVALID, "NULL argument");
+    return runPipeline(b, NULL, -1, 0, mode, w, h, glyphs, NULL, 0, atlas, atlasBytes, NULL, cfg);
+}
+
+// ---- streamed generation: shapes in, host bitmaps out, everything in between overlapped (SURVEY.md 8d's end-to-end metric) ----------------------
+//
+// msdfhip_batch_create + msdfhip_batch_generate_host run one after the other: flatten all shapes (the caller), upload + digest all, then the chunk
+// pipeline. Here the glyph list is cut into the pipeline's chunks FIRST and every stage works chunk-wise: the host threads flatten chunk k+1 / k+2 from the
+// caller's shape objects straight into pinned staging while chunk k's upload, digest and kernels run and chunk k-1's tiles are copied back.
+int msdfhip_generate_stream(int device, int mode, int w, int h, int n_glyphs, const MsdfHipShapeSource *source, const MsdfHipGlyph *glyphs, float *out,
+                            size_t out_floats, uint8_t *atlas, size_t atlas_bytes, uint8_t *stencil, const MsdfHipConfig *cfg) {
+    if (!source || !source->count || !source->fill || n_glyphs < 0 || (!out) == (!atlas) || (n_glyphs > 0 && !glyphs))
+        return fail(MSDFHIP_ERR_INVALID, "bad arguments to msdfhip_generate_stream (a shape source with count and fill, exactly one of out / atlas)");
+    if (atlas && stencil)
+        return fail(MSDFHIP_ERR_INVALID, "msdfhip_generate_stream: a stencil buffer only goes with float output");
+    if (n_glyphs == 0)
+        return MSDFHIP_OK;
+    if (device >= 0) {
+        int count = 0;
+        int rc = msdfhip_device_count(&count);
+        if (rc != MSDFHIP_OK)
+            return rc;
+        if (device >= count)
+            return fail(MSDFHIP_ERR_INVALID, "device %d out of range (0..%d)", device, count-1);
+    }
+    int rc = ensureDevice(device);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    StreamFeeder feeder(source, n_glyphs);
+    rc = feeder.count();
+    if (rc != MSDFHIP_OK)
+        return rc;
+    return runPipeline(NULL, &feeder, currentDevice(), n_glyphs, mode, w, h, glyphs, out, out_floats, atlas, atlas_bytes, stencil, cfg);
+}
+
+namespace {
+struct CsrSource {                                               // a shape source over HOST CSR arrays (what msdfhip_batch_create takes)
+    const int32_t *gco, *co;
+    const double *points;
+    const uint8_t *types, *colors;
+    static void count(void *user, int g, int32_t *nC, int32_t *nE) {
+        const CsrSource &s = *static_cast<const CsrSource *>(user);
+        *nC = s.gco[g+1]-s.gco[g], *nE = s.co[s.gco[g+1]]-s.co[s.gco[g]];
+    }
+    static void fill(void *user, int g, int32_t edgeBase, int32_t *contourEnd, double *points, uint8_t *types, uint8_t *colors) {
+        const CsrSource &s = *static_cast<const CsrSource *>(user);
+        const int c0 = s.gco[g], c1 = s.gco[g+1], e0 = s.co[c0], nE = s.co[c1]-e0;
+        for (int c = c0; c < c1; ++c)
+            contourEnd[c-c0] = edgeBase+(s.co[c+1]-e0);
+        memcpy(points, s.points+(size_t) e0*8, (size_t) nE*8*sizeof(double));
+        memcpy(types, s.types+e0, (size_t) nE);
+        memcpy(colors, s.colors+e0, (size_t) nE);
+    }
+};
+}
+
+int msdfhip_generate_stream_csr(int device, int mode, int w, int h, int n_glyphs, const int32_t *gco, const int32_t *co, const double *points, const uint8_t *types,
+                                const uint8_t *colors, const MsdfHipGlyph *glyphs, float *out, size_t out_floats, uint8_t *atlas, size_t atlas_bytes, uint8_t *stencil,
+                                const MsdfHipConfig *cfg) {
+    std::vector<int> hc, he;
+    int maxC = 0, maxE = 0;
+    int rc = checkShapeArrays(n_glyphs, gco, co, points, types, colors, true, hc, he, maxC, maxE);
+    if (rc != MSDFHIP_OK)
+        return rc;
+    CsrSource csr = { gco, co, points, types, colors };
+    MsdfHipShapeSource source = { &csr, CsrSource::count, CsrSource::fill };
+    return msdfhip_generate_stream(device, mode, w, h, n_glyphs, &source, glyphs, out, out_floats, atlas, atlas_bytes, stencil, cfg);
+}
+
+int msdfhip_set_host_threads(int threads) {
+    if (threads < 0)
+        return fail(MSDFHIP_ERR_INVALID, "msdfhip_set_host_threads(%d)", threads);
+    std::lock_guard<std::mutex> lock(gHostPoolMutex);
+    if (gHostPool)                                               // (the pool is created once, on first use)
+        return gHostPool->threads()+1;
+    gHostThreads.store(threads);
+    return 0;
 }
 
 int msdfhip_set_pipeline_chunk(int glyphs_per_chunk) {
@@ -2160,8 +2578,8 @@ int msdfhip_generate_sharded(const int *devices, int n_devices, int mode, int w,
             MsdfHipBatch *b = NULL;
             int r = msdfhip_batch_create_on(&b, devices[k], g1-g0, lgco.data(), lco.data(), points+(size_t) e0*8, types+e0, colors+e0);
             if (r == MSDFHIP_OK) {
-                r = out ? runPipeline(b, mode, w, h, glyphs+g0, out, outFloats, NULL, 0, NULL, cfg)
-                        : runPipeline(b, mode, w, h, glyphs+g0, NULL, 0, atlas, atlasBytes, NULL, cfg);
+                r = out ? runPipeline(b, NULL, -1, 0, mode, w, h, glyphs+g0, out, outFloats, NULL, 0, NULL, cfg)
+                        : runPipeline(b, NULL, -1, 0, mode, w, h, glyphs+g0, NULL, 0, atlas, atlasBytes, NULL, cfg);
                 msdfhip_batch_destroy(b);
             }
             rcs[k] = r;
@@ -2286,6 +2704,11 @@ static void destroyPipe(Pipe *p) {
             pinnedFree(s.pinnedGlyphs);
         if (s.pinnedTiles)
             pinnedFree(s.pinnedTiles);
+        if (s.pinnedIn)
+            pinnedFree(s.pinnedIn);
+        hipFree(s.devIn);
+        if (s.inputsUploaded)
+            hipEventDestroy(s.inputsUploaded);
         if (s.done)
             hipEventDestroy(s.done);
         if (s.kernelsDone)
@@ -2298,12 +2721,6 @@ static void destroyPipe(Pipe *p) {
     (void) hipGetLastError();
     delete p;
 }
-
-struct Carver {                                                  // 256-byte aligned sub-allocation inside an arena
-    size_t off;
-    Carver() : off(0) { }
-    size_t take(size_t bytes) { const size_t at = off; off += (bytes+255)/256*256; return at; }
-};
 
 enum SingleOp { OP_GENERATE = 0, OP_ERROR_CORRECTION = 1, OP_SIGN_CORRECTION = 2, OP_RASTERIZE = 3 };   // what the single-shape call does to `pixels`
 
@@ -2330,6 +2747,7 @@ static bool sameLaunch(const ShapeCall &a, const ShapeCall &b) {
 }
 
 static std::atomic<long long> gNsStage(0), gNsDevice(0), gNsScatter(0);
+static std::atomic<unsigned long long> gSingleTimeouts(0), gSingleLost(0), gSingleRefused(0);   // fused launches that gave up at their grid barrier / ended without their flag (both rerun through the batched sequence)
 static std::atomic<unsigned long long> gSinglePhase[8], gSingleCalls(0), gSingleCycles(0);   // sums of k_single_call's phase stamps (msdfhip_debug_single_call_phases)
 static long long nowNs() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -2392,6 +2810,71 @@ static int frontDoorDevice() {
         return -1;
     return gFrontDevices[gFrontNext.fetch_add(1u)%gFrontDevices.size()];
 }
+
+// k_single_call's grid barrier needs all workgroups of a launch resident at the same time, and the launch is not cooperative. Two things make
+// that hold: (1) the fused launches in flight on a device are counted against what the device can hold of this kernel at this LDS size
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor x compute units) -- a call that would not fit takes the batched sequence; (2) what this process cannot
+// count (persistent k_distance launches of other threads, other processes) is covered by the bounded spin + rerun (msdf_single.hpp: gridBarrier).
+static std::atomic<int> gFusedInFlight[64];                     // workgroups of fused launches in flight, per device
+extern "C++" {
+template <int SEL, bool OVERLAP>
+static int fusedBlocksPerCu(size_t lds) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(k_single_call<SEL, OVERLAP>), WAVE, lds) != hipSuccess) {
+        (void) hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+}
+static int fusedCapacity(int device, int variant, size_t lds) {  // variant = mode*2 + overlap (2..9)
+    enum { LDS_STEP = 4096, LDS_STEPS = 17 };
+    static std::atomic<int> cache[10][LDS_STEPS];                // (one gfx950 is like another: not keyed by device)
+    const size_t step = (lds+LDS_STEP-1)/LDS_STEP;
+    if (variant < 2 || variant > 9 || step >= LDS_STEPS)
+        return 0;
+    int v = cache[variant][step].load();
+    if (!v) {
+        const size_t rounded = step*LDS_STEP;
+        int perCu = 0;
+        switch (variant) {
+            case 2: perCu = fusedBlocksPerCu<1, false>(rounded); break;
+            case 3: perCu = fusedBlocksPerCu<1, true>(rounded); break;
+            case 4: perCu = fusedBlocksPerCu<2, false>(rounded); break;
+            case 5: perCu = fusedBlocksPerCu<2, true>(rounded); break;
+            case 6: perCu = fusedBlocksPerCu<3, false>(rounded); break;
+            case 7: perCu = fusedBlocksPerCu<3, true>(rounded); break;
+            case 8: perCu = fusedBlocksPerCu<4, false>(rounded); break;
+            default: perCu = fusedBlocksPerCu<4, true>(rounded); break;
+        }
+        v = perCu > 0 ? perCu*residentSlots(device) : -1;
+        cache[variant][step].store(v);
+    }
+    return v > 0 ? v : 0;
+}
+struct FusedReservation {                                        // the workgroups a fused launch holds of its device, released when the call is over
+    std::atomic<int> *counter;
+    int groups;
+    FusedReservation() : counter(NULL), groups(0) { }
+    ~FusedReservation() { release(); }
+    bool take(int device, int variant, size_t lds, int want) {
+        if (device < 0 || device >= 64)
+            return false;
+        const int capacity = fusedCapacity(device, variant, lds);
+        std::atomic<int> &c = gFusedInFlight[device];
+        if (c.fetch_add(want)+want > capacity) {
+            c.fetch_sub(want);
+            return false;
+        }
+        counter = &c, groups = want;
+        return true;
+    }
+    void release() {
+        if (counter)
+            counter->fetch_sub(groups);
+        counter = NULL;
+    }
+};
 
 static int runGroup(ShapeCall *const *calls, int n) {
     const ShapeCall &c0 = *calls[0];
@@ -2506,8 +2989,14 @@ static int runGroup(ShapeCall *const *calls, int n) {
         lds = lds > ecFastLdsBytes(maxE, channels) ? lds : ecFastLdsBytes(maxE, channels);
         lds = lds > queryLds ? lds : queryLds;
     }
-    const bool fusedOK = fusedShape && !tuning().noFusedSingle && !cfg->sign_correction && cfg->ec_stage_limit == 0 &&
-                         lds <= (size_t) 64*1024 && (!overlapEff || resInLds || gresNeed >= tilesAll*resBytes);
+    bool fusedOK = fusedShape && !tuning().noFusedSingle && !cfg->sign_correction && cfg->ec_stage_limit == 0 &&
+                   lds <= (size_t) 64*1024 && (!overlapEff || resInLds || gresNeed >= tilesAll*resBytes);
+    FusedReservation fusedSlots;                                 // (see fusedCapacity: all workgroups of the launch must be resident together)
+    if (fusedOK) {
+        fusedOK = fusedSlots.take(a.device, mode*2+(overlapEff ? 1 : 0), lds, (int) tilesAll+(correct ? 1 : 0));
+        if (!fusedOK)
+            gSingleRefused += 1;
+    }
     const bool zeroCopy = fusedOK && a.pinnedDev != NULL && !anyStencil && !tuning().noZeroCopySingle;
     if (zeroCopy) {
         // (nothing to upload)
@@ -2592,10 +3081,19 @@ static int runGroup(ShapeCall *const *calls, int n) {
             sa.slotCap = slotCap, sa.slotOffset = slotOffset;
             const unsigned groups = (unsigned) tilesAll+(correct ? 1u : 0u);
             sa.barrier = a.barrier, sa.barrierBase = a.barrierEpoch, sa.doneBase = a.doneCount;
-            a.barrierEpoch += (correct ? 1u : 0u)*groups, a.doneCount += groups;   // what this launch adds to the two counters
-            if (++a.doneEpoch == 0)
-                a.doneEpoch = 1;
-            sa.doneValue = a.doneEpoch;
+            sa.doneValue = a.doneEpoch+1u ? a.doneEpoch+1u : 1u;
+            {   // ~70 ns per iteration: 2-3 ms for a font glyph, growing with the edges a tile may have to walk, at most the old 0.3 s
+                const unsigned long long limit = (1ull<<15)+((unsigned long long) sumE<<8);
+                sa.spinLimit = tuning().singleSpinLimit ? (unsigned) tuning().singleSpinLimit : (unsigned) (limit < (1ull<<22) ? limit : (1ull<<22));
+            }
+            // Leaves the counters as a fresh arena has them (after a failed or abandoned launch the values on the device no longer match the epochs kept here).
+            auto resetCounters = [&a, &lease]() -> int {
+                lease.quiescent = false;
+                HIPCHK(hipStreamSynchronize(a.stream));
+                HIPCHK(hipMemsetAsync(a.barrier, 0, 256, a.stream));
+                a.barrierEpoch = a.doneCount = 0;
+                return MSDFHIP_OK;
+            };
             volatile unsigned *hostStatus = reinterpret_cast<volatile unsigned *>(a.pinned+hStatus);
             sa.status = reinterpret_cast<unsigned *>(zeroCopy ? a.pinnedDev+hStatus : a.dev+hStatus);
             if (zeroCopy)
@@ -2612,35 +3110,54 @@ static int runGroup(ShapeCall *const *calls, int n) {
                 case 8: hipLaunchKernelGGL((k_single_call<4, false>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
                 default: hipLaunchKernelGGL((k_single_call<4, true>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
             }
-            HIPCHK(hipGetLastError());
+            {
+                const hipError_t launched = hipGetLastError();
+                if (launched != hipSuccess)                      // nothing ran: the counters and the epochs kept here still agree
+                    return fail(MSDFHIP_ERR_HIP, "k_single_call launch failed: %s", hipGetErrorString(launched));
+            }
+            a.barrierEpoch += (correct ? 1u : 0u)*groups, a.doneCount += groups;   // what this launch adds to the two counters
+            a.doneEpoch = sa.doneValue;
+            bool abandoned = false;                              // the launch did not do its job: rerun through the batched sequence, from fresh counters
             if (zeroCopy) {
+                // Polls the completion word: pause between looks (the sibling hyperthread keeps its core), and once a call has outlasted the common
+                // case give the core away between looks -- 64 waiting leaders must not starve the threads that stage the next calls.
                 const long long deadline = nowNs()+2000000;      // 2 ms of polling, then the runtime's own wait (a failed launch never raises the flag)
-                while (hostStatus[2] != sa.doneValue && nowNs() < deadline) { }
+                for (unsigned looks = 0; hostStatus[2] != sa.doneValue && nowNs() < deadline; ++looks) {
+                    if (looks < 4096)
+                        __builtin_ia32_pause();
+                    else
+                        sched_yield();
+                }
                 if (hostStatus[2] != sa.doneValue) {
                     HIPCHK(hipStreamSynchronize(a.stream));
                     if (hostStatus[2] != sa.doneValue) {
                         unsigned counters[32] = { 0 };
                         (void) hipMemcpy(counters, a.barrier, sizeof(counters), hipMemcpyDeviceToHost);
-                        return fail(MSDFHIP_ERR_HIP, "k_single_call ended without raising its completion flag (flag %u, expected %u; status %u %u; finished-workgroup counter %u, "
-                                    "expected %u + %u; barrier counter %u, base %u)", (unsigned) hostStatus[2], sa.doneValue, (unsigned) hostStatus[0], (unsigned) hostStatus[1],
-                                    counters[16], sa.doneBase, groups, counters[0], sa.barrierBase);
+                        gSingleLost += 1;
+                        if (tuning().singleVerbose)
+                            fprintf(stderr, "msdfgen_hip: k_single_call ended without raising its completion flag (flag %u, expected %u; status %u %u; finished-workgroup "
+                                    "counter %u, expected %u + %u; barrier counter %u, base %u): rerunning the call through the batched sequence\n", (unsigned) hostStatus[2],
+                                    sa.doneValue, (unsigned) hostStatus[0], (unsigned) hostStatus[1], counters[16], sa.doneBase, groups, counters[0], sa.barrierBase);
+                        abandoned = true;
                     }
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);
-                lease.quiescent = true;
+                lease.quiescent = !abandoned;
             } else {
                 HIPCHK(hipMemcpyAsync(a.pinned+hStatus, a.dev+hStatus, 256+(anyStencil ? resultBytes : n*tileBytes), hipMemcpyDeviceToHost, a.stream));
                 HIPCHK(waitStream(a.stream));
             }
-            if (hostStatus[1] != 0) {
-                // workgroups gave up at a barrier: the counters no longer match the epochs kept here -- start over from fresh ones
-                lease.quiescent = false;
-                HIPCHK(hipStreamSynchronize(a.stream));
-                HIPCHK(hipMemsetAsync(a.barrier, 0, 256, a.stream));
-                a.barrierEpoch = a.doneCount = 0;
-                return fail(MSDFHIP_ERR_HIP, "k_single_call: a grid barrier timed out (workgroups of one launch not co-resident?)");
+            if (hostStatus[1] != 0) {                            // workgroups gave up at the grid barrier (the launch was not resident as a whole)
+                gSingleTimeouts += 1;
+                abandoned = true;
             }
-            fusedDone = hostStatus[0] == 0;
+            fusedSlots.release();
+            if (abandoned) {
+                rc = resetCounters();
+                if (rc != MSDFHIP_OK)
+                    return rc;
+            }
+            fusedDone = !abandoned && hostStatus[0] == 0;
             if (fusedDone && correct && zeroCopy) {              // (all phases ran and the stamps are at hand: the diagnostics count these calls)
                 for (int k = 0; k < 7; ++k)
                     gSinglePhase[k] += (unsigned long long) hostStatus[8+k];
@@ -3139,6 +3656,18 @@ int msdfhip_reload_tuning(void) {
 // Where the time of the fused single-shape launches went (k_single_call stamps workgroup 0's phase boundaries with the 100 MHz realtime counter):
 // out[0] calls, out[1..6] microseconds per call of workgroup 0's digest | distance tile | wait for all tiles | correction sweep | wait for all sweeps |
 // distance checks, out[7] start of workgroup 0 -> last workgroup finished.
+int msdfhip_single_call_fallbacks(unsigned long long *barrier_timeouts, unsigned long long *lost_flags, unsigned long long *refused, int reset) {
+    if (barrier_timeouts)
+        *barrier_timeouts = gSingleTimeouts.load();
+    if (lost_flags)
+        *lost_flags = gSingleLost.load();
+    if (refused)
+        *refused = gSingleRefused.load();
+    if (reset)
+        gSingleTimeouts.store(0), gSingleLost.store(0), gSingleRefused.store(0);
+    return MSDFHIP_OK;
+}
+
 int msdfhip_debug_single_call_phases(double *out8, int reset) {
     if (!out8)
         return fail(MSDFHIP_ERR_INVALID, "NULL argument");

@@ -68,6 +68,7 @@ struct SingleArgs {
     unsigned *status;                  // [0] candidate overflow (the host reruns the call through the batched path) [1] a barrier gave up
                                        // [2] completion flag (= doneValue, written last, system scope) [8..14] phase stamps of workgroup 0 (10 ns units) [15] its shader-clock cycles from the first to the last stamp
     unsigned doneValue;
+    unsigned spinLimit;                // iterations a workgroup waits at the grid barrier before it gives up (status[1]; the host then reruns the call through the batched sequence)
     // Small shapes travel INSIDE the kernel arguments (the runtime keeps the argument buffer in device memory: the host writes it through the
     // PCIe aperture, posted, and the digest reads it locally -- reading the staged arrays from pinned host memory instead costs two dependent
     // PCIe round trips, ~8 of the ~11 us the digest took): payloadBytes != 0 -> contour offsets | points | types | colors | descriptor at
@@ -77,25 +78,33 @@ struct SingleArgs {
 };
 static_assert(sizeof(SingleArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
-// (The spin is bounded -- ~0.3 s -- so that a launch whose workgroups could not all become resident ends with status[1] set instead of hanging
-// the queue; the host then fails the call loudly. It has never been seen to happen: <= 257 wavefronts on a device with 3 072+ slots.)
-__device__ inline void gridBarrier(unsigned *counter, unsigned target, unsigned *status) {
+// The launch is not cooperative: nothing GUARANTEES that its tiles+1 workgroups are resident together. The host only takes this path while the
+// fused launches in flight fit the device (runGroup: fusedCapacity), but a persistent k_distance launch of another thread or process may still hold
+// the slots. The spin is therefore bounded (spinLimit, scaled by the host with the shape's size: ~2 ms for a font glyph, at most ~0.3 s): a workgroup that
+// gives up raises status[1], the rest of the launch drains, and the host reruns the call through the batched sequence -- generate*() never fails for it.
+// Returns false (wave-uniform) when this workgroup gave up: what lies behind the barrier is then NOT complete -- the caller must skip its next phase (the
+// other workgroups' fields, the candidate counters the extra workgroup zeroes: reading them would mean stale counts and out-of-range texel indices).
+__device__ inline bool gridBarrier(unsigned *counter, unsigned target, unsigned *status, unsigned spinLimit) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");              // this wavefront's stores (all lanes) are written back before it arrives
     __builtin_amdgcn_wave_barrier();
+    int ok = 1;
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         while ((int) (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)-target) < 0) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u<<22)) {
-                status[1] = 1u;
+            if (++spins > spinLimit) {
+                __hip_atomic_store(status+1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ok = 0;
                 break;
             }
         }
     }
+    ok = __builtin_amdgcn_readfirstlane(ok);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // the hand-placed s_load batches of the survivor walk (see above)
+    return ok != 0;
 }
 
 __device__ __forceinline__ void stampPhase(const SingleArgs &a, int k) {
@@ -239,10 +248,10 @@ k_single_call(SingleArgs a) {
     stampPhase(a, 2);
     if constexpr (SEL >= 3) {
         if (a.correct) {
-            gridBarrier(a.barrier, a.barrierBase+groups, a.status);
+            const bool together = gridBarrier(a.barrier, a.barrierBase+groups, a.status, a.spinLimit);
             stampPhase(a, 3);
             // ---- phase 2: error correction sweep (k_ec_fast) of the tile, then the distance checks of the candidates it left
-            if (blk < T) {
+            if (blk < T && together) {
                 ecFastBody<(int) N>(batch, glyph, a.width, a.height, a.tilesX, a.tiles, a.scratch, a.out, a.stencil, a.cfg, a.ecParams, a.cands, a.seg,
                                     a.listStride, a.corners, blk, reinterpret_cast<int *>(smemSingle), (int) T, (int) blk);
                 stampPhase(a, 4);

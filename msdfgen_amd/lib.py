@@ -102,6 +102,11 @@ _PROTOS = {
     "msdfhip_front_door_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "msdfhip_debug_wait_profile": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "msdfhip_debug_single_call_phases": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
+    "msdfhip_generate_stream": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.POINTER(Config)]),
+    "msdfhip_generate_stream_csr": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, _bp, _bp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp,
+                                              C.POINTER(Config)]),
+    "msdfhip_set_host_threads": (C.c_int, [C.c_int]),
+    "msdfhip_single_call_fallbacks": (C.c_int, [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_PROTOS))
@@ -139,7 +144,7 @@ def load(build_if_missing=True):
             fn = getattr(lib, name)  # AttributeError here == a symbol of include/msdfgen_hip.h is missing from the library
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.msdfhip_abi_version() != 4:
+        if lib.msdfhip_abi_version() != 5:
             raise MsdfHipError(ERR_INVALID, "ABI version mismatch")
         _lib = lib
         return lib

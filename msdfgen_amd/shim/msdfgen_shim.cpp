@@ -20,6 +20,7 @@
 
 #include "msdfgen.h"
 #include "msdfgen_hip.h"
+#include "msdfgen_hip_batch.hpp"
 
 namespace msdfgen {
 
@@ -298,6 +299,126 @@ void distanceSignCorrection(const BitmapSection<float, 3> &sdf, const Shape &sha
 }
 void distanceSignCorrection(const BitmapSection<float, 4> &sdf, const Shape &shape, const Vector2 &scale, const Vector2 &translate, FillRule fillRule) {
     signCorrect<4>(sdf, shape, Projection(scale, translate), .5f, fillRule);
+}
+
+}
+
+// ---- msdfgen_hip_batch.hpp: a LIST of shapes in one pipelined call (msdfhip_generate_stream) ------------------------------------------------------
+namespace msdfgen_hip {
+
+namespace {
+
+using namespace msdfgen;
+
+// The library's view of `const Shape *const *` (MsdfHipShapeSource, include/msdfgen_hip.h): called from its host threads, read-only.
+struct ShapeList {
+    const Shape *const *shapes;
+    const int *index;                                                      // the glyphs of this launch group (sections of one size), in list order
+    static void count(void *user, int g, int32_t *nContours, int32_t *nEdges) {
+        const ShapeList &list = *static_cast<const ShapeList *>(user);
+        const Shape &shape = *list.shapes[list.index[g]];
+        *nContours = (int32_t) shape.contours.size();
+        *nEdges = (int32_t) shape.edgeCount();
+    }
+    // core/Shape.h:24 (contours), core/Contour.h:17 (edges), core/edge-segments.h:28-31 (type / controlPoints), core/EdgeHolder.h (one heap object per edge)
+    static void fill(void *user, int g, int32_t edgeBase, int32_t *contourEnd, double *points, uint8_t *types, uint8_t *colors) {
+        const ShapeList &list = *static_cast<const ShapeList *>(user);
+        const Shape &shape = *list.shapes[list.index[g]];
+        int32_t at = 0;
+        for (std::vector<Contour>::const_iterator contour = shape.contours.begin(); contour != shape.contours.end(); ++contour) {
+            for (std::vector<EdgeHolder>::const_iterator edge = contour->edges.begin(); edge != contour->edges.end(); ++edge, ++at) {
+                const EdgeSegment &segment = **edge;
+                const int type = segment.type();
+                const Point2 *p = segment.controlPoints();
+                double *dst = points+(size_t) at*8;
+                for (int i = 0; i < 4; ++i)
+                    dst[2*i] = i <= type ? p[i].x : 0., dst[2*i+1] = i <= type ? p[i].y : 0.;
+                types[at] = (uint8_t) type;
+                colors[at] = (uint8_t) segment.color;
+            }
+            *contourEnd++ = edgeBase+at;
+        }
+    }
+};
+
+template <typename T, int N>
+void generateBatch(int mode, const BitmapSection<T, N> *outputs, const Shape *const *shapes, const SDFTransformation *transformations, int count, bool overlapSupport,
+                   const ErrorCorrectionConfig *ec) {
+    if (count <= 0)
+        return;
+    if (!outputs || !shapes || !transformations) {
+        msdfgen::check(MSDFHIP_ERR_INVALID, "generateBatch (NULL argument)");
+        return;
+    }
+    const bool bytes = sizeof(T) == 1;
+    // one pipelined call per bitmap size (a launch parameter); an atlas run has one
+    std::vector<int> order((size_t) count);
+    for (int i = 0; i < count; ++i)
+        order[(size_t) i] = i;
+    std::stable_sort(order.begin(), order.end(), [outputs](int a, int b) {
+        return outputs[a].width != outputs[b].width ? outputs[a].width < outputs[b].width : outputs[a].height < outputs[b].height;
+    });
+    std::vector<MsdfHipGlyph> glyphs;
+    for (size_t first = 0; first < order.size(); ) {
+        size_t last = first;
+        const int w = outputs[order[first]].width, h = outputs[order[first]].height;
+        while (last < order.size() && outputs[order[last]].width == w && outputs[order[last]].height == h)
+            ++last;
+        const int n = (int) (last-first);
+        if (w > 0 && h > 0) {
+            // all sections of the group as rectangles of ONE address range [base, end): the lowest and the highest element any of them touches
+            const T *base = NULL, *end = NULL;
+            for (size_t k = first; k < last; ++k) {
+                const BitmapSection<T, N> &o = outputs[order[k]];
+                const T *lo = o.pixels+(o.rowStride < 0 ? (ptrdiff_t) o.rowStride*(h-1) : 0), *hi = o.pixels+(o.rowStride < 0 ? 0 : (ptrdiff_t) o.rowStride*(h-1))+(ptrdiff_t) N*w;
+                base = !base || lo < base ? lo : base, end = !end || hi > end ? hi : end;
+            }
+            glyphs.resize((size_t) n);
+            for (int g = 0; g < n; ++g) {
+                const int i = order[first+(size_t) g];
+                msdfgen::transformationToXf(transformations[i], glyphs[(size_t) g].xf);
+                glyphs[(size_t) g].out_offset = (int64_t) (outputs[i].pixels-base);
+                glyphs[(size_t) g].row_stride = outputs[i].rowStride;
+                glyphs[(size_t) g].flip = shapes[i]->getYAxisOrientation() != outputs[i].yOrientation;   // output.reorient(shape.getYAxisOrientation()), core/msdfgen.cpp:55
+            }
+            MsdfHipConfig cfg = msdfgen::makeConfig(overlapSupport, ec);
+            ShapeList list = { shapes, order.data()+first };
+            MsdfHipShapeSource source = { &list, ShapeList::count, ShapeList::fill };
+            const int rc = msdfhip_generate_stream(-1, mode, w, h, n, &source, glyphs.data(), bytes ? NULL : (float *) base, bytes ? 0 : (size_t) (end-base),
+                                                   bytes ? (uint8_t *) base : NULL, bytes ? (size_t) (end-base) : 0, NULL, &cfg);
+            msdfgen::check(rc, "generateBatch");
+            if (rc != MSDFHIP_OK)
+                return;
+        }
+        first = last;
+    }
+}
+
+}
+
+void generateSDFBatch(const BitmapSection<float, 1> *outputs, const Shape *const *shapes, const SDFTransformation *transformations, int count, const GeneratorConfig &config) {
+    generateBatch<float, 1>(MSDFHIP_MODE_SDF, outputs, shapes, transformations, count, config.overlapSupport, NULL);
+}
+void generatePSDFBatch(const BitmapSection<float, 1> *outputs, const Shape *const *shapes, const SDFTransformation *transformations, int count, const GeneratorConfig &config) {
+    generateBatch<float, 1>(MSDFHIP_MODE_PSDF, outputs, shapes, transformations, count, config.overlapSupport, NULL);
+}
+void generateMSDFBatch(const BitmapSection<float, 3> *outputs, const Shape *const *shapes, const SDFTransformation *transformations, int count, const MSDFGeneratorConfig &config) {
+    generateBatch<float, 3>(MSDFHIP_MODE_MSDF, outputs, shapes, transformations, count, config.overlapSupport, &config.errorCorrection);
+}
+void generateMTSDFBatch(const BitmapSection<float, 4> *outputs, const Shape *const *shapes, const SDFTransformation *transformations, int count, const MSDFGeneratorConfig &config) {
+    generateBatch<float, 4>(MSDFHIP_MODE_MTSDF, outputs, shapes, transformations, count, config.overlapSupport, &config.errorCorrection);
+}
+void generateSDFBatch(const BitmapSection<byte, 1> *outputs, const Shape *const *shapes, const SDFTransformation *transformations, int count, const GeneratorConfig &config) {
+    generateBatch<byte, 1>(MSDFHIP_MODE_SDF, outputs, shapes, transformations, count, config.overlapSupport, NULL);
+}
+void generatePSDFBatch(const BitmapSection<byte, 1> *outputs, const Shape *const *shapes, const SDFTransformation *transformations, int count, const GeneratorConfig &config) {
+    generateBatch<byte, 1>(MSDFHIP_MODE_PSDF, outputs, shapes, transformations, count, config.overlapSupport, NULL);
+}
+void generateMSDFBatch(const BitmapSection<byte, 3> *outputs, const Shape *const *shapes, const SDFTransformation *transformations, int count, const MSDFGeneratorConfig &config) {
+    generateBatch<byte, 3>(MSDFHIP_MODE_MSDF, outputs, shapes, transformations, count, config.overlapSupport, &config.errorCorrection);
+}
+void generateMTSDFBatch(const BitmapSection<byte, 4> *outputs, const Shape *const *shapes, const SDFTransformation *transformations, int count, const MSDFGeneratorConfig &config) {
+    generateBatch<byte, 4>(MSDFHIP_MODE_MTSDF, outputs, shapes, transformations, count, config.overlapSupport, &config.errorCorrection);
 }
 
 }

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "libmsdfgen_hip.so does not export "+s
     assert set(syms) == set(L.EXPORTED_SYMBOLS), set(syms) ^ set(L.EXPORTED_SYMBOLS)
-    assert lib.msdfhip_abi_version() == 4
+    assert lib.msdfhip_abi_version() == 5
 
 
 def test_default_config_matches_reference_defaults():

@@ -422,6 +422,99 @@ def test_single_shape_call_paths_are_byte_identical(latin, oracle):
     close(want[-1], oracle.generate(s, 3, 48, 48, autoframe(s.bounds(), 48, 48, 4), overlap=False, ec_mode=2, ec_dist=2), "candidate overflow")
 
 
+def _fallbacks(lib, reset=0):
+    t, l, r = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
+    lib.msdfhip_single_call_fallbacks(C.byref(t), C.byref(l), C.byref(r), reset)
+    return int(t.value), int(l.value), int(r.value)
+
+
+def test_single_call_whose_grid_barrier_gives_up_is_rerun_not_failed(latin):
+    """core/msdfgen.cpp:92-98 cannot fail. k_single_call's grid barrier needs the whole launch resident; when it is not (another thread's persistent
+    kernel holds the slots) the barrier gives up after a bounded wait and the call must be RERUN through the batched sequence, not failed (ADVICE r4,
+    VERDICT r4 next #6). Forced here: a spin limit of one look makes (nearly) every launch give up; the bytes must be those of the undisturbed call, the
+    counters must show that the slow road was taken, and the arena must be usable afterwards (its barrier counters restart from zero)."""
+    import os
+    batch, xf64, _ = latin
+    lib = M.load()
+    cases = [(batch.shape(g), 64, 64, xf64[g]) for g in (1, 12, 33, 45, 77)]
+    s = synth.cjk_like_shape(8601)
+    cases.append((s, 48, 40, autoframe(s.bounds(), 48, 40, 4)))
+
+    def render():
+        return [gen(m, s, w, h, xf) for s, w, h, xf in cases for m in (3, 4)]
+    want = render()
+    _fallbacks(lib, 1)
+    os.environ["MSDFHIP_SINGLE_SPIN_LIMIT"] = "1"
+    lib.msdfhip_reload_tuning()
+    try:
+        got = render()
+    finally:
+        del os.environ["MSDFHIP_SINGLE_SPIN_LIMIT"]
+        lib.msdfhip_reload_tuning()
+    timeouts, lost, refused = _fallbacks(lib, 1)
+    assert timeouts >= len(cases), "the forced barrier time-outs did not happen (%d)" % timeouts
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert (a.view(np.uint8) == b.view(np.uint8)).all(), i
+    ph = (C.c_double*8)()
+    lib.msdfhip_debug_single_call_phases(ph, 1)
+    again = render()                                                              # the same arenas, counters restarted: the fused launch works again
+    lib.msdfhip_debug_single_call_phases(ph, 1)
+    assert int(ph[0]) >= len(cases) and _fallbacks(lib, 1)[0] == 0
+    for i, (a, b) in enumerate(zip(again, want)):
+        assert (a.view(np.uint8) == b.view(np.uint8)).all(), i
+
+
+def test_single_calls_next_to_a_large_batch_never_fail(latin):
+    """Eight threads hammer generateMSDF() single calls while another thread loops an 8 192-glyph CJK-like batch, whose global-scratch class runs as a
+    PERSISTENT launch that holds every wavefront slot it gets. No call may fail, every tile must be byte-identical to the undisturbed call
+    (VERDICT r4 next #6). Whether launches had to give up depends on timing; the counters are printed, not asserted."""
+    import torch
+    batch, xf64, _ = latin
+    lib = M.load()
+    picks = [1, 5, 12, 20, 33, 45, 60, 77]
+    want = [gen(3, batch.shape(g), 64, 64, xf64[g]) for g in picks]
+    base = [synth.cjk_like_shape(20000+i) for i in range(128)]
+    cj = ShapeBatch.from_shapes([base[i % 128] for i in range(8192)])
+    cx = np.stack([autoframe(s.bounds(), 48, 48, 4) for s in base])[np.arange(8192) % 128]
+    gb = M.GlyphBatch(cj)
+    out = torch.empty((8192, 48, 48, 3), dtype=torch.float32, device="cuda")
+    desc = gb.descriptors(cx, 48, 48, 3)
+    stop = threading.Event()
+    errors = []
+
+    def big():
+        try:
+            side = torch.cuda.Stream()
+            while not stop.is_set():
+                gb.generate(3, 48, 48, descriptors=desc, out=out, stream=side)
+                side.synchronize()
+        except Exception as e:                                                    # noqa: BLE001
+            errors.append(("batch", repr(e)))
+
+    def small(k):
+        try:
+            for it in range(40):
+                g = picks[(k+it) % len(picks)]
+                got = gen(3, batch.shape(g), 64, 64, xf64[g])
+                if not (got.view(np.uint8) == want[(k+it) % len(picks)].view(np.uint8)).all():
+                    errors.append(("bytes", k, it))
+        except Exception as e:                                                    # noqa: BLE001
+            errors.append(("call", k, repr(e)))
+    _fallbacks(lib, 1)
+    tb = threading.Thread(target=big)
+    tb.start()
+    ts = [threading.Thread(target=small, args=(k,)) for k in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    stop.set()
+    tb.join()
+    gb.close()
+    print("fused launches next to a persistent batch: barrier time-outs %d, lost flags %d, refused %d" % _fallbacks(lib, 1))
+    assert not errors, errors[:5]
+
+
 def test_very_many_contours_use_the_global_combiner_scratch(oracle):
     """Maximum-size edge case: 260 overlapping contours. The overlapping combiner's per-contour scratch (260*3*512 B) exceeds the CU's
     LDS, so k_distance / k_ec_query keep it in a global workspace; results must not change."""
