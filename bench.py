@@ -314,6 +314,55 @@ def inprocess(args):
     M.host_free(atlas)
 
 
+def streamed_end_to_end(M, batch, xfs, w, h, reps=7):
+    """SURVEY.md 8(d)'s metric as ONE pipelined call. (a) From REAL msdfgen::Shape objects: tests/shim/shim_check (a client of msdfgen's public headers linked
+    against the C++ shim; built in the authoring container, it travels to the GPU box) rebuilds the Shape objects of this workload and times
+    msdfgen_hip::generateMSDFBatch() -- host threads flatten chunk k+1 / k+2 into pinned staging while chunk k is uploaded, digested and rendered and chunk k-1
+    travels back; the clock starts at `const Shape *const *` and stops when the caller's pinned bitmaps are complete. (b) msdfhip_generate_stream_csr from this
+    process: the same pipeline fed from host CSR arrays (no Shape walk)."""
+    import tempfile
+    n = batch.n_glyphs
+    res = {}
+    exe = os.path.join(ROOT, "tests", "shim", "shim_check")
+    if os.path.exists(exe):
+        with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+            path = f.name
+        try:
+            batch.dump(path, xfs)
+            env = dict(os.environ)
+            env.setdefault("GPU_MAX_HW_QUEUES", "8")
+            r = subprocess.run([exe, "e2e", path, str(w), str(h), str(reps)], capture_output=True, text=True, timeout=300, env=env)
+            if r.returncode == 0 and r.stdout.strip():
+                d = json.loads(r.stdout.strip().splitlines()[-1])
+                res["from_shape_objects"] = {"float_tiles_glyphs_per_s": d["float_tiles_glyphs_per_s"], "uint8_atlas_glyphs_per_s": d["uint8_atlas_glyphs_per_s"],
+                                             "float_tiles_ms": d["float_tiles_ms"], "uint8_atlas_ms": d["uint8_atlas_ms"], "reps": d["reps"],
+                                             "entry": "msdfgen_hip::generateMSDFBatch(BitmapSection<T,3>[], const Shape *const[], SDFTransformation[], n) -- include/msdfgen_hip_batch.hpp",
+                                             "host_threads": available_cores()}
+        except (OSError, ValueError, KeyError, subprocess.SubprocessError):
+            pass
+        finally:
+            os.unlink(path)
+    tiles = M.host_alloc((n, h, w, 3))
+    cols = 128
+    atlas = M.host_alloc((((n+cols-1)//cols)*h, cols*w, 3), np.uint8)
+    offs = np.array([((g//cols)*h*cols*w+(g % cols)*w)*3 for g in range(n)], np.int64)
+    tf, tb = [], []
+    for rep in range(reps+1):
+        t0 = time.perf_counter()
+        M.generate_stream(batch, M.MODE_MSDF, w, h, xfs, out=tiles)
+        t1 = time.perf_counter()
+        M.generate_stream(batch, M.MODE_MSDF, w, h, xfs, atlas=atlas, out_offsets=offs, row_stride=cols*w*3)
+        t2 = time.perf_counter()
+        if rep:
+            tf.append(t1-t0), tb.append(t2-t1)
+    f, b = float(np.median(tf)), float(np.median(tb))
+    res["from_csr_arrays"] = {"float_tiles_glyphs_per_s": n/f, "uint8_atlas_glyphs_per_s": n/b, "float_tiles_ms": 1e3*f, "uint8_atlas_ms": 1e3*b, "reps": reps,
+                              "entry": "msdfhip_generate_stream_csr (include/msdfgen_hip.h) through ctypes; the figure includes the binding's descriptor preparation in numpy"}
+    M.host_free(tiles)
+    M.host_free(atlas)
+    return res
+
+
 def flatten_ms(batch):
     """SURVEY 8(d) counts the HOST FLATTEN in the end-to-end metric: const msdfgen::Shape & -> CSR edge buffer, what the C++ shim does per call
     (msdfgen_shim.cpp: flatten). Measured by the shim's own client (tests/shim/shim_check, built against the msdfgen headers in the authoring
@@ -468,9 +517,18 @@ def main():
     cfg = M.MSDFGeneratorConfig(overlap_support=not args.simple_combiner)
 
     elapsed, dist_ms, ec_ms, launches = timed_steps(M, torch, dist, lib, gb, desc, out, cfg, w, h, args.steps, args.warmup, world, dev, stream)
+    per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.same_device else dev)
+        cdev = "cpu" if args.same_device else dev
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # what every rank did, for the line's reader (not part of the timed region): ms per step, glyphs, edges, device index -- one all_gather
+        row = torch.tensor([1e3*elapsed/args.steps, batch.n_glyphs, batch.n_edges, local_rank, rank], dtype=torch.float64, device=cdev)
+        rows = [torch.zeros_like(row) for _ in range(world)]
+        dist.all_gather(rows, row)
+        rows = [r.cpu().tolist() for r in rows]
+        per_rank = {"backend": dist.get_backend(), "ranks_seen": sorted(int(r[4]) for r in rows), "ms_per_step": [round(r[0], 4) for r in rows],
+                    "glyphs": [int(r[1]) for r in rows], "edges": [int(r[2]) for r in rows], "device_index": [int(r[3]) for r in rows]}
         elapsed = float(t.item())
 
     if rank == 0:
@@ -479,6 +537,8 @@ def main():
         achieved = ab/(dist_ms*1e-3)/1e9 if dist_ms > 0 else 0.
         gflops = algorithmic_flops(batch, w, h)/(dist_ms*1e-3)/1e9 if dist_ms > 0 else 0.
         prof = profile_counters(args, w, h)
+        if per_rank is not None:
+            assert per_rank["ranks_seen"] == list(range(world)), per_rank
         res = {
             "metric": "MSDF glyphs/sec (48x48, fp32), BASELINE config 4: one 8192-glyph atlas glyph-sharded over the GPUs" if args.strong else "MSDF glyphs/sec (64x64, fp32)",
             "value": total_glyphs/elapsed, "unit": "glyphs/s", "n_gpus": world, "steps": args.steps,
@@ -489,7 +549,8 @@ def main():
                                     % (args.strong_set, world, "glyphs in order of modelled cost dealt out to the ranks" if args.strong_cut == "dealt" else "contiguous ranges of equal modelled cost")) if args.strong else "msdf %dx%d tiles, %d DISTINCT glyphs per GPU per step = the first 8192 glyphs with outlines of DejaVuSans + DejaVuSans-Bold "
                                    "(%.1f edges, %.2f contours per glyph; tests/golden/dejavu8192.npz, every tile pinned to the compiled reference); "
                                    "overlapSupport=true, error correction EDGE_PRIORITY+CHECK_DISTANCE_AT_EDGE (library defaults); "
-                                   "step = digest + distance field + error correction, inputs/outputs resident in HBM" % (
+                                   "step = digest + distance field + error correction, inputs/outputs resident in HBM -- `value` is this RESIDENT step (bench contract); "
+                                   "SURVEY 8(d)'s end-to-end rate from Shape objects to caller bitmaps is `end_to_end_metric` of this line" % (
                                        w, h, args.glyphs, batch.n_edges/batch.n_glyphs, batch.n_contours/batch.n_glyphs),
                        "glyphs_per_gpu": batch.n_glyphs if args.strong else args.glyphs, "tile": [w, h], "mode": "msdf",
                        "parallelism": ("glyph-sharded x%d, dealt by modelled cost (msdfgen_amd.shard.partition_dealt), no collective; rank 0 owns %d glyphs of 8192%s" % (
@@ -516,6 +577,8 @@ def main():
                           "valu_issue_frac_pmc_note": prof.get("valu_busy_note") if prof else None},
             "kernel_ms": {"distance": dist_ms, "error_correction": ec_ms},
         }
+        if per_rank is not None:
+            res["per_rank"] = per_rank
         if not args.no_extras:
             # outside the timed region: the reference-defined quality of what was just rendered (estimateSDFError, core/sdf-error-estimation.h)
             err = gb.estimate_sdf_error(out, xfs)
@@ -557,14 +620,22 @@ def main():
         fl = min(e2e["ms_flatten"]["per_pass_over_all_glyphs"].values()) if "ms_flatten" in e2e else None
         ms_u8 = e2e["float_tiles"]["ms_upload_and_digest"]+e2e["uint8_atlas"]["ms_generate_convert_and_copy_back"]
         ms_f32 = e2e["float_tiles"]["ms_upload_and_digest"]+e2e["float_tiles"]["ms_generate_and_copy_back"]
+        staged_u8, staged_f32 = batch.n_glyphs/((ms_u8+(fl or 0.))*1e-3), batch.n_glyphs/((ms_f32+(fl or 0.))*1e-3)
+        streamed = streamed_end_to_end(M, batch, xfs, w, h)
+        res["end_to_end"]["streamed"] = streamed
+        src = streamed.get("from_shape_objects")
         res["end_to_end_metric"] = {
-            "metric": "MSDF glyphs/sec (64x64) END TO END as SURVEY.md 8(d) defines it: Shape -> CSR flatten + H2D + digest + kernels incl. error correction + D2H",
-            "uint8_atlas_glyphs_per_s": batch.n_glyphs/((ms_u8+(fl or 0.))*1e-3), "float_tiles_glyphs_per_s": batch.n_glyphs/((ms_f32+(fl or 0.))*1e-3),
-            "ms": {"flatten": fl, "upload_and_digest": e2e["float_tiles"]["ms_upload_and_digest"], "uint8_generate_convert_copy_back": e2e["uint8_atlas"]["ms_generate_convert_and_copy_back"],
-                   "float_generate_copy_back": e2e["float_tiles"]["ms_generate_and_copy_back"]},
+            "metric": "MSDF glyphs/sec (64x64) END TO END as SURVEY.md 8(d) defines it: Shape -> CSR flatten + H2D + digest + kernels incl. error correction + D2H into caller bitmaps",
+            "uint8_atlas_glyphs_per_s": src["uint8_atlas_glyphs_per_s"] if src else staged_u8, "float_tiles_glyphs_per_s": src["float_tiles_glyphs_per_s"] if src else staged_f32,
+            "path": ("ONE pipelined call over real msdfgen::Shape objects, msdfgen_hip::generateMSDFBatch (flatten on the host threads || upload + digest || kernels || copy back, chunk by chunk); "
+                     "wall clock of the call, median of %d" % src["reps"]) if src else
+                    "staged (flatten, then msdfhip_batch_create, then msdfhip_batch_generate_host): tests/shim/shim_check absent on this box, the streamed C++ entry was not timed",
+            "staged": {"uint8_atlas_glyphs_per_s": staged_u8, "float_tiles_glyphs_per_s": staged_f32,
+                       "ms": {"flatten": fl, "upload_and_digest": e2e["float_tiles"]["ms_upload_and_digest"], "uint8_generate_convert_copy_back": e2e["uint8_atlas"]["ms_generate_convert_and_copy_back"],
+                              "float_generate_copy_back": e2e["float_tiles"]["ms_generate_and_copy_back"]},
+                       "note": "round 4's figure: the three stages one after the other (flatten -> msdfhip_batch_create -> msdfhip_batch_generate_host / _bytes_host)"},
             "note": "the 8-bit atlas (pixelFloatToByte on the device, a quarter of the D2H bytes) is what an atlas tool consumes; the float path is PCIe bound "
-                    "(%d MB D2H). `value` above is the HBM-resident step as the bench contract asks; flatten %s" % (
-                        e2e["float_tiles"]["d2h_bytes"]//1000000, "measured by the shim's own client on the usable host threads" if fl else "NOT measured on this box (tests/shim/shim_check absent)")}
+                    "(%d MB D2H). `value` above is the HBM-resident step as the bench contract asks" % (e2e["float_tiles"]["d2h_bytes"]//1000000)}
         res["strong_scaling"] = strong_scaling_one_gpu(M, torch, lib, dev, stream, cfg, steps=max(3, args.steps//6))
         res["secondary"] = {"workload": "round 1's bench workload: DejaVuSans Basic-Latin (94 prepared shapes, 15.6 edges / 1.41 contours per glyph) tiled to %d glyphs" % args.glyphs,
                             "glyphs_per_s": args.glyphs*max(5, args.steps//3)/e2, "kernel_ms": {"distance": d2, "error_correction": c2}}

@@ -83,6 +83,10 @@ struct Tuning {
     char devices[256];               // MSDFHIP_DEVICES             "all" | "0,1,..." devices the single-shape front door spreads over
     int smallMaxEdges;               // MSDFHIP_SMALL_MAX_EDGES     glyphs of the LDS-scratch class have at most this many edges (128)
     int ldsClassTpw;                 // MSDFHIP_LDS_CLASS_TPW       tiles per wavefront of the LDS-scratch class: 4 (default; 1 in short launches) or always 1
+    int pipelineDepth;               // MSDFHIP_PIPELINE_DEPTH      chunks of the host-output pipeline whose kernels may run at the same time (2; at most PIPE_SLOTS-1)
+    bool pipelineConcurrentClasses;  // MSDFHIP_PIPELINE_CLASSES=concurrent: a chunk's glyph classes on side streams (default: one after the other on the chunk's stream)
+    bool pipelineNoAhead;            // MSDFHIP_PIPELINE_NO_AHEAD    A/B: a chunk's class lists and correction constants inside its launch chain, as before round 5
+    bool streamUploadByCopy;         // MSDFHIP_STREAM_UPLOAD=copy: the streamed generator uploads a chunk's inputs with hipMemcpyAsync instead of the upload kernel (A/B)
     int hostThreads;                 // MSDFHIP_HOST_THREADS        host threads of the streamed generator's flatten pool (0 = the usable cores, at most 32); read when the pool is created
     long singleSpinLimit;            // MSDFHIP_SINGLE_SPIN_LIMIT   tests: iterations k_single_call's grid barrier waits before it gives up (0 = scaled with the shape)
     bool singleVerbose;              // MSDFHIP_SINGLE_VERBOSE      report abandoned fused launches on stderr
@@ -132,6 +136,10 @@ void readTuning() {
         snprintf(t.devices, sizeof(t.devices), "%s", env);
     t.smallMaxEdges = (env = getenv("MSDFHIP_SMALL_MAX_EDGES")) && atoi(env) > 0 ? atoi(env) : 128;
     t.ldsClassTpw = (env = getenv("MSDFHIP_LDS_CLASS_TPW")) && atoi(env) == 1 ? 1 : 4;
+    t.pipelineDepth = (env = getenv("MSDFHIP_PIPELINE_DEPTH")) && atoi(env) >= 1 && atoi(env) <= 3 ? atoi(env) : 2;
+    t.pipelineConcurrentClasses = (env = getenv("MSDFHIP_PIPELINE_CLASSES")) && env[0] == 'c';
+    t.pipelineNoAhead = getenv("MSDFHIP_PIPELINE_NO_AHEAD") != NULL;
+    t.streamUploadByCopy = (env = getenv("MSDFHIP_STREAM_UPLOAD")) && env[0] == 'c';
     t.hostThreads = (env = getenv("MSDFHIP_HOST_THREADS")) && atoi(env) > 0 ? atoi(env) : 0;
     t.singleSpinLimit = (env = getenv("MSDFHIP_SINGLE_SPIN_LIMIT")) && atol(env) > 0 ? atol(env) : 0;
     t.singleVerbose = getenv("MSDFHIP_SINGLE_VERBOSE") != NULL;
@@ -238,7 +246,7 @@ struct ScopedTimer {
     hipStream_t stream;
     TimedLaunch t;
     bool on;
-    ScopedTimer(hipStream_t s, int kind) : stream(s), on(gTiming.load() != 0) {
+    ScopedTimer(hipStream_t s, int kind, bool enabled = true) : stream(s), on(enabled && gTiming.load() != 0) {
         t.kind = kind;
         if (on) {
             if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) { on = false; return; }
@@ -292,13 +300,14 @@ struct MsdfHipBatch {
     mutable hipEvent_t ecOrderReady;  // (recorded behind that upload)
     mutable int *dEcOrder;            // glyph indices heaviest first (k_ec_scan / k_ec_query), built on first use; NULL: batch order
     mutable bool ecOrderTried;
+    mutable bool ecParamsAhead;       // k_ec_params of the coming correction pass was launched ahead of the distance pass (prepareAhead): launchEc skips it
     int glyphCap;                     // per-glyph work buffers are sized for max(nGlyphs, glyphCap) glyphs (views of the host-output pipeline)
     mutable hipStream_t sideStream[2];   // the three glyph classes of the distance pass run concurrently: two of them on these (fork / join by events)
     mutable hipEvent_t forkEvent, joinEvent[2];
     MsdfHipBatch() : device(0), nGlyphs(0), nContours(0), nEdges(0), maxContours(0), maxEdges(0), ownsInputs(false), dGlyphContourOffsets(NULL),
                      dContourOffsets(NULL), dPoints(NULL), dTypes(NULL), dColors(NULL), dRecs(NULL), dWindings(NULL), dScratch(NULL), scratchFloats(0),
                      dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
-                     smallMaxC(0), smallMaxE(0), oneMaxE(0), nHuge(0), restMaxC(0), restMaxE(0), restShare(1.f), serialClasses(false), overflowOut(NULL), overflowMirrored(false), hEcOrder(NULL), ecOrderReady(NULL), dEcOrder(NULL), ecOrderTried(false), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
+                     smallMaxC(0), smallMaxE(0), oneMaxE(0), nHuge(0), restMaxC(0), restMaxE(0), restShare(1.f), serialClasses(false), overflowOut(NULL), overflowMirrored(false), hEcOrder(NULL), ecOrderReady(NULL), dEcOrder(NULL), ecOrderTried(false), ecParamsAhead(false), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
 };
 
 namespace {
@@ -478,8 +487,8 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
 int uploadSmall(void *dst, const void *srcPinned, size_t bytes, hipStream_t stream) {
     if (bytes == 0)
         return MSDFHIP_OK;
-    const size_t words = bytes/4;
-    const unsigned blocks = (unsigned) ((words+255)/256 < 64 ? (words+255)/256 : 64);
+    const size_t words = bytes/4, quads = (words+3)/4;
+    const unsigned blocks = (unsigned) ((quads+255)/256 < 256 ? (quads+255)/256 : 256);
     hipLaunchKernelGGL(k_upload_words, dim3(blocks ? blocks : 1), dim3(256), 0, stream, reinterpret_cast<uint32_t *>(dst), reinterpret_cast<const uint32_t *>(srcPinned), words);
     HIPCHK(hipGetLastError());
     return MSDFHIP_OK;
@@ -693,6 +702,16 @@ int launchUnculled(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
     return MSDFHIP_OK;
 }
 
+// Contours up to which a glyph's combiner scratch fits the per-wavefront LDS budget next to the lists of a smallMaxEdges glyph (the LDS class's bound).
+int overlapClassLimit(int nch) {
+    const size_t perContourLds = (size_t) nch*WAVE*sizeof(double);
+    const int smallMaxEdges = tuning().smallMaxEdges, classTpw = tuning().ldsClassTpw == 1 ? 1 : (int) QUAD;
+    int limitAll = 0;
+    while ((size_t) (limitAll+1)*perContourLds+(size_t) classTpw*tileListBytes(smallMaxEdges, limitAll+1, false) <= ldsBudget())
+        ++limitAll;
+    return limitAll;
+}
+
 template <int SEL>
 int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, bool overlap, hipStream_t stream) {
     // A glyph whose survivor lists exceed a CU's LDS takes the list-free kernel (the reference cannot fail on a large shape; neither may this) --
@@ -705,11 +724,8 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
                                              : launchUnculled<SEL, false>(b, dGlyphs, w, h, dst, toScratch, stream);
     }
     int maxE = b->maxEdges, maxC = b->maxContours, nHuge = 0, rc = MSDFHIP_OK;
-    const size_t perContourLds = (size_t) SelTraits<SEL>::NCH*WAVE*sizeof(double);
-    int limitAll = 0;                                            // contours whose combiner scratch fits the per-wavefront LDS budget next to the lists of a SMALL_MAX_EDGES glyph
+    const int limitAll = overlapClassLimit(SelTraits<SEL>::NCH);   // contours whose combiner scratch fits the per-wavefront LDS budget next to the lists of a smallMaxEdges glyph
     const int smallMaxEdges = tuning().smallMaxEdges, classTpw = tuning().ldsClassTpw == 1 ? 1 : (int) QUAD;
-    while ((size_t) (limitAll+1)*perContourLds+(size_t) classTpw*tileListBytes(smallMaxEdges, limitAll+1, false) <= ldsBudget())
-        ++limitAll;
     if (hugeBatch) {
         rc = ensureBuckets(b, limitAll < 1 ? 1 : limitAll, stream);
         if (rc != MSDFHIP_OK)
@@ -888,7 +904,9 @@ int ensureDeferred(const MsdfHipBatch *b, size_t cap, EcCandidate **out) {
 
 template <int N, bool OVERLAP, bool GRES>
 int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, const float *src, float *out, uint8_t *stencil,
-             const MsdfHipConfig &cfg, hipStream_t stream) {
+             const MsdfHipConfig &cfg, hipStream_t stream, bool paramsOnly = false) {
+    // paramsOnly (prepareAhead): only what does not depend on the distance field -- the work buffers and k_ec_params (per-glyph constants, corner texels,
+    // zeroed candidate header) -- so that it is off the launch chain that follows the distance pass; the full call then skips that launch.
     const int tilesX = (w+TILE-1)/TILE, tilesY = (h+TILE-1)/TILE, tiles = tilesX*tilesY;
     const unsigned blocks = (unsigned) b->nGlyphs*(unsigned) tiles;
     const size_t allTexels = (size_t) b->nGlyphs*w*h;
@@ -908,8 +926,10 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     rc = setLds(k_ec_slow<N, OVERLAP, GRES>, slowLds);
     if (rc != MSDFHIP_OK)
         return rc;
-    ScopedTimer timer(stream, 1);
+    ScopedTimer timer(stream, 1, !paramsOnly);
     if (cfg.ec_stage_limit != 0) {                               // test hook: stencil snapshots through the full pipeline for every texel
+        if (paramsOnly)
+            return MSDFHIP_OK;
         const unsigned cap = GRES ? slowGrid : 16384u;
         const unsigned slowBlocks = (unsigned) ((allTexels+WAVE-1)/WAVE < cap ? (allTexels+WAVE-1)/WAVE : cap);
         hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowBlocks), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
@@ -961,6 +981,8 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     if (GRES && queryLds > (size_t) gLdsLimit.load() && fastLds <= (size_t) gLdsLimit.load()) {
         // More contours than k_ec_query's per-contour LDS scratch holds (~19 000): the full per-texel pipeline with its scratch in the global
         // workspace takes every texel -- slow, but a valid shape is corrected instead of refused (the reference cannot fail either).
+        if (paramsOnly)
+            return MSDFHIP_OK;
         hipLaunchKernelGGL((k_ec_slow<N, OVERLAP, GRES>), dim3(slowGrid), dim3(WAVE), slowLds, stream, viewOf(b), dGlyphs, w, h, src, out, stencil, cfg,
                            (const EcCandidate *) NULL, 0u, 0, gres, gresStride);
         HIPCHK(hipGetLastError());
@@ -981,12 +1003,19 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     // (a wavefront that finds the list empty leaves after one atomic; still, a single 64x64 glyph should not launch thousands of them)
     const size_t wanted = allTexels/512;
     const unsigned queryBlocks = (unsigned) (wanted < 64 ? 64 : wanted > 8192 ? 8192 : wanted);
-    hipLaunchKernelGGL(k_ec_params, dim3((unsigned) b->nGlyphs), dim3(WAVE), 0, stream, b->dEcParams, viewOf(b), dGlyphs, cfg,
-                       reinterpret_cast<unsigned *>(deferred), corners, offsets+ecSizesAt(b->nGlyphs));   // also zeroes the candidate header
+    if (!b->ecParamsAhead)
+        hipLaunchKernelGGL(k_ec_params, dim3((unsigned) b->nGlyphs), dim3(WAVE), 0, stream, b->dEcParams, viewOf(b), dGlyphs, cfg,
+                           reinterpret_cast<unsigned *>(deferred), corners, offsets+ecSizesAt(b->nGlyphs));   // also zeroes the candidate header
     const int *ecOrder = NULL;                                   // glyphs heaviest first for the distance checks' work list (NULL: batch order)
     rc = ensureEcOrder(b, &ecOrder, stream);
     if (rc != MSDFHIP_OK)
         return rc;
+    if (paramsOnly) {
+        HIPCHK(hipGetLastError());
+        b->ecParamsAhead = true;
+        return MSDFHIP_OK;
+    }
+    b->ecParamsAhead = false;
     hipLaunchKernelGGL((k_ec_fast<N>), dim3(blocks), dim3(WAVE), fastLds, stream, viewOf(b), dGlyphs, w, h, tilesX, tiles, src, out, stencil, cfg,
                        (const EcGlyphParams *) b->dEcParams, deferred, seg, b->maxEdges, (const int *) corners);
     hipLaunchKernelGGL(k_ec_scan, dim3(1), dim3(1024), 0, stream, b->nGlyphs, reinterpret_cast<const unsigned *>(deferred), seg, offsets, lpcMaxContours, ecOrder);
@@ -1005,12 +1034,12 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
 
 template <int N>
 int dispatchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, const float *src, float *out, uint8_t *stencil,
-               const MsdfHipConfig &cfg, hipStream_t stream) {
+               const MsdfHipConfig &cfg, hipStream_t stream, bool paramsOnly = false) {
     if (!cfg.overlap_support)
-        return launchEc<N, false, false>(b, dGlyphs, w, h, src, out, stencil, cfg, stream);
+        return launchEc<N, false, false>(b, dGlyphs, w, h, src, out, stencil, cfg, stream, paramsOnly);
     const bool globalRes = (size_t) b->maxContours*WAVE*sizeof(double) > 96*1024;
-    return globalRes ? launchEc<N, true, true>(b, dGlyphs, w, h, src, out, stencil, cfg, stream)
-                     : launchEc<N, true, false>(b, dGlyphs, w, h, src, out, stencil, cfg, stream);
+    return globalRes ? launchEc<N, true, true>(b, dGlyphs, w, h, src, out, stencil, cfg, stream, paramsOnly)
+                     : launchEc<N, true, false>(b, dGlyphs, w, h, src, out, stencil, cfg, stream, paramsOnly);
 }
 
 int checkConfig(const MsdfHipConfig *cfg) {
@@ -1037,8 +1066,28 @@ int ensureScratch(const MsdfHipBatch *b, size_t floats, float **out) {
 
 // Error correction only: src (packed pre-correction tiles) -> out.
 int runCorrection(const MsdfHipBatch *b, int channels, int w, int h, const MsdfHipGlyph *dGlyphs, const float *src, float *out, uint8_t *stencil,
-                  const MsdfHipConfig &cfg, hipStream_t stream) {
-    return channels == 3 ? dispatchEc<3>(b, dGlyphs, w, h, src, out, stencil, cfg, stream) : dispatchEc<4>(b, dGlyphs, w, h, src, out, stencil, cfg, stream);
+                  const MsdfHipConfig &cfg, hipStream_t stream, bool paramsOnly = false) {
+    return channels == 3 ? dispatchEc<3>(b, dGlyphs, w, h, src, out, stencil, cfg, stream, paramsOnly) : dispatchEc<4>(b, dGlyphs, w, h, src, out, stencil, cfg, stream, paramsOnly);
+}
+
+// What a generate call on `b` will need that does NOT depend on other work of the device: the class lists of the overlapping combiner and the correction
+// pass's per-glyph constants. The host-output pipeline queues these on a chunk's stream BEFORE the chunk waits for its turn on the device -- a small
+// kernel launched between two chunks' large ones waits 0.1-0.4 ms for wavefront slots, and every such launch in a chunk's chain delays the whole chunk
+// (rocprofv3 timeline of the pipeline, profiles/r05_ab_notes.md).
+int prepareAhead(const MsdfHipBatch *b, int mode, int w, int h, const MsdfHipGlyph *dGlyphs, const MsdfHipConfig *cfg, hipStream_t stream) {
+    if (b->nGlyphs == 0 || w == 0 || h == 0)
+        return MSDFHIP_OK;
+    const int nch = channelsOf(mode), tilesAll = ((w+TILE-1)/TILE)*((h+TILE-1)/TILE);
+    const bool smallLaunch = (size_t) b->nGlyphs*tilesAll <= (size_t) tuning().smallLaunchTiles;
+    const bool hugeBatch = tileListBytes(b->maxEdges, b->maxContours, true) > (size_t) gLdsLimit.load();
+    int rc = MSDFHIP_OK;
+    if (cfg->overlap_support && b->maxContours > 1 && b->nGlyphs > 1 && !hugeBatch && !smallLaunch) {
+        const int limit = overlapClassLimit(nch);
+        rc = ensureBuckets(b, limit < 1 ? 1 : limit, stream);
+    }
+    if (rc == MSDFHIP_OK && mode >= 3 && cfg->ec_mode != MSDFHIP_EC_DISABLED)
+        rc = runCorrection(b, nch, w, h, dGlyphs, NULL, NULL, NULL, *cfg, stream, true);
+    return rc;
 }
 
 // distanceSignCorrection: src (packed tiles) -> out (packed if dstPacked, else the caller's bitmaps).
@@ -1681,7 +1730,7 @@ int msdfhip_simulate_8bit(float *dPixels, size_t n, void *streamPtr) {
 // of chunk k+1 overlap the device-to-host copy of chunk k. A chunk is a non-owning view of the batch (the CSR arrays are global:
 // a glyph range is the same arrays with shifted glyph offsets).
 
-enum { PIPE_SLOTS = 3 };
+enum { PIPE_SLOTS = 4 };
 struct PipeSlot {
     hipStream_t stream;               // kernels and copy back of the slot's chunk
     hipEvent_t done;                  // the slot's last device-to-host copy has finished
@@ -1793,7 +1842,7 @@ static void sliceBatch(const MsdfHipBatch *b, MsdfHipBatch &v, int g0, int n) {
     }
     v.maxContours = maxC, v.maxEdges = maxE;
     v.bucketLimit = -1;                                          // the class lists are per glyph range
-    v.serialClasses = true;                                      // pipeline chunks overlap each other; side streams per chunk only alias the few hardware queues
+    v.serialClasses = !tuning().pipelineConcurrentClasses;       // pipeline chunks overlap each other; side streams per chunk only alias the few hardware queues
 }
 
 static int fetchGlyphCounts(const MsdfHipBatch *b) {             // device-array batches: the per-glyph counts are read back once
@@ -2070,7 +2119,8 @@ struct StreamFeeder : ChunkFeeder {
         HostPool::wait(*jobs[ci]);
         if (badType[ci] >= 0)
             return fail(MSDFHIP_ERR_INVALID, "shape source: glyph %d did not deliver the contours / edges it counted, or an edge type outside 1..3", badType[ci]);
-        // the chunk after the next one goes into the staging of the slot that chunk ci-1... no: of chunk ci+2-PIPE_SLOTS -- its upload must have left it
+        // keep the host threads two chunks ahead of the device: chunk ci+2 goes into the staging of the slot chunk ci+2-PIPE_SLOTS used -- that chunk's
+        // upload (queued long ago) must have left it
         const size_t ahead = ci+2;
         if (ahead < chunkLen.size()) {
             PipeSlot &q = slots[ahead%PIPE_SLOTS];
@@ -2083,7 +2133,13 @@ struct StreamFeeder : ChunkFeeder {
         }
         const size_t nC = (size_t) (contourBase[(size_t) g0+n]-contourBase[(size_t) g0]), nE = (size_t) (edgeBase[(size_t) g0+n]-edgeBase[(size_t) g0]);
         const Layout l = layout((size_t) n, nC, nE);
-        HIPCHK(hipMemcpyAsync(p.devIn, p.pinnedIn, l.bytes, hipMemcpyHostToDevice, stream));
+        if (tuning().streamUploadByCopy)
+            HIPCHK(hipMemcpyAsync(p.devIn, p.pinnedIn, l.bytes, hipMemcpyHostToDevice, stream));
+        else {                                                   // (a kernel reading the pinned staging: never queues behind another chunk's copy back)
+            const int rcUp = uploadSmall(p.devIn, p.pinnedIn, (l.bytes+15)/16*16, stream);
+            if (rcUp != MSDFHIP_OK)
+                return rcUp;
+        }
         HIPCHK(hipEventRecord(p.inputsUploaded, stream));
         p.inputsInFlight = true;
         MsdfHipBatch &v = p.view;
@@ -2104,15 +2160,11 @@ struct StreamFeeder : ChunkFeeder {
         }
         v.maxContours = maxC, v.maxEdges = maxE;
         v.bucketLimit = -1;
-        v.serialClasses = true;
-        if (ahead >= chunkLen.size() || &slots[ahead%PIPE_SLOTS] == &p) {
-            // (PIPE_SLOTS == 2 would put chunk ci+2 into THIS slot's staging: it is flattened when this chunk's upload has left it, see below)
-        }
+        v.serialClasses = !tuning().pipelineConcurrentClasses;
         return digest(&v, stream);
     }
 
-    // chunk ci+2 shares the staging of chunk ci when there are only two slots; with three (the build's value) the look-ahead above never lands on the same slot
-    static_assert(PIPE_SLOTS >= 3, "StreamFeeder flattens two chunks ahead: it needs three staging areas");
+    static_assert(PIPE_SLOTS >= 3, "StreamFeeder flattens two chunks ahead of the one being queued: it needs three staging areas");
 };
 
 // Rows of the chunk waiting in the slot's pinned staging -> the caller's rectangles (any offsets / strides; nothing else is touched).
@@ -2246,6 +2298,7 @@ static int runPipeline(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, i
     // kernels of the next ones, and the kernels of two consecutive chunks overlap each other (a 2 048-glyph step alone leaves the device
     // half empty in its tails: serialising the chunks' kernels on one stream was measured, 17 instead of 12 ms). THREE slots: with two, the
     // device idled 0.8 ms per chunk while a copy held the slot the next chunk needed (MSDFHIP_PIPELINE_TRACE, profiles/r03_ab_notes.md).
+    const int depth = tuning().pipelineDepth;
     rc = feeder->begin(pipe, lengths);
     if (rc != MSDFHIP_OK)
         return rc;
@@ -2254,8 +2307,6 @@ static int runPipeline(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, i
         const int n = lengths[ci];
         PipeSlot &p = pipe[slot];
         hipStream_t compute = p.stream;
-        if (ci >= 2)                                             // at most two chunks' kernels at a time, in order: chunk k starts when chunk k-2's KERNELS are done
-            HIPCHK(hipStreamWaitEvent(compute, pipe[(slot+PIPE_SLOTS-2)%PIPE_SLOTS].kernelsDone, 0));
         if (p.busy) {                                            // the slot's previous copy must have left its buffers
             HIPCHK(hipEventSynchronize(p.done));
             p.busy = false;
@@ -2326,12 +2377,8 @@ static int runPipeline(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, i
         rc = uploadSmall(dGlyphs, p.pinnedGlyphs, sizeof(MsdfHipGlyph)*(size_t) n, compute);
         if (rc != MSDFHIP_OK)
             break;
-        rc = msdfhip_batch_generate(&p.view, mode, w, h, dGlyphs, dTiles, dStencil, NULL, cfg, compute);
-        if (rc != MSDFHIP_OK)
-            break;
-        const char *dResult = reinterpret_cast<const char *>(dTiles);
-        if (atlas) {                                             // the conversion reads the packed float tiles and blits into the byte layout
-            MsdfHipGlyph *hBlit = p.pinnedGlyphs+p.pinnedGlyphCap, *dBlit = dGlyphs+chunk;
+        MsdfHipGlyph *hBlit = p.pinnedGlyphs+p.pinnedGlyphCap, *dBlit = dGlyphs+chunk;
+        if (atlas) {                                             // descriptors of the conversion: it reads the packed float tiles and blits into the byte layout
             for (int g = 0; g < n; ++g) {
                 hBlit[g] = glyphs[g0+g];
                 if (dense)
@@ -2342,6 +2389,21 @@ static int runPipeline(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, i
             rc = uploadSmall(dBlit, hBlit, sizeof(MsdfHipGlyph)*(size_t) n, compute);
             if (rc != MSDFHIP_OK)
                 break;
+        }
+        // Everything up to here -- the chunk's inputs (streamed calls: upload + digest), its descriptors -- and the two preparations below do not depend on
+        // the chunks before it: they are queued AHEAD of the chunk's turn on the device and run under the earlier chunks' kernels.
+        if (!tuning().pipelineNoAhead) {
+            rc = prepareAhead(&p.view, mode, w, h, dGlyphs, cfg, compute);
+            if (rc != MSDFHIP_OK)
+                break;
+        }
+        if (ci >= (size_t) depth)                                // at most `depth` (two) chunks' kernels at a time, in order: chunk k starts when chunk k-depth's KERNELS are done
+            HIPCHK(hipStreamWaitEvent(compute, pipe[(slot+PIPE_SLOTS-depth)%PIPE_SLOTS].kernelsDone, 0));
+        rc = msdfhip_batch_generate(&p.view, mode, w, h, dGlyphs, dTiles, dStencil, NULL, cfg, compute);
+        if (rc != MSDFHIP_OK)
+            break;
+        const char *dResult = reinterpret_cast<const char *>(dTiles);
+        if (atlas) {
             rc = msdfhip_tiles_to_bytes(dTiles, n, w, h, N, dBlit, dBytes, compute);
             if (rc != MSDFHIP_OK)
                 break;

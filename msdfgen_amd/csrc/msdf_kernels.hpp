@@ -103,8 +103,15 @@ __global__ void k_prep_records(EdgeRec *recs, int nEdges, int nContours, const i
 // Small host-to-device uploads from PINNED host memory as a kernel (the device reads the pinned source over PCIe): descriptors and class
 // lists of a pipeline chunk. As hipMemcpyAsync they go to an SDMA engine and queue up BEHIND the 100 MB device-to-host copy of the previous
 // chunk -- the next chunk's kernels then start only when that copy is done (MSDFHIP_PIPELINE_TRACE showed exactly that).
+// (Round 5: 16 bytes per lane. A lane's load from host memory is a PCIe read of its own; as 4-byte loads the 128 KB descriptor block of a 2 048-glyph
+// chunk took 0.2-0.37 ms -- twice per chunk of the 8-bit pipeline, at the head of the chunk's launch chain (rocprofv3 timeline, profiles/r05_ab_notes.md).)
 __global__ void k_upload_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ srcPinned, size_t nWords) {
-    for (size_t i = (size_t) blockIdx.x*blockDim.x+threadIdx.x; i < nWords; i += (size_t) gridDim.x*blockDim.x)
+    const size_t nQuads = ((reinterpret_cast<size_t>(dst)|reinterpret_cast<size_t>(srcPinned))&15) == 0 ? nWords/4 : 0;
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(srcPinned);
+    uint4 *dst4 = reinterpret_cast<uint4 *>(dst);
+    for (size_t i = (size_t) blockIdx.x*blockDim.x+threadIdx.x; i < nQuads; i += (size_t) gridDim.x*blockDim.x)
+        dst4[i] = src4[i];
+    for (size_t i = nQuads*4+(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < nWords; i += (size_t) gridDim.x*blockDim.x)
         dst[i] = srcPinned[i];
 }
 

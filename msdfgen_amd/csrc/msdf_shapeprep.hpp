@@ -2,11 +2,15 @@
 // generators -- Shape::normalize (core/Shape.cpp:65-92) and edgeColoringSimple (core/edge-coloring.cpp:68-142) -- so that raw outlines
 // can be uploaded once and never come back to the host.
 //
-// Both are sequential along a contour (normalize modifies the previous and the current edge at every cusp; the colouring carries its
-// colour / seed state from contour to contour of a shape), but independent across contours resp. glyphs: normalize runs one thread per
-// contour, the colouring one thread per glyph (integer work; corner detection is redone per contour, it is cheap). Edge counts change
-// (a single-edge contour is split in thirds; a one-corner contour with fewer than three edges is split in six), hence the passes
-//   normalizedCount -> normalizeContour -> colouredCount -> (host prefix over contours) -> colourGlyph.
+// The reference walks a contour edge by edge (normalize modifies the previous and the current edge at every cusp; the colouring carries its
+// colour / seed state from contour to contour of a shape). Here the LANES ARE THE EDGES (round 4): a wavefront takes a contour (normalize:
+// k_prep_normalize_flat, one lane per output edge slot) or a glyph (colouring: k_prep_colour_wave -- corners by ballot, the colour sequence of a
+// contour from prefix popcounts over the corner mask, the seed state carried across the glyph's contours in scalar registers), no per-thread
+// scratch. Edge counts change (a single-edge contour is split in thirds; a one-corner contour with fewer than three edges is split in six),
+// hence the passes   normalizedCount -> normalize -> colouredCount -> (device prefix over contours) -> colour.
+// The helpers below (deconvergeEdge, curveOrderingAt, switchColor, symmetricalTrichotomy) are the per-edge leaves all forms share. Of the serial
+// drivers of rounds 1-3, normalizeContour is still the device's route for the rare contour with a convergent junction (pass 2 of the flat
+// normalize: one lane per FLAGGED contour); the serial colouring survives only in tests/hostemu, the twin the tests compare against the oracle.
 // All arithmetic is the reference's, operation for operation (fp64, no contraction); sin(angleThreshold) is taken on the host.
 #pragma once
 

@@ -120,6 +120,17 @@ class ShapeBatch:
         return ShapeBatch(np.array(gco, np.int32), np.array(co, np.int32), cat(pts, np.float64, (0, 8)).reshape(-1, 8),
                           cat(types, np.int32, (0,)), cat(colors, np.int32, (0,)), np.array(inv, np.uint8), list(names or []))
 
+    def dump(self, path, xfs) -> None:
+        """The flat file tests/shim/shim_check reads to rebuild real msdfgen::Shape objects (`batch`, `e2e`, `flatten` modes): int32 nGlyphs, nContours,
+        nEdges; gco; co; f64 points[nEdges][8]; u8 types; u8 colors; f64 xfs[nGlyphs][6] (sx, sy, tx, ty, range lower, range upper); u8 inverse_y."""
+        gco, co = self.glyph_contour_offsets.astype(np.int32), self.contour_offsets.astype(np.int32)
+        with open(path, "wb") as f:
+            np.array([len(gco)-1, len(co)-1, int(co[-1])], np.int32).tofile(f)
+            gco.tofile(f), co.tofile(f), np.ascontiguousarray(self.points, np.float64).tofile(f)
+            np.ascontiguousarray(self.types, np.uint8).tofile(f), np.ascontiguousarray(self.colors, np.uint8).tofile(f)
+            np.ascontiguousarray(xfs, np.float64).reshape(len(gco)-1, 6).tofile(f)
+            np.ascontiguousarray(self.inverse_y, np.uint8).tofile(f)
+
     def shape(self, g: int) -> FlatShape:
         c0, c1 = int(self.glyph_contour_offsets[g]), int(self.glyph_contour_offsets[g+1])
         e0, e1 = int(self.contour_offsets[c0]), int(self.contour_offsets[c1])

@@ -267,3 +267,55 @@ def test_front_door_spreads_over_the_devices_of_msdfhip_devices(glyphs):
         os.environ.pop("MSDFHIP_DEVICES", None)
         lib.msdfhip_reload_tuning()
     assert lib.msdfhip_front_door_devices(None, 0) == 0
+
+
+def test_streamed_generator_matches_the_resident_pipeline(glyphs):
+    """msdfhip_generate_stream_csr (host CSR arrays -> chunks flattened / uploaded / digested under the kernels of the chunks before) against the device
+    batch: packed float tiles with a stencil, rectangles of an atlas with gaps (host scatter), the 8-bit atlas; several chunk sizes (also one chunk, and
+    chunks far smaller than the list so that every staging slot is reused many times); 1 and many host threads cannot be switched inside one process (the
+    pool is created once) -- the sanitizer driver covers the thread counts."""
+    sub, xfs, want = glyphs
+    lib = L.load()
+    n = sub.n_glyphs
+    st_want = np.zeros((n, 48, 48), np.uint8)
+    hb = M.HostBatch(sub)
+    ref = hb.generate_host(M.MODE_MSDF, 48, 48, xfs, stencil=st_want)
+    hb.close()
+    assert (bits(ref) == bits(want)).all()
+    try:
+        for chunk in (0, 64, 192, 4096):
+            lib.msdfhip_set_pipeline_chunk(chunk)
+            st = np.zeros((n, 48, 48), np.uint8)
+            got = M.generate_stream(sub, M.MODE_MSDF, 48, 48, xfs, stencil=st)
+            assert (bits(got) == bits(want)).all(), chunk
+            assert (st == st_want).all(), chunk
+    finally:
+        lib.msdfhip_set_pipeline_chunk(0)
+    # rectangles of an atlas with a gutter: the chunks take the staging + host scatter route
+    cols, cell = 32, 50
+    rows = (n+cols-1)//cols
+    atlas = np.full((rows*cell, cols*cell, 3), -5, np.float32)
+    offs = np.array([(((g//cols)*cell+1)*cols*cell+(g % cols)*cell+1)*3 for g in range(n)], np.int64)
+    M.generate_stream(sub, M.MODE_MSDF, 48, 48, xfs, out=atlas, out_offsets=offs, row_stride=cols*cell*3)
+    for g in (0, 1, 31, 32, 777, n-1):
+        y, x = (g//cols)*cell+1, (g % cols)*cell+1
+        assert (bits(atlas[y:y+48, x:x+48]) == bits(want[g])).all(), g
+    assert (atlas[0] == -5).all() and (atlas[:, 0] == -5).all() and (atlas[cell-1] == -5).all()
+    # 8-bit atlas, dense row bands
+    cols = 50
+    rows = (n+cols-1)//cols
+    a8 = np.zeros((rows*48, cols*48, 3), np.uint8)
+    offs8 = np.array([((g//cols)*48*cols*48+(g % cols)*48)*3 for g in range(n)], np.int64)
+    M.generate_stream(sub, M.MODE_MSDF, 48, 48, xfs, atlas=a8, out_offsets=offs8, row_stride=cols*48*3)
+    hb = M.HostBatch(sub)
+    b8 = np.zeros_like(a8)
+    hb.generate_bytes_host(M.MODE_MSDF, 48, 48, xfs, b8, offs8, cols*48*3)
+    hb.close()
+    assert (a8 == b8).all()
+    # other field types + an empty shape in the list + a list of one
+    for mode in (M.MODE_SDF, M.MODE_PSDF, M.MODE_MTSDF):
+        few = sub.select(list(range(0, n, 37)))
+        w2 = M.GlyphBatch(few).generate(mode, 48, 48, xfs[::37]).cpu().numpy()
+        assert (bits(M.generate_stream(few, mode, 48, 48, xfs[::37])) == bits(w2)).all(), mode
+    one = sub.select([5])
+    assert (bits(M.generate_stream(one, M.MODE_MSDF, 48, 48, xfs[5:6])) == bits(want[5:6])).all()

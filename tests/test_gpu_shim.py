@@ -103,3 +103,30 @@ def test_reference_client_shapeless_error_correction_through_cpp_shim(tmp_path, 
     pre = oracle.generate(s, mode, w, h, xf, ec_mode=0)
     want = ref.fast_error_correction(pre, xf, 1.11111111111111111 if which == 7 else 1.5, which == 8)
     assert (bits(got) == bits(want)).all()
+
+
+@pytest.mark.parametrize("mode,size,count", [(3, 64, 0), (4, 48, 300), (1, 32, 300), (2, 40, 200)])
+def test_batch_entry_of_the_shim_equals_per_call_results(tmp_path, mode, size, count):
+    """msdfgen_hip::generate*Batch() (include/msdfgen_hip_batch.hpp; VERDICT r4 next #1): a LIST of real msdfgen::Shape objects through ONE pipelined call --
+    host threads flatten chunk k+1 into pinned staging while chunk k is uploaded, digested and rendered and chunk k-1 travels back. The client renders every
+    glyph through its own generate*() call as well and compares: packed float tiles, float rectangles of an atlas (gutters, two cell sizes, both
+    orientations, negative row strides) and an 8-bit atlas (pixelFloatToByte of the per-call floats; gutter bytes untouched) -- zero differing values.
+    The 94 + 1 406 distinct glyphs: Basic Latin (Y-down flags as in the fixture) followed by DejaVu glyphs up to 543 edges / 43 contours."""
+    if not os.path.exists(BIN):
+        pytest.skip("tests/shim/shim_check not built (needs the msdfgen headers)")
+    import json
+    from msdfgen_amd.shape import ShapeBatch, autoframe
+    z = load_npz("dejavu8192.npz")
+    full = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
+                      z["colors"].astype(np.int32), np.zeros(len(z["names"]), bool), [str(n) for n in z["names"]])
+    sub = full.select(list(range(0, 8192, 5)) if count == 0 else list(range(3, 8192, 8192//count))[:count])
+    sub.inverse_y = (np.arange(sub.n_glyphs) % 7 == 3).astype(np.uint8)          # some shapes Y-down: the flip flag is per glyph
+    xfs = np.stack([autoframe(sub.shape(g).bounds(), size, size, 4) for g in range(sub.n_glyphs)])
+    path = tmp_path/"shapes.bin"
+    sub.dump(str(path), xfs)
+    r = subprocess.run([BIN, "batch", str(path), str(mode), str(size), str(size)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    print(res)
+    assert res["glyphs"] == sub.n_glyphs
+    assert res["packed_values_differing"] == 0 and res["atlas_values_differing"] == 0 and res["byte_values_differing"] == 0 and res["gutter_bytes_touched"] == 0
