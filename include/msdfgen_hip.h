@@ -255,6 +255,10 @@ int msdfhip_generate_stream_csr(int device, int mode, int width, int height, int
 /* Host threads of the streamed generator's flatten pool, incl. the calling thread (0 = the usable cores -- affinity mask and cgroup quota --, at most 32; also
  * MSDFHIP_HOST_THREADS). The pool is created on first use: returns 0 when the value was taken, else the size of the pool that already exists. */
 int msdfhip_set_host_threads(int threads);
+/* GPU_MAX_HW_QUEUES as the host process exported it (0: not set -- the HIP runtime then multiplexes all streams onto 4 hardware queues and the chunks of the
+ * generators above wait behind one another's copies: 12.0 instead of 10.2 ms per 8 192 glyphs). The library does not touch the environment; a host that
+ * runs the pipeline with fewer than 8 gets ONE note on stderr (MSDFHIP_QUIET=1 silences it). Figures in README.md / DESIGN.md assume GPU_MAX_HW_QUEUES=8. */
+int msdfhip_hw_queues_env(void);
 /* Glyphs per pipeline chunk (0 = automatic: about 96 MB of float tiles). */
 int msdfhip_set_pipeline_chunk(int glyphs_per_chunk);
 /* Pinned (page-locked, portable across devices) host memory for outputs of the two functions above. */

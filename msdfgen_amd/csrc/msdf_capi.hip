@@ -87,6 +87,9 @@ struct Tuning {
     bool pipelineConcurrentClasses;  // MSDFHIP_PIPELINE_CLASSES=concurrent: a chunk's glyph classes on side streams (default: one after the other on the chunk's stream)
     bool pipelineNoAhead;            // MSDFHIP_PIPELINE_NO_AHEAD    A/B: a chunk's class lists and correction constants inside its launch chain, as before round 5
     bool streamUploadByCopy;         // MSDFHIP_STREAM_UPLOAD=copy: the streamed generator uploads a chunk's inputs with hipMemcpyAsync instead of the upload kernel (A/B)
+    bool pipelineGateDistance;       // MSDFHIP_PIPELINE_GATE=distance|kernels: chunk k+depth takes its turn when chunk k's DISTANCE PASS is done (its correction pass then runs under the
+                                     //                              next chunk's distance pass) or when all its kernels are
+    bool prepLargeTier;              // MSDFHIP_PREP_LARGE_TIER     tests: the colouring kernel always with its 2 048-edge LDS tables (default: 256-edge tier when no contour is longer)
     int hostThreads;                 // MSDFHIP_HOST_THREADS        host threads of the streamed generator's flatten pool (0 = the usable cores, at most 32); read when the pool is created
     long singleSpinLimit;            // MSDFHIP_SINGLE_SPIN_LIMIT   tests: iterations k_single_call's grid barrier waits before it gives up (0 = scaled with the shape)
     bool singleVerbose;              // MSDFHIP_SINGLE_VERBOSE      report abandoned fused launches on stderr
@@ -140,6 +143,8 @@ void readTuning() {
     t.pipelineConcurrentClasses = (env = getenv("MSDFHIP_PIPELINE_CLASSES")) && env[0] == 'c';
     t.pipelineNoAhead = getenv("MSDFHIP_PIPELINE_NO_AHEAD") != NULL;
     t.streamUploadByCopy = (env = getenv("MSDFHIP_STREAM_UPLOAD")) && env[0] == 'c';
+    t.prepLargeTier = getenv("MSDFHIP_PREP_LARGE_TIER") != NULL;
+    t.pipelineGateDistance = (env = getenv("MSDFHIP_PIPELINE_GATE")) ? env[0] == 'd' : false;
     t.hostThreads = (env = getenv("MSDFHIP_HOST_THREADS")) && atoi(env) > 0 ? atoi(env) : 0;
     t.singleSpinLimit = (env = getenv("MSDFHIP_SINGLE_SPIN_LIMIT")) && atol(env) > 0 ? atol(env) : 0;
     t.singleVerbose = getenv("MSDFHIP_SINGLE_VERBOSE") != NULL;
@@ -301,13 +306,14 @@ struct MsdfHipBatch {
     mutable int *dEcOrder;            // glyph indices heaviest first (k_ec_scan / k_ec_query), built on first use; NULL: batch order
     mutable bool ecOrderTried;
     mutable bool ecParamsAhead;       // k_ec_params of the coming correction pass was launched ahead of the distance pass (prepareAhead): launchEc skips it
+    mutable hipEvent_t afterDistance; // host-output pipeline: recorded on the call's stream between the distance pass and what follows it (NULL: not wanted)
     int glyphCap;                     // per-glyph work buffers are sized for max(nGlyphs, glyphCap) glyphs (views of the host-output pipeline)
     mutable hipStream_t sideStream[2];   // the three glyph classes of the distance pass run concurrently: two of them on these (fork / join by events)
     mutable hipEvent_t forkEvent, joinEvent[2];
     MsdfHipBatch() : device(0), nGlyphs(0), nContours(0), nEdges(0), maxContours(0), maxEdges(0), ownsInputs(false), dGlyphContourOffsets(NULL),
                      dContourOffsets(NULL), dPoints(NULL), dTypes(NULL), dColors(NULL), dRecs(NULL), dWindings(NULL), dScratch(NULL), scratchFloats(0),
                      dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
-                     smallMaxC(0), smallMaxE(0), oneMaxE(0), nHuge(0), restMaxC(0), restMaxE(0), restShare(1.f), serialClasses(false), overflowOut(NULL), overflowMirrored(false), hEcOrder(NULL), ecOrderReady(NULL), dEcOrder(NULL), ecOrderTried(false), ecParamsAhead(false), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
+                     smallMaxC(0), smallMaxE(0), oneMaxE(0), nHuge(0), restMaxC(0), restMaxE(0), restShare(1.f), serialClasses(false), overflowOut(NULL), overflowMirrored(false), hEcOrder(NULL), ecOrderReady(NULL), dEcOrder(NULL), ecOrderTried(false), ecParamsAhead(false), afterDistance(NULL), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
 };
 
 namespace {
@@ -1424,12 +1430,17 @@ int msdfhip_batch_create_prepared(MsdfHipBatch **batch, int n_glyphs, const int3
                 PREP_CHK(dev.alloc((void **) &big.minor, eNorm));
             }
         }
-        if (n_glyphs && cfg->coloring == 1)                       // one wavefront per glyph, lanes = edges / corners
-            hipLaunchKernelGGL(k_prep_colour_wave<false>, dim3((unsigned) n_glyphs), dim3(WAVE), 0, 0, norm, (const int32_t *) dGco, (const int32_t *) dCo1, (const int32_t *) dCo2,
-                               n_glyphs, crossThreshold, (const unsigned long long *) dSeeds, (unsigned long long) cfg->seed, fin, big);
-        else if (n_glyphs)
-            hipLaunchKernelGGL(k_prep_colour_wave<true>, dim3((unsigned) n_glyphs), dim3(WAVE), 0, 0, norm, (const int32_t *) dGco, (const int32_t *) dCo1, (const int32_t *) dCo2,
-                               n_glyphs, crossThreshold, (const unsigned long long *) dSeeds, (unsigned long long) cfg->seed, fin, big);
+        // one wavefront per glyph, lanes = edges / corners; the LDS tier of the launch from the batch's longest contour (a contour beyond the tier uses `big`,
+        // which exists only past the large tier: the small tier is chosen only when no contour exceeds it)
+        const bool smallTier = longest <= PREP_WAVE_SMALL_EDGES && !tuning().prepLargeTier;
+        #define PREP_COLOUR(INK, TIER) hipLaunchKernelGGL((k_prep_colour_wave<INK, TIER>), dim3((unsigned) n_glyphs), dim3(WAVE), 0, 0, norm, (const int32_t *) dGco, \
+                                                          (const int32_t *) dCo1, (const int32_t *) dCo2, n_glyphs, crossThreshold, (const unsigned long long *) dSeeds, (unsigned long long) cfg->seed, fin, big)
+        if (n_glyphs && cfg->coloring == 1) {
+            if (smallTier) PREP_COLOUR(false, PREP_WAVE_SMALL_EDGES); else PREP_COLOUR(false, PREP_WAVE_MAX_EDGES);
+        } else if (n_glyphs) {
+            if (smallTier) PREP_COLOUR(true, PREP_WAVE_SMALL_EDGES); else PREP_COLOUR(true, PREP_WAVE_MAX_EDGES);
+        }
+        #undef PREP_COLOUR
         PREP_CHK(hipMemcpy(co2.data(), dCo2, sizeof(int32_t)*(size_t) (nC+1), hipMemcpyDeviceToHost));   // in stream order after the kernels above
         finalCo = co2.data();
         dFinalCo = dCo2;
@@ -1591,6 +1602,8 @@ int msdfhip_batch_generate(const MsdfHipBatch *b, int mode, int w, int h, const 
         case 3: rc = dispatchDistance<3>(b, dGlyphs, w, h, dst, stages != 0, overlap, stream); break;
         default: rc = dispatchDistance<4>(b, dGlyphs, w, h, dst, stages != 0, overlap, stream); break;
     }
+    if (rc == MSDFHIP_OK && b->afterDistance)
+        HIPCHK(hipEventRecord(b->afterDistance, stream));
     if (rc != MSDFHIP_OK || !stages)
         return rc;
     const float *ecSrc = stageA;
@@ -1735,6 +1748,7 @@ struct PipeSlot {
     hipStream_t stream;               // kernels and copy back of the slot's chunk
     hipEvent_t done;                  // the slot's last device-to-host copy has finished
     hipEvent_t kernelsDone;           // the kernels (and the small uploads before them) of the slot's last chunk have finished
+    hipEvent_t distanceDone;          // the distance pass of the slot's last chunk has finished (its correction pass may still run)
     bool busy;
     char *dev;                        // [descriptors | float tiles | stencil | byte tiles]
     size_t devCap;
@@ -1800,7 +1814,7 @@ struct PipeLease {
         fresh->compute = NULL;
         for (int k = 0; k < PIPE_SLOTS; ++k) {
             PipeSlot &s = fresh->slot[k];
-            s.stream = NULL, s.done = NULL, s.kernelsDone = NULL, s.busy = false, s.dev = NULL, s.devCap = 0, s.pinnedGlyphs = NULL, s.pinnedGlyphCap = 0, s.viewCap = 0;
+            s.stream = NULL, s.done = NULL, s.kernelsDone = NULL, s.distanceDone = NULL, s.busy = false, s.dev = NULL, s.devCap = 0, s.pinnedGlyphs = NULL, s.pinnedGlyphCap = 0, s.viewCap = 0;
             s.pinnedTiles = NULL, s.pinnedTilesCap = 0, s.pendingFirst = 0, s.pendingCount = 0;
             s.pinnedIn = NULL, s.pinnedInCap = 0, s.devIn = NULL, s.devInCap = 0, s.inputsUploaded = NULL, s.inputsInFlight = false;
         }
@@ -1812,6 +1826,8 @@ struct PipeLease {
                 e = hipEventCreateWithFlags(&fresh->slot[k].done, hipEventDisableTiming);
             if (e == hipSuccess)
                 e = hipEventCreateWithFlags(&fresh->slot[k].kernelsDone, hipEventDisableTiming);
+            if (e == hipSuccess)
+                e = hipEventCreateWithFlags(&fresh->slot[k].distanceDone, hipEventDisableTiming);
             if (e == hipSuccess)
                 e = hipEventCreateWithFlags(&fresh->slot[k].inputsUploaded, hipEventDisableTiming);
             if (e != hipSuccess) {
@@ -2182,6 +2198,21 @@ static void scatterPending(PipeSlot &p, const MsdfHipGlyph *glyphs, char *dst, s
 // out != NULL: float tiles into the caller's bitmaps (glyphs[g].out_offset / row_stride in floats). atlas != NULL: pixelFloatToByte
 // + blit into the caller's 8-bit atlas (out_offset / row_stride in bytes). Exactly one of the two.
 // b: a resident batch (its chunks are views of it), or NULL with `feeder` = a shape source whose chunks are flattened, uploaded and digested as they come.
+// GPU_MAX_HW_QUEUES as the host process set it (0: unset -- the runtime's default of 4). The library never changes the environment (see the top of this
+// file); a multi-chunk pipeline call of a host that left the default says so ONCE on stderr (MSDFHIP_QUIET silences it): its chunk streams alias on the
+// 4 queues and a chunk's kernels wait behind another chunk's copy back (measured 12.0 instead of 10.2 ms per 8 192 glyphs, INTEGRATION.md "environment").
+static int hwQueuesEnv() {
+    const char *env = getenv("GPU_MAX_HW_QUEUES");
+    return env && atoi(env) > 0 ? atoi(env) : 0;
+}
+static void hintHwQueuesOnce() {
+    static std::atomic<bool> said(false);
+    const int q = hwQueuesEnv();
+    if ((q == 0 || q < 8) && !getenv("MSDFHIP_QUIET") && !said.exchange(true))
+        fprintf(stderr, "msdfgen_hip: note: GPU_MAX_HW_QUEUES is %s; the host-output pipeline overlaps its chunks on distinct hardware queues -- export "
+                        "GPU_MAX_HW_QUEUES=8 before the process starts (INTEGRATION.md, \"environment\"; MSDFHIP_QUIET=1 silences this note)\n", q ? "below 8" : "not set (HIP uses 4)");
+}
+
 static int runPipeline(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, int nGlyphs, int mode, int w, int h, const MsdfHipGlyph *glyphs, float *out, size_t outFloats,
                        uint8_t *atlas, size_t atlasBytes, uint8_t *stencil, const MsdfHipConfig *cfg) {
     if ((!b && !feeder) || !glyphs || (!out && !atlas) || mode < 1 || mode > 4 || w < 0 || h < 0)
@@ -2258,24 +2289,34 @@ static int runPipeline(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, i
         p.view.glyphCap = p.viewCap;                             // sized for a full chunk whatever the length of the slot's first chunk
         p.pendingCount = 0;
     }
-    // Chunk lengths: what the pipeline cannot hide is the kernels of the FIRST chunk and the copy of the LAST one -- with enough glyphs
-    // those two are half chunks (8 192 glyphs: 1 024, 2 048, 2 048, 2 048, 1 024).
+    // Chunk lengths: what the pipeline cannot hide is the kernels (streamed calls: also flatten + upload + digest) of the FIRST chunk and the kernels' tail +
+    // copy of the LAST ones. Round 5 swept the schedule on the streamed end-to-end path (profiles/r05_ab_notes.md, tools/r05_call3.sh; 8 192 glyphs at 64x64):
+    //   float tiles (copy bound: 403 MB at the link's 57 GB/s are 7.4 ms, the kernels 5.7): HALF chunks with a quarter chunk in front -- the copy engine starts
+    //     after 512 glyphs' kernels and never waits again: 512, 1 024 x 7, 512 -> 9.29 ms against 10.0-10.2 for 1 024, 2 048 x 3, 1 024;
+    //   8-bit atlas (kernel bound, a quarter of the bytes): full chunks keep the device fuller; 3/8 of a chunk in front, the remainder in two falling pieces
+    //     (768, 2 048 x 3, 768, 512 -> 7.25-7.30 ms against 7.34-7.38).
     std::vector<int> lengths;
     {
-        const int half = chunk/2 >= 64 ? chunk/2/64*64 : chunk;
         int rem = nG;
-        if (nG >= 2*chunk && half < chunk && !tuning().pipelineUniform) {
-            lengths.push_back(half);
-            for (rem -= half; rem > chunk+half; rem -= chunk)
-                lengths.push_back(chunk);
-            if (rem > chunk)
-                lengths.push_back(rem-half), rem = half;
+        const int unit = out ? (chunk/2 >= 64 ? chunk/2/64*64 : chunk) : chunk;     // the schedule's full chunk (the slots are sized for `chunk` either way)
+        const int first = out ? (unit/2 >= 64 ? unit/2/64*64 : unit) : (unit*3/8 >= 64 ? unit*3/8/64*64 : unit);
+        if (nG >= 2*chunk && first < unit && !tuning().pipelineUniform) {
+            lengths.push_back(first);
+            for (rem -= first; rem > unit+unit/2; rem -= unit)
+                lengths.push_back(unit);
+            if (!out && rem > unit/2) {                          // (8-bit) the tail in two falling pieces
+                const int a = (rem*3/5+63)/64*64 < rem ? (rem*3/5+63)/64*64 : rem;
+                lengths.push_back(a), rem -= a;
+            } else if (out && rem > unit)
+                lengths.push_back(unit), rem -= unit;
         } else
             for (; rem > chunk; rem -= chunk)
                 lengths.push_back(chunk);
         if (rem > 0)
             lengths.push_back(rem);
     }
+    if (lengths.size() > 1)
+        hintHwQueuesOnce();
     if (tuning().pipelineLengths[0]) {                           // experiment knob: explicit schedule, capped by the slots' capacity
         lengths.clear();
         int rem = nG, last = chunk;
@@ -2398,7 +2439,8 @@ static int runPipeline(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, i
                 break;
         }
         if (ci >= (size_t) depth)                                // at most `depth` (two) chunks' kernels at a time, in order: chunk k starts when chunk k-depth's KERNELS are done
-            HIPCHK(hipStreamWaitEvent(compute, pipe[(slot+PIPE_SLOTS-depth)%PIPE_SLOTS].kernelsDone, 0));
+            HIPCHK(hipStreamWaitEvent(compute, tuning().pipelineGateDistance ? pipe[(slot+PIPE_SLOTS-depth)%PIPE_SLOTS].distanceDone : pipe[(slot+PIPE_SLOTS-depth)%PIPE_SLOTS].kernelsDone, 0));
+        p.view.afterDistance = p.distanceDone;
         rc = msdfhip_batch_generate(&p.view, mode, w, h, dGlyphs, dTiles, dStencil, NULL, cfg, compute);
         if (rc != MSDFHIP_OK)
             break;
@@ -2551,6 +2593,8 @@ int msdfhip_set_host_threads(int threads) {
     gHostThreads.store(threads);
     return 0;
 }
+
+int msdfhip_hw_queues_env(void) { return hwQueuesEnv(); }
 
 int msdfhip_set_pipeline_chunk(int glyphs_per_chunk) {
     if (glyphs_per_chunk < 0)
@@ -2775,6 +2819,8 @@ static void destroyPipe(Pipe *p) {
             hipEventDestroy(s.done);
         if (s.kernelsDone)
             hipEventDestroy(s.kernelsDone);
+        if (s.distanceDone)
+            hipEventDestroy(s.distanceDone);
         if (s.stream)
             hipStreamDestroy(s.stream);
     }

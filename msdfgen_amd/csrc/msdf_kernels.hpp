@@ -1827,14 +1827,18 @@ __global__ void __launch_bounds__(256) k_prep_offsets(const int32_t *count, int 
 // edgeColoringSimple / edgeColoringInkTrap, one wavefront per glyph, lanes = edges / corners (colourContourWave): the colour / seed state runs
 // through the glyph's contours (edge-coloring.cpp:68-72, :151-155) as wave-uniform values. Contours of up to PREP_WAVE_MAX_EDGES edges keep
 // their tables in LDS; longer ones in `big` (global, indexed like the edges; allocated only when the batch has such a contour).
-enum { PREP_WAVE_MAX_EDGES = 2048 };
-template <bool INKTRAP>
+// LDS_EDGES: the tier of the launch -- PREP_WAVE_SMALL_EDGES when no contour of the batch is longer (the usual case: font contours have tens of
+// edges; the ink-trap tables then take 5.4 KB per one-wavefront workgroup instead of 45 KB, which had capped a CU at 3 wavefronts), else
+// PREP_WAVE_MAX_EDGES. The host picks it from the longest contour (msdfhip_batch_create_prepared).
+enum { PREP_WAVE_MAX_EDGES = 2048, PREP_WAVE_SMALL_EDGES = 256 };
+template <bool INKTRAP, int LDS_EDGES = PREP_WAVE_MAX_EDGES>
 __global__ void __launch_bounds__(WAVE)
 k_prep_colour_wave(EdgeArrays norm, const int32_t *gco, const int32_t *co1, const int32_t *co2, int nGlyphs, double crossThreshold,
                    const unsigned long long *seeds, unsigned long long seedAll, EdgeArrays out, ColourTables big) {
-    enum { INK_EDGES = INKTRAP ? (int) PREP_WAVE_MAX_EDGES : 1 };
-    __shared__ unsigned long long cornerMask[PREP_WAVE_MAX_EDGES/WAVE];
-    __shared__ unsigned char splineColor[PREP_WAVE_MAX_EDGES];
+    static_assert(LDS_EDGES%WAVE == 0, "one ballot word per 64 edges");
+    enum { INK_EDGES = INKTRAP ? (int) LDS_EDGES : 1 };
+    __shared__ unsigned long long cornerMask[LDS_EDGES/WAVE];
+    __shared__ unsigned char splineColor[LDS_EDGES];
     __shared__ double edgeLength[INK_EDGES], cornerLength[INK_EDGES];
     __shared__ int cornerIndex[INK_EDGES];
     __shared__ unsigned char minor[INK_EDGES];
@@ -1847,7 +1851,7 @@ k_prep_colour_wave(EdgeArrays norm, const int32_t *gco, const int32_t *co1, cons
     int color = initColor(seed);
     for (int c = gco[g]; c < gco[g+1]; ++c) {
         const int ib = co1[c], n = co1[c+1]-ib, ob = co2[c];
-        if (n <= PREP_WAVE_MAX_EDGES) {
+        if (n <= LDS_EDGES) {
             ColourTables lds;
             lds.cornerMask = cornerMask, lds.splineColor = splineColor, lds.edgeLength = edgeLength, lds.cornerLength = cornerLength;
             lds.cornerIndex = cornerIndex, lds.minor = minor;

@@ -247,6 +247,77 @@ int main(int argc, char **argv) {
         EXPECT(msdfhip_generate_sharded(devs, 2, MSDFHIP_MODE_MSDF, W, W, G, s.gco.data(), s.co.data(), s.points.data(), s.types.data(), s.colors.data(),
                                         gd.data(), got.data(), got.size(), NULL, 0, &cfg) == MSDFHIP_ERR_INVALID);
     }
+    // 6. round 5: the STREAMED generator (msdfhip_generate_stream / _stream_csr): the library's host threads call the shape source concurrently and write
+    // straight into pinned staging while earlier chunks are uploaded, rendered and copied back -- chunk sizes from one glyph per chunk ... one chunk,
+    // float tiles + stencil and the 8-bit atlas, two caller threads at once (two pipes, one flatten pool), and a source that miscounts.
+    {
+        struct Src {
+            const Shapes *s;
+            std::atomic<long> counts, fills;
+            int lieAt;
+            static void count(void *u, int g, int32_t *nc, int32_t *ne) {
+                Src *me = (Src *) u;
+                ++me->counts;
+                const Shapes &s = *me->s;
+                *nc = s.gco[g+1]-s.gco[g], *ne = s.co[s.gco[g+1]]-s.co[s.gco[g]];
+            }
+            static void fill(void *u, int g, int32_t edgeBase, int32_t *contourEnd, double *points, uint8_t *types, uint8_t *colors) {
+                Src *me = (Src *) u;
+                ++me->fills;
+                const Shapes &s = *me->s;
+                const int c0 = s.gco[g], nC = s.gco[g+1]-c0, e0 = s.co[c0], nE = s.co[c0+nC]-e0;
+                for (int c = 0; c < nC; ++c)
+                    contourEnd[c] = edgeBase+s.co[c0+c+1]-e0-(g == me->lieAt && c == nC-1 ? 1 : 0);
+                memcpy(points, &s.points[8*(size_t) e0], sizeof(double)*8*(size_t) nE);
+                memcpy(types, &s.types[e0], (size_t) nE), memcpy(colors, &s.colors[e0], (size_t) nE);
+            }
+        } src;
+        src.s = &s, src.counts = 0, src.fills = 0, src.lieAt = -1;
+        MsdfHipShapeSource source = { &src, Src::count, Src::fill };
+        std::vector<uint8_t> st2((size_t) G*W*W), bytesWant(G*tile), bytesGot(G*tile);
+        for (size_t i = 0; i < bytesWant.size(); ++i) {                       // pixelFloatToByte of the float result (core/pixel-conversion.hpp:8-10)
+            const float x = want[i], c = x >= 0.f && x <= 1.f ? x : (float) (x > 0.f);
+            bytesWant[i] = (uint8_t) ~(int) (255.5f-255.f*c);
+        }
+        for (int chunk : { 1, 7, 64, 1000 }) {
+            EXPECT(msdfhip_set_pipeline_chunk(chunk) == MSDFHIP_OK);
+            std::fill(got.begin(), got.end(), -1.f), std::fill(st2.begin(), st2.end(), 0xee);
+            EXPECT(msdfhip_generate_stream(-1, MSDFHIP_MODE_MSDF, W, W, G, &source, gd.data(), got.data(), got.size(), NULL, 0, st2.data(), &cfg) == MSDFHIP_OK);
+            EXPECT(memcmp(got.data(), want.data(), sizeof(float)*got.size()) == 0);
+            EXPECT(memcmp(st2.data(), stencil.data(), st2.size()) == 0);
+            std::fill(bytesGot.begin(), bytesGot.end(), 0);
+            EXPECT(msdfhip_generate_stream_csr(-1, MSDFHIP_MODE_MSDF, W, W, G, s.gco.data(), s.co.data(), s.points.data(), s.types.data(), s.colors.data(), gd.data(),
+                                               NULL, 0, bytesGot.data(), bytesGot.size(), NULL, &cfg) == MSDFHIP_OK);
+            EXPECT(memcmp(bytesGot.data(), bytesWant.data(), bytesGot.size()) == 0);
+        }
+        EXPECT(src.counts.load() == 4L*G && src.fills.load() == 4L*G);       // every glyph exactly once per pass
+        msdfhip_set_pipeline_chunk(16);
+        {
+            std::atomic<int> bad(0);
+            std::vector<std::thread> callers;
+            for (int t = 0; t < 2; ++t)
+                callers.emplace_back([&, t]() {
+                    std::vector<float> mine(G*tile, -2.f);
+                    for (int i = 0; i < 3; ++i) {
+                        const int rc = t ? msdfhip_generate_stream(-1, MSDFHIP_MODE_MSDF, W, W, G, &source, gd.data(), mine.data(), mine.size(), NULL, 0, NULL, &cfg)
+                                         : msdfhip_generate_stream_csr(-1, MSDFHIP_MODE_MSDF, W, W, G, s.gco.data(), s.co.data(), s.points.data(), s.types.data(), s.colors.data(),
+                                                                       gd.data(), mine.data(), mine.size(), NULL, 0, NULL, &cfg);
+                        if (rc != MSDFHIP_OK || memcmp(mine.data(), want.data(), sizeof(float)*mine.size()) != 0)
+                            ++bad;
+                    }
+                });
+            for (auto &th : callers)
+                th.join();
+            EXPECT(bad.load() == 0);
+        }
+        src.lieAt = 57;                                                       // fill delivers one edge fewer than count promised: refused, nothing read past the staging
+        EXPECT(msdfhip_generate_stream(-1, MSDFHIP_MODE_MSDF, W, W, G, &source, gd.data(), got.data(), got.size(), NULL, 0, NULL, &cfg) == MSDFHIP_ERR_INVALID);
+        src.lieAt = -1;
+        EXPECT(msdfhip_generate_stream(-1, MSDFHIP_MODE_MSDF, W, W, G, &source, gd.data(), got.data(), got.size(), NULL, 0, NULL, &cfg) == MSDFHIP_OK);   // and the pipe is usable afterwards
+        EXPECT(memcmp(got.data(), want.data(), sizeof(float)*got.size()) == 0);
+        msdfhip_set_pipeline_chunk(0);
+        EXPECT(msdfhip_trim() == MSDFHIP_OK);
+    }
     printf("san_driver: %d failure(s)\n", failures);
     fflush(stdout);
 #if defined(__has_feature)

@@ -6,6 +6,7 @@ from glibc's in the last ulp; the tests report the number of texels whose bits d
 Stencils (integer flags) must match exactly.
 """
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -921,6 +922,23 @@ def test_shape_preparation_random_vs_oracle(oracle):
     _same_batch(gb.shapes, ShapeBatch.from_shapes([FlatShape(f.contour_offsets, f.points, f.types, f.colors) for f in iwant]), "long contours, ink trap")
     gb.close()
     assert sum(int((np.asarray(a.colors) != np.asarray(b.colors)).any()) for a, b in zip(iwant, bwant)) >= 3    # minor corners were in it
+    # the colouring kernel's SMALL LDS tier (no contour beyond 256 edges: what font batches are) on the contours of 64..256 edges of the same list, and the
+    # large tier forced on the same batch -- both against the oracle
+    mid = [k for k, s in enumerate(big) if int(np.diff(s.contour_offsets).max()) <= 256]
+    assert len(mid) >= 5 and max(int(np.diff(big[k].contour_offsets).max()) for k in mid) >= 200
+    for forced in (False, True):
+        if forced:
+            os.environ["MSDFHIP_PREP_LARGE_TIER"] = "1"
+        M.load().msdfhip_reload_tuning()
+        try:
+            for coloring, wants in ((1, bwant), (2, iwant)):
+                gb = M.GlyphBatch.from_raw(ShapeBatch.from_shapes([big[k] for k in mid]), False, coloring, 3.0, seeds=np.array([bseeds[k] for k in mid], np.uint64))
+                _same_batch(gb.shapes, ShapeBatch.from_shapes([FlatShape(wants[k].contour_offsets, wants[k].points, wants[k].types, wants[k].colors) for k in mid]),
+                            "contours up to 256 edges, colouring %d, %s tier" % (coloring, "large" if forced else "small"))
+                gb.close()
+        finally:
+            os.environ.pop("MSDFHIP_PREP_LARGE_TIER", None)
+            M.load().msdfhip_reload_tuning()
     # shapes built for the preparation passes (tests/test_shape_prep_oracle.py): contours of hundreds of edges, > 64 corners, CUSPS (normalize's
     # serial repair next to the lanes-=-edges pass), one- and two-edge contours (split in thirds) -- normalize x {keep, simple, ink trap}
     from test_shape_prep_oracle import prep_stress_shapes
