@@ -26,6 +26,7 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   cpu_baseline  the compiled reference (or the oracle port) on the host cores, bounded sample
 """
 import argparse
+import ctypes as C
 import json
 import os
 import socket
@@ -439,6 +440,35 @@ def mock_rank(args, rank, world):
         dist.destroy_process_group()
 
 
+def _flush_c_stdio():
+    try:
+        C.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+
+
+def _silence_stdout():
+    """The driver reads ONE JSON line from this command's stdout: ranks other than 0 never write to it (RCCL and gloo print lines of their own per process), and
+    rank 0 closes it behind its line."""
+    sys.stdout.flush()
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+
+
+def _stdout_to_stderr():
+    """While the bench runs, whatever the runtimes print on stdout ("[Gloo] Rank 0 is connected ...", "Librccl path : ...") goes to stderr; returns the saved stdout."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return saved
+
+
+def _restore_stdout(saved):
+    _flush_c_stdio()
+    os.dup2(saved, 1)
+    os.close(saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -469,6 +499,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != max(args.gpus, 1):
         raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1 and rank != 0 and not args.mock:
+        _silence_stdout()
+    saved_stdout = _stdout_to_stderr() if rank == 0 and not args.mock else None
     if args.mock:
         return mock_rank(args, rank, world)
 
@@ -640,13 +673,16 @@ def main():
         res["secondary"] = {"workload": "round 1's bench workload: DejaVuSans Basic-Latin (94 prepared shapes, 15.6 edges / 1.41 contours per glyph) tiled to %d glyphs" % args.glyphs,
                             "glyphs_per_s": args.glyphs*max(5, args.steps//3)/e2, "kernel_ms": {"distance": d2, "error_correction": c2}}
         g2.close()
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(batch, xfs, w, h)
-        print(json.dumps(res))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(batch, xfs, w, h)
+        _restore_stdout(saved_stdout)                                # (everything the runtimes printed meanwhile went to stderr)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        _silence_stdout()                                            # whatever the runtimes still print at exit must not follow rank 0's line
 
 
 if __name__ == "__main__":

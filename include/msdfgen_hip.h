@@ -259,6 +259,10 @@ int msdfhip_set_host_threads(int threads);
  * generators above wait behind one another's copies: 12.0 instead of 10.2 ms per 8 192 glyphs). The library does not touch the environment; a host that
  * runs the pipeline with fewer than 8 gets ONE note on stderr (MSDFHIP_QUIET=1 silences it). Figures in README.md / DESIGN.md assume GPU_MAX_HW_QUEUES=8. */
 int msdfhip_hw_queues_env(void);
+/* How often a host-output / streamed call was run a second time because a glyph's distance-check candidates overflowed their segment (more than 1/16 of its
+ * texels needed a check: overlapping strokes rendered without overlap support, ALWAYS_CHECK_DISTANCE on noise). The chunks of those calls do not launch the
+ * per-texel overflow pass; the count is mirrored to the host with the chunk's results and such a call is repeated with the pass -- same bytes either way. */
+unsigned long long msdfhip_pipeline_overflow_reruns(int reset);
 /* Glyphs per pipeline chunk (0 = automatic: about 96 MB of float tiles). */
 int msdfhip_set_pipeline_chunk(int glyphs_per_chunk);
 /* Pinned (page-locked, portable across devices) host memory for outputs of the two functions above. */

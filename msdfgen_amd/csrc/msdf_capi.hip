@@ -89,6 +89,8 @@ struct Tuning {
     bool streamUploadByCopy;         // MSDFHIP_STREAM_UPLOAD=copy: the streamed generator uploads a chunk's inputs with hipMemcpyAsync instead of the upload kernel (A/B)
     bool pipelineGateDistance;       // MSDFHIP_PIPELINE_GATE=distance|kernels: chunk k+depth takes its turn when chunk k's DISTANCE PASS is done (its correction pass then runs under the
                                      //                              next chunk's distance pass) or when all its kernels are
+    bool pipelineOverflowPass;       // MSDFHIP_PIPELINE_OVERFLOW_PASS  A/B: every chunk of the host-output pipeline launches the per-texel overflow pass (round 4) instead of mirroring the count
+    bool queueMemset;                // MSDFHIP_QUEUE_MEMSET        A/B: zero the persistent launch's work queue with a memset in front of every launch (round 4) instead of by the launch itself
     bool prepLargeTier;              // MSDFHIP_PREP_LARGE_TIER     tests: the colouring kernel always with its 2 048-edge LDS tables (default: 256-edge tier when no contour is longer)
     int hostThreads;                 // MSDFHIP_HOST_THREADS        host threads of the streamed generator's flatten pool (0 = the usable cores, at most 32); read when the pool is created
     long singleSpinLimit;            // MSDFHIP_SINGLE_SPIN_LIMIT   tests: iterations k_single_call's grid barrier waits before it gives up (0 = scaled with the shape)
@@ -144,6 +146,8 @@ void readTuning() {
     t.pipelineNoAhead = getenv("MSDFHIP_PIPELINE_NO_AHEAD") != NULL;
     t.streamUploadByCopy = (env = getenv("MSDFHIP_STREAM_UPLOAD")) && env[0] == 'c';
     t.prepLargeTier = getenv("MSDFHIP_PREP_LARGE_TIER") != NULL;
+    t.queueMemset = getenv("MSDFHIP_QUEUE_MEMSET") != NULL;
+    t.pipelineOverflowPass = getenv("MSDFHIP_PIPELINE_OVERFLOW_PASS") != NULL;
     t.pipelineGateDistance = (env = getenv("MSDFHIP_PIPELINE_GATE")) ? env[0] == 'd' : false;
     t.hostThreads = (env = getenv("MSDFHIP_HOST_THREADS")) && atoi(env) > 0 ? atoi(env) : 0;
     t.singleSpinLimit = (env = getenv("MSDFHIP_SINGLE_SPIN_LIMIT")) && atol(env) > 0 ? atol(env) : 0;
@@ -283,6 +287,8 @@ struct MsdfHipBatch {
     mutable EcCandidate *dDeferred;   // [0] = header (count), [1..cap] = distance checks deferred to k_ec_query
     mutable EcGlyphParams *dEcParams; // per-glyph constants of the error-correction pass
     mutable double *dGres;            // global combiner scratch for glyphs whose contour count exceeds what LDS can hold
+    mutable unsigned *dWorkQueue;     // item counters of the persistent distance launch: TWO sets of 8 per-XCD counters, 64 bytes apart; zeroed once by the host, then each launch zeroes the set the NEXT one uses
+    mutable unsigned queueParity;     // which set the next persistent launch draws from
     mutable size_t gresBytes;
     mutable bool gresExternal;        // dGres belongs to someone else (the single-shape calls carve it from their arena)
     mutable size_t deferredCap;
@@ -312,7 +318,7 @@ struct MsdfHipBatch {
     mutable hipEvent_t forkEvent, joinEvent[2];
     MsdfHipBatch() : device(0), nGlyphs(0), nContours(0), nEdges(0), maxContours(0), maxEdges(0), ownsInputs(false), dGlyphContourOffsets(NULL),
                      dContourOffsets(NULL), dPoints(NULL), dTypes(NULL), dColors(NULL), dRecs(NULL), dWindings(NULL), dScratch(NULL), scratchFloats(0),
-                     dDeferred(NULL), dEcParams(NULL), dGres(NULL), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
+                     dDeferred(NULL), dEcParams(NULL), dGres(NULL), dWorkQueue(NULL), queueParity(0), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
                      smallMaxC(0), smallMaxE(0), oneMaxE(0), nHuge(0), restMaxC(0), restMaxE(0), restShare(1.f), serialClasses(false), overflowOut(NULL), overflowMirrored(false), hEcOrder(NULL), ecOrderReady(NULL), dEcOrder(NULL), ecOrderTried(false), ecParamsAhead(false), afterDistance(NULL), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
 };
 
@@ -402,6 +408,21 @@ int setLds(K kernel, size_t bytes) {
     return MSDFHIP_OK;
 }
 
+// The work queue of the persistent distance launch. Zeroing it with a memset in front of every launch put a tiny kernel at the head of the class's launch
+// chain -- rocprofv3 shows `__amd_rocclr_fillBufferAligned` at 49 us on average (up to 83) per step: it waits for wavefront slots next to the other classes'
+// launches like every small kernel between large ones. A batch now owns TWO sets of counters and its launches alternate between them: a launch draws from one
+// and zeroes the other (distanceBody), so the host zeroes them once, when a batch (or pipeline view) first needs them. (Launches on one batch are ordered
+// on the caller's stream, as they always had to be: they share the batch's workspaces.)
+int ensureWorkQueue(const MsdfHipBatch *b, unsigned **out) {
+    std::lock_guard<std::mutex> lock(b->scratchMutex);
+    if (!b->dWorkQueue) {
+        HIPCHK(hipMalloc((void **) &b->dWorkQueue, 256));
+        HIPCHK(hipMemset(b->dWorkQueue, 0, 256));                 // (synchronous: visible to every stream that will ever launch on it)
+    }
+    *out = b->dWorkQueue;
+    return MSDFHIP_OK;
+}
+
 int ensureGres(const MsdfHipBatch *b, size_t bytes, double **out) {
     std::lock_guard<std::mutex> lock(b->scratchMutex);
     if (b->gresBytes < bytes) {
@@ -461,11 +482,15 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
             chunk = byShare ? shareGrid : slots;
             if (tuning().persistentGrid > 0 && (size_t) tuning().persistentGrid < chunk)
                 chunk = (size_t) tuning().persistentGrid;            // (A/B: a fixed grid)
-            rc = ensureGres(b, chunk*plan.resBytes+8*sizeof(unsigned), &gres);
+            rc = ensureGres(b, chunk*plan.resBytes, &gres);
+            if (rc == MSDFHIP_OK)
+                rc = ensureWorkQueue(b, &queue);
             if (rc != MSDFHIP_OK)
                 return rc;
-            queue = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(gres)+chunk*plan.resBytes);
-            HIPCHK(hipMemsetAsync(queue, 0, 8*sizeof(unsigned), stream));
+            queue += b->queueParity ? 16 : 0;                    // (the kernel finds the other set at `queue ^ 64 bytes`)
+            b->queueParity ^= 1u;
+            if (tuning().queueMemset)                            // (A/B: round 4's memset in front of the launch)
+                HIPCHK(hipMemsetAsync(queue, 0, 8*sizeof(unsigned), stream));
             args.gres = gres, args.gresStride = stride, args.workQueue = queue, args.workItems = (unsigned) blocks;
             launchDistanceKernel<SEL, OVERLAP, GRES, TPW_>((unsigned) chunk, plan.bytes, stream, args);
             HIPCHK(hipGetLastError());
@@ -1547,6 +1572,7 @@ void msdfhip_batch_destroy(MsdfHipBatch *b) {
     if (b->ecOrderReady)
         hipEventDestroy(b->ecOrderReady);
     hipFree(b->dGres);
+    hipFree(b->dWorkQueue);
     if (!b->bucketExternal) {
         hipFree(b->dBucket);
         if (b->hBucket)
@@ -1749,6 +1775,7 @@ struct PipeSlot {
     hipEvent_t done;                  // the slot's last device-to-host copy has finished
     hipEvent_t kernelsDone;           // the kernels (and the small uploads before them) of the slot's last chunk have finished
     hipEvent_t distanceDone;          // the distance pass of the slot's last chunk has finished (its correction pass may still run)
+    unsigned *pinnedOverflow;         // pinned, device-visible word: k_ec_query mirrors the chunk's candidate-overflow count here (no k_ec_slow launch per chunk)
     bool busy;
     char *dev;                        // [descriptors | float tiles | stencil | byte tiles]
     size_t devCap;
@@ -1814,7 +1841,7 @@ struct PipeLease {
         fresh->compute = NULL;
         for (int k = 0; k < PIPE_SLOTS; ++k) {
             PipeSlot &s = fresh->slot[k];
-            s.stream = NULL, s.done = NULL, s.kernelsDone = NULL, s.distanceDone = NULL, s.busy = false, s.dev = NULL, s.devCap = 0, s.pinnedGlyphs = NULL, s.pinnedGlyphCap = 0, s.viewCap = 0;
+            s.stream = NULL, s.done = NULL, s.kernelsDone = NULL, s.distanceDone = NULL, s.pinnedOverflow = NULL, s.busy = false, s.dev = NULL, s.devCap = 0, s.pinnedGlyphs = NULL, s.pinnedGlyphCap = 0, s.viewCap = 0;
             s.pinnedTiles = NULL, s.pinnedTilesCap = 0, s.pendingFirst = 0, s.pendingCount = 0;
             s.pinnedIn = NULL, s.pinnedInCap = 0, s.devIn = NULL, s.devInCap = 0, s.inputsUploaded = NULL, s.inputsInFlight = false;
         }
@@ -1828,6 +1855,11 @@ struct PipeLease {
                 e = hipEventCreateWithFlags(&fresh->slot[k].kernelsDone, hipEventDisableTiming);
             if (e == hipSuccess)
                 e = hipEventCreateWithFlags(&fresh->slot[k].distanceDone, hipEventDisableTiming);
+            if (e == hipSuccess) {
+                e = pinnedAlloc((void **) &fresh->slot[k].pinnedOverflow, 256);
+                if (e == hipSuccess)
+                    fresh->slot[k].pinnedOverflow[0] = 0;
+            }
             if (e == hipSuccess)
                 e = hipEventCreateWithFlags(&fresh->slot[k].inputsUploaded, hipEventDisableTiming);
             if (e != hipSuccess) {
@@ -2213,8 +2245,13 @@ static void hintHwQueuesOnce() {
                         "GPU_MAX_HW_QUEUES=8 before the process starts (INTEGRATION.md, \"environment\"; MSDFHIP_QUIET=1 silences this note)\n", q ? "below 8" : "not set (HIP uses 4)");
 }
 
-static int runPipeline(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, int nGlyphs, int mode, int w, int h, const MsdfHipGlyph *glyphs, float *out, size_t outFloats,
-                       uint8_t *atlas, size_t atlasBytes, uint8_t *stencil, const MsdfHipConfig *cfg) {
+// mirrorOverflow: the chunks' correction passes do not launch the per-texel overflow pass (k_ec_slow: a launch at the END of every chunk's chain that almost
+// never has anything to do, but waits 0.07-0.24 ms for wavefront slots between the other chunks' kernels, rocprofv3 timeline of the pipeline); k_ec_query
+// mirrors the chunk's candidate-overflow count into the slot's pinned word instead, the host looks at it when the chunk's copy is done, and *overflowed says
+// whether any chunk of the call had one -- the caller then runs the call once more WITH the overflow pass (pathological inputs only; same results either way).
+static int runPipelineOnce(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, int nGlyphs, int mode, int w, int h, const MsdfHipGlyph *glyphs, float *out, size_t outFloats,
+                           uint8_t *atlas, size_t atlasBytes, uint8_t *stencil, const MsdfHipConfig *cfg, bool mirrorOverflow, bool *overflowed) {
+    *overflowed = false;
     if ((!b && !feeder) || !glyphs || (!out && !atlas) || mode < 1 || mode > 4 || w < 0 || h < 0)
         return fail(MSDFHIP_ERR_INVALID, "bad arguments to the host-output generator");
     int rc = checkConfig(cfg);
@@ -2352,6 +2389,8 @@ static int runPipeline(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, i
             HIPCHK(hipEventSynchronize(p.done));
             p.busy = false;
             p.view.bucketUploaded = false;
+            if (mirrorOverflow && p.pinnedOverflow[0] != 0)
+                *overflowed = true;
             if (p.pendingCount)
                 scatterPending(p, glyphs, dstBytes, elem, w, h, N);
             p.pendingCount = 0;
@@ -2441,6 +2480,8 @@ static int runPipeline(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, i
         if (ci >= (size_t) depth)                                // at most `depth` (two) chunks' kernels at a time, in order: chunk k starts when chunk k-depth's KERNELS are done
             HIPCHK(hipStreamWaitEvent(compute, tuning().pipelineGateDistance ? pipe[(slot+PIPE_SLOTS-depth)%PIPE_SLOTS].distanceDone : pipe[(slot+PIPE_SLOTS-depth)%PIPE_SLOTS].kernelsDone, 0));
         p.view.afterDistance = p.distanceDone;
+        p.pinnedOverflow[0] = 0;                                 // (the slot's previous chunk is done: nothing on the device writes it any more)
+        p.view.overflowOut = mirrorOverflow ? p.pinnedOverflow : NULL, p.view.overflowMirrored = false;
         rc = msdfhip_batch_generate(&p.view, mode, w, h, dGlyphs, dTiles, dStencil, NULL, cfg, compute);
         if (rc != MSDFHIP_OK)
             break;
@@ -2480,6 +2521,9 @@ static int runPipeline(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, i
         p.busy = false;
         if (e != hipSuccess && rc == MSDFHIP_OK)
             rc = fail(MSDFHIP_ERR_HIP, "host-output pipeline: %s", hipGetErrorString(e));
+        if (mirrorOverflow && e == hipSuccess && p.pinnedOverflow[0] != 0)
+            *overflowed = true;
+        p.view.overflowOut = NULL;
         if (rc == MSDFHIP_OK && p.pendingCount)
             scatterPending(p, glyphs, dstBytes, elem, w, h, N);
         p.pendingCount = 0;
@@ -2499,6 +2543,24 @@ static int runPipeline(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, i
             hipEventDestroy(trace[i].start), hipEventDestroy(trace[i].kernels), hipEventDestroy(trace[i].copied);
     }
     return rc;
+}
+
+static std::atomic<unsigned long long> gPipelineOverflowReruns(0);
+
+static int runPipeline(const MsdfHipBatch *b, ChunkFeeder *feeder, int device, int nGlyphs, int mode, int w, int h, const MsdfHipGlyph *glyphs, float *out, size_t outFloats,
+                       uint8_t *atlas, size_t atlasBytes, uint8_t *stencil, const MsdfHipConfig *cfg) {
+    bool overflowed = false;
+    const bool mirror = !tuning().pipelineOverflowPass;
+    int rc = runPipelineOnce(b, feeder, device, nGlyphs, mode, w, h, glyphs, out, outFloats, atlas, atlasBytes, stencil, cfg, mirror, &overflowed);
+    if (rc == MSDFHIP_OK && overflowed) {                        // some glyph's candidate segment overflowed: the whole call again, every chunk with the overflow pass
+        ++gPipelineOverflowReruns;
+        rc = runPipelineOnce(b, feeder, device, nGlyphs, mode, w, h, glyphs, out, outFloats, atlas, atlasBytes, stencil, cfg, false, &overflowed);
+    }
+    return rc;
+}
+
+unsigned long long msdfhip_pipeline_overflow_reruns(int reset) {
+    return reset ? gPipelineOverflowReruns.exchange(0) : gPipelineOverflowReruns.load();
 }
 
 int msdfhip_batch_generate_host(const MsdfHipBatch *b, int mode, int w, int h, const MsdfHipGlyph *glyphs, float *out, size_t outFloats,
@@ -2802,7 +2864,7 @@ static void destroyPipe(Pipe *p) {
         if (s.stream)
             (void) hipStreamSynchronize(s.stream);
         destroySideStreams(&s.view);
-        hipFree(s.view.dScratch), hipFree(s.view.dDeferred), hipFree(s.view.dEcParams), hipFree(s.view.dGres), hipFree(s.view.dBucket);
+        hipFree(s.view.dScratch), hipFree(s.view.dDeferred), hipFree(s.view.dEcParams), hipFree(s.view.dGres), hipFree(s.view.dWorkQueue), hipFree(s.view.dBucket);
         if (s.view.hBucket)
             pinnedFree(s.view.hBucket);
         hipFree(s.dev);
@@ -2821,6 +2883,8 @@ static void destroyPipe(Pipe *p) {
             hipEventDestroy(s.kernelsDone);
         if (s.distanceDone)
             hipEventDestroy(s.distanceDone);
+        if (s.pinnedOverflow)
+            pinnedFree(s.pinnedOverflow);
         if (s.stream)
             hipStreamDestroy(s.stream);
     }
@@ -3140,7 +3204,7 @@ static int runGroup(ShapeCall *const *calls, int n) {
     }
     struct Owned {                                               // workspaces the launches may have allocated for this view (many-contour shapes)
         MsdfHipBatch &b;
-        ~Owned() { if (!b.gresExternal) hipFree(b.dGres); destroySideStreams(&b); }
+        ~Owned() { if (!b.gresExternal) hipFree(b.dGres); hipFree(b.dWorkQueue); destroySideStreams(&b); }
     } owned = { b };
     const MsdfHipGlyph *dGlyph = reinterpret_cast<const MsdfHipGlyph *>(a.dev+hGlyph);
     float *dOut = reinterpret_cast<float *>(a.dev+hOut);

@@ -458,7 +458,7 @@ struct DistanceArgs {
     size_t gresStride;
     const int *glyphMap;
     int nMapped;
-    unsigned *workQueue;               // persistent launch (global-scratch form only): 8 per-XCD item counters, zeroed by the host
+    unsigned *workQueue;               // persistent launch (global-scratch form only): 8 per-XCD item counters, zero when the launch starts (the launch before it zeroed them: queues alternate)
     unsigned workItems;
 };
 
@@ -482,11 +482,18 @@ __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restr
     unsigned item = blockId+blockBase;
     int steal = 0;
     const bool persistent = GRES && workQueue != NULL;
+    // The queues of a batch come in PAIRS 64 bytes apart and consecutive launches alternate between them: this launch draws from `workQueue` and leaves the
+    // OTHER one zeroed for the next launch -- no memset in front of every launch (msdf_capi.hip: ensureWorkQueue). Done here, at the start, where nothing else
+    // is live: the same reset at a workgroup's exit (a count of the workgroups that left against gridDim.x) cost this kernel 592 SGPR-spill lane moves INSIDE
+    // its edge loop (tools/isa_loop_depth.py) and 40 % of its speed.
     for (;;) {
     if (persistent) {
         item = nextItem(workQueue, workItems, steal);
-        if (item == ~0u)
+        if (item == ~0u) {
+            if (blockId == 0 && threadIdx.x < 8)
+                reinterpret_cast<unsigned *>(reinterpret_cast<size_t>(workQueue)^64u)[threadIdx.x] = 0u;
             return;
+        }
     }
     const int quadsPerGlyph = (tilesPerGlyph+TPW-1)/TPW;
     GlyphWork wk = decodeItem(item, glyphMap ? nMapped : batch.nGlyphs, quadsPerGlyph);

@@ -81,6 +81,7 @@ _PROTOS = {
     "msdfhip_batch_generate_host": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp, C.POINTER(Config)]),
     "msdfhip_batch_generate_bytes_host": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, C.POINTER(Config)]),
     "msdfhip_hw_queues_env": (C.c_int, []),
+    "msdfhip_pipeline_overflow_reruns": (C.c_ulonglong, [C.c_int]),
     "msdfhip_set_pipeline_chunk": (C.c_int, [C.c_int]),
     "msdfhip_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "msdfhip_host_free": (C.c_int, [_vp]),

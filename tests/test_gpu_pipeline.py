@@ -319,3 +319,60 @@ def test_streamed_generator_matches_the_resident_pipeline(glyphs):
         assert (bits(M.generate_stream(few, mode, 48, 48, xfs[::37])) == bits(w2)).all(), mode
     one = sub.select([5])
     assert (bits(M.generate_stream(one, M.MODE_MSDF, 48, 48, xfs[5:6])) == bits(want[5:6])).all()
+
+
+def test_candidate_overflow_in_a_pipeline_chunk_reruns_the_call(glyphs):
+    """The chunks of the host-output pipeline do not launch the per-texel overflow pass of the correction (k_ec_slow) any more: k_ec_query mirrors the
+    chunk's candidate-overflow count into pinned memory and a call that had one is run again with the pass (msdfhip_pipeline_overflow_reruns). Overlapping
+    strokes rendered WITHOUT overlap support under ALWAYS_CHECK_DISTANCE overflow their candidate segments (tests/test_gpu_parity.py:
+    test_candidate_segment_overflow_is_handled_per_glyph): mixed into ordinary glyphs, through packed float tiles, the 8-bit atlas and the streamed generator
+    -- bytes must equal the device batch (whose correction always launches the pass), with and without the mirror."""
+    from msdfgen_amd import synth
+    from msdfgen_amd.shape import autoframe
+    sub, xfs, want48 = glyphs
+    lib = L.load()
+    shapes = [sub.shape(g) for g in range(0, 600, 3)]
+    fr = [xfs[g] for g in range(0, 600, 3)]
+    for k, at in enumerate((17, 90, 91, 160)):
+        s = synth.cjk_like_shape(8801+k)
+        shapes.insert(at, s), fr.insert(at, autoframe(s.bounds(), 48, 48, 4))
+    mix, mxf = ShapeBatch.from_shapes(shapes), np.stack(fr)
+    c = M.MSDFGeneratorConfig(False, M.ErrorCorrectionConfig(M.EC_EDGE_PRIORITY, M.ALWAYS_CHECK_DISTANCE))
+    want = M.GlyphBatch(mix).generate(M.MODE_MSDF, 48, 48, mxf, config=c).cpu().numpy()
+    n = mix.n_glyphs
+    offs8 = np.arange(n, dtype=np.int64)*48*48*3
+    want8 = np.zeros((n, 48, 48, 3), np.uint8)
+    hb = M.HostBatch(mix)
+    try:
+        lib.msdfhip_set_pipeline_chunk(64)
+        lib.msdfhip_pipeline_overflow_reruns(1)
+        got = hb.generate_host(M.MODE_MSDF, 48, 48, mxf, config=c)
+        assert (bits(got) == bits(want)).all()
+        assert lib.msdfhip_pipeline_overflow_reruns(1) == 1, "the stroke glyphs were meant to overflow their candidate segments"
+        hb.generate_bytes_host(M.MODE_MSDF, 48, 48, mxf, want8, offs8, 48*3, config=c)
+        assert lib.msdfhip_pipeline_overflow_reruns(1) == 1
+        conv = (255-(np.float32(255.5)-np.float32(255)*np.clip(want, np.float32(0), np.float32(1))).astype(np.int32)).astype(np.uint8)   # pixelFloatToByte
+        assert (want8 == conv).all()
+        st = np.zeros((n, 48, 48), np.uint8)
+        got = M.generate_stream(mix, M.MODE_MSDF, 48, 48, mxf, config=c, stencil=st)
+        assert (bits(got) == bits(want)).all() and lib.msdfhip_pipeline_overflow_reruns(1) == 1
+        a8 = np.zeros_like(want8)
+        M.generate_stream(mix, M.MODE_MSDF, 48, 48, mxf, atlas=a8, out_offsets=offs8, row_stride=48*3, config=c)
+        assert (a8 == want8).all()
+        # ordinary glyphs only: no second run
+        lib.msdfhip_pipeline_overflow_reruns(1)
+        plain = M.generate_stream(sub.select(list(range(0, 600, 3))), M.MODE_MSDF, 48, 48, np.stack([xfs[g] for g in range(0, 600, 3)]))
+        assert lib.msdfhip_pipeline_overflow_reruns(1) == 0 and (bits(plain) == bits(want48[0:600:3])).all()
+    finally:
+        lib.msdfhip_set_pipeline_chunk(0)
+        hb.close()
+    # the round-4 form (every chunk launches the pass) gives the same bytes
+    import os
+    os.environ["MSDFHIP_PIPELINE_OVERFLOW_PASS"] = "1"
+    lib.msdfhip_reload_tuning()
+    try:
+        got = M.generate_stream(mix, M.MODE_MSDF, 48, 48, mxf, config=c)
+        assert (bits(got) == bits(want)).all() and lib.msdfhip_pipeline_overflow_reruns(1) == 0
+    finally:
+        del os.environ["MSDFHIP_PIPELINE_OVERFLOW_PASS"]
+        lib.msdfhip_reload_tuning()

@@ -54,7 +54,7 @@ def test_rccl_world_of_one_runs_the_bench_collectives(tmp_path):
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300,
                        env=_env({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_PORT": str(_free_port())}))
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
+    d = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])   # (RCCL prints a "Librccl path" line of its own on stdout)
     assert d == {"backend": "nccl", "world": 1, "max": 1.5, "gather_ok": True, "ranks": [0]}
 
 

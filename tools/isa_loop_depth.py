@@ -16,8 +16,8 @@ sys.path.insert(0, ROOT)
 from msdfgen_amd import build as B  # noqa: E402
 
 
-def main():
-    sel, overlap, gres, tpw = (sys.argv[1:5] + ["3", "true", "false", "4"][len(sys.argv[1:5]):])
+def analyse(sel="3", overlap="true", gres="false", tpw="4"):
+    """-> {"resources": {...}, "instructions": {depth: n}, "lane_moves": {depth: n}, "edge_loop": {class: n} or None}"""
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "probe.hip")
         open(src, "w").write('#include "msdf_kernels.hpp"\nusing namespace msdfhip;\n'
@@ -26,6 +26,8 @@ def main():
         flags = [f for f in B.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
         r = subprocess.run([B.hipcc()] + flags + ["-I", B.CSRC, "-I", os.path.join(ROOT, "include"), "-c", "--cuda-device-only", "-save-temps", "-Rpass-analysis=kernel-resource-usage",
                             src, "-o", os.path.join(d, "probe.o")], capture_output=True, text=True, cwd=d)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-2000:])
         asm = open(os.path.join(d, "probe-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
         res = {}
         for line in r.stderr.splitlines():
@@ -52,19 +54,31 @@ def main():
         tot[depth[i]] += 1
         if "v_readlane" in lines[i] or "v_writelane" in lines[i]:
             moves[depth[i]] += 1
+    # the edge loop: from the header of the loop that holds the first hand-placed s_load_dwordx16 batch to its back branch
+    edge = None
+    first = next((i for i in instr if "s_load_dwordx16" in lines[i]), None)
+    hdrs = [i for i in range(first or 0) if re.match(r"\.LBB\d+_\d+:", lines[i]) and "Loop Header" in "".join(lines[i:i+4])]
+    if first is not None and hdrs:
+        label = re.match(r"(\.LBB\d+_\d+):", lines[max(hdrs)]).group(1)
+        backs = [i for i, l in enumerate(lines) if re.search(r"s_c?branch\S*\s+" + re.escape(label) + r"\b", l)]
+        if backs and max(backs) > first:
+            body = [lines[i] for i in instr if max(hdrs) <= i <= max(backs)]
+            mix = [("instructions", r"."), ("f64 arithmetic", r"_f64"), ("v_cndmask", r"v_cndmask"), ("v_mov", r"v_mov_b"), ("v_cmp", r"v_cmp"), ("lane moves", r"v_readlane|v_writelane"),
+                   ("salu", r"^\s+s_(?!waitcnt|load|cbranch|branch|nop)"), ("branches", r"s_c?branch"), ("s_load", r"s_load"), ("lds", r"\bds_")]
+            edge = {n: sum(1 for l in body if re.search(p, l)) for n, p in mix}
+    return {"resources": res, "instructions": dict(tot), "lane_moves": dict(moves), "edge_loop": edge}
+
+
+def main():
+    sel, overlap, gres, tpw = (sys.argv[1:5] + ["3", "true", "false", "4"][len(sys.argv[1:5]):])
+    a = analyse(sel, overlap, gres, tpw)
+    res = a["resources"]
     print("k_distance<%s, %s, %s, %s>: %s" % (sel, overlap, gres, tpw, ", ".join("%s %s" % (k, res[k]) for k in ("VGPRs", "TotalSGPRs", "SGPRs Spill", "VGPRs Spill", "Occupancy") if k in res)))
     print("loop depth   instructions   v_readlane + v_writelane")
-    for k in sorted(tot):
-        print("%10d %14d %10d" % (k, tot[k], moves[k]))
-    # the edge loop: the innermost loop that contains the first s_load_dwordx16
-    first = next(i for i in instr if "s_load_dwordx16" in lines[i])
-    hdr = max(i for i in range(first) if re.match(r"\.LBB\d+_\d+:", lines[i]) and "Loop Header" in "".join(lines[i:i+4]))
-    label = re.match(r"(\.LBB\d+_\d+):", lines[hdr]).group(1)
-    back = max(i for i, l in enumerate(lines) if re.search(r"s_c?branch\S*\s+" + re.escape(label) + r"\b", l))
-    body = [lines[i] for i in instr if hdr <= i <= back]
-    mix = [("f64 arithmetic", r"_f64"), ("v_cndmask", r"v_cndmask"), ("v_mov", r"v_mov_b"), ("v_cmp", r"v_cmp"), ("lane moves", r"v_readlane|v_writelane"), ("salu", r"^\s+s_(?!waitcnt|load|cbranch|branch|nop)"),
-           ("branches", r"s_c?branch"), ("s_load", r"s_load"), ("lds", r"\bds_")]
-    print("edge loop %s .. line %d: %d instructions: %s" % (label, back, len(body), ", ".join("%s %d" % (n, sum(1 for l in body if re.search(p, l))) for n, p in mix)))
+    for k in sorted(a["instructions"]):
+        print("%10d %14d %10d" % (k, a["instructions"][k], a["lane_moves"].get(k, 0)))
+    if a["edge_loop"]:
+        print("edge loop: " + ", ".join("%s %d" % kv for kv in a["edge_loop"].items()))
 
 
 if __name__ == "__main__":
