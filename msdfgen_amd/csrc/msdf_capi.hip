@@ -106,7 +106,7 @@ std::vector<Tuning *> gTuningTables;                             // every table 
 void readTuning() {
     Tuning &t = *new Tuning;
     const char *env;
-    t.resLdsBudget = (env = getenv("MSDFHIP_RES_LDS_BUDGET")) ? (size_t) atol(env) : (size_t) 13*1024;
+    t.resLdsBudget = (env = getenv("MSDFHIP_RES_LDS_BUDGET")) ? (size_t) atol(env) : (size_t) 10*1024;
     t.persistentRounds = (env = getenv("MSDFHIP_PERSISTENT_ROUNDS")) ? atol(env) : 8;
     t.serialClasses = getenv("MSDFHIP_SERIAL_CLASSES") != NULL;
     t.querySlotCap = 160, t.queryLpcContours = 24;
@@ -351,7 +351,7 @@ int digest(MsdfHipBatch *b, hipStream_t stream) {
 struct LdsPlan { size_t bytes; bool globalRes; size_t resBytes, ldsBudget, idxBytes; int listStride; };
 const size_t GRES_WORKSPACE_CAP = (size_t) 1<<30;   // bound of the global combiner scratch; larger launches are chunked
 const int SMALL_MAX_EDGES = 128;                    // cost model only: the edge bound of the LDS-scratch class (tuning().smallMaxEdges is what the launches use)
-const int COST_LDS_MAX_CONTOURS = 7;                // cost model only: the LDS class's contour bound at the default LDS budget, msdf (ensureBuckets derives the real one per launch)
+const int COST_LDS_MAX_CONTOURS = 5;                // cost model only: the LDS class's contour bound at the default LDS budget, msdf (ensureBuckets derives the real one per launch)
 
 // SIMDs of a device (4 per compute unit): the number of wavefronts of a W-waves-per-SIMD kernel it holds at once is residentSlots()*W.
 int residentSlots(int device) {
@@ -372,10 +372,10 @@ int residentSlots(int device) {
 size_t tileListBytes(int maxEdges, int maxContours, bool withBounds) { return ((size_t) maxEdges+(withBounds ? 4 : 1)*(size_t) maxContours+2)*sizeof(int); }
 
 size_t ldsBudget() {
-    // The combiner scratch lives in LDS only while 12 wavefronts (3 per SIMD, the register-limited occupancy) fit a CU's 160 KB:
-    // beyond ~13 KB per wavefront LDS would cap the occupancy (a 20-contour glyph set ran at 1.25 wavefronts/SIMD), so it moves to a
-    // global workspace instead -- written and read once per contour with lane-consecutive addresses.
-    return tuning().resLdsBudget;                                // 13 KB unless MSDFHIP_RES_LDS_BUDGET says otherwise
+    // The combiner scratch lives in LDS only while 16 wavefronts (4 per SIMD, the register-limited occupancy: MSDF_DISTANCE_WAVES_PER_SIMD) fit a CU's
+    // 160 KB: beyond 10 KB per wavefront LDS would cap the occupancy (a 20-contour glyph set ran at 1.25 wavefronts/SIMD), so it moves to a
+    // global workspace instead -- written and read once per contour with lane-consecutive addresses. (13 KB = 12 wavefronts until round 5.)
+    return tuning().resLdsBudget;                                // 10 KB unless MSDFHIP_RES_LDS_BUDGET says otherwise
 }
 
 // maxContours / maxEdges: of the glyphs this launch covers (default: of the whole batch).

@@ -28,8 +28,13 @@
 namespace msdfhip {
 
 #ifndef MSDF_DISTANCE_WAVES_PER_SIMD
-#define MSDF_DISTANCE_WAVES_PER_SIMD 3   // caps k_distance at 168 VGPRs: three wavefronts per SIMD hide the fp64 / scalar-load latency
-                                         // (measured on MI355X, ms per 8192 glyphs: 1 wave 8.7, 2 waves 4.4, 3 waves 3.7, 4 waves 3.9)
+#define MSDF_DISTANCE_WAVES_PER_SIMD 4   // overlapping-combiner instantiations of k_distance: 128 VGPRs, FOUR wavefronts per SIMD. Round 2 measured "1 wave 8.7 ms per 8 192
+                                         // glyphs, 2 waves 4.4, 3 waves 3.7, 4 waves 3.9" and kept three (154-168 VGPRs, no scratch) -- but at the 13 KB of LDS per wavefront of
+                                         // that build a CU holds 12 wavefronts whatever the registers allow, so "4" had measured the spills without the occupancy. Round 5
+                                         // (profiles/r05_ab_notes.md): the 94-164 dwords the 128-VGPR build spills all land OUTSIDE the edge loop (tools/isa_loop_depth.py: 0
+                                         // scratch operations and 0 lane moves at its depth; 44-58 per tile, 49-74 per phase-1 round), and with the LDS budget of the class
+                                         // at 10 KB (msdf_capi.hip: ldsBudget) a CU really holds 16: bench step 5.62 -> 5.39 ms, CJK-like set 13.65 -> 12.45, logo 7.54 -> 7.31.
+                                         // 5 / 6 wavefronts (96 / 80 VGPRs) put scratch traffic into the contour and edge loops: 7.5 / 8.9 ms.
 #endif
 constexpr int TILE = 8;          // 8x8 texels per wavefront
 constexpr int WAVE = 64;

@@ -24,7 +24,7 @@ COST_MODEL = {
 }
 
 
-LDS_MAX_CONTOURS, LDS_MAX_EDGES = 7, 128       # msdf_capi.hip: COST_LDS_MAX_CONTOURS, SMALL_MAX_EDGES (the one place these live on this side)
+LDS_MAX_CONTOURS, LDS_MAX_EDGES = 5, 128       # msdf_capi.hip: COST_LDS_MAX_CONTOURS, SMALL_MAX_EDGES (the one place these live on this side)
 
 
 def glyph_class(contours, edges):

@@ -23,7 +23,7 @@ def analyse(sel="3", overlap="true", gres="false", tpw="4"):
         open(src, "w").write('#include "msdf_kernels.hpp"\nusing namespace msdfhip;\n'
                              "template __global__ void msdfhip::k_distance<%s, %s, %s, %s>(int, const int32_t *, const int32_t *, const EdgeRec *, const int8_t *, const MsdfHipGlyph *, "
                              "int, int, int, int, int, float *, int, unsigned, double *, size_t, const int *, int, unsigned *, unsigned);\n" % (sel, overlap, gres, tpw))
-        flags = [f for f in B.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+        flags = [f for f in B.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]+os.environ.get("MSDF_ISA_FLAGS", "").split()   # e.g. MSDF_ISA_FLAGS=-DMSDF_DISTANCE_WAVES_PER_SIMD=3
         r = subprocess.run([B.hipcc()] + flags + ["-I", B.CSRC, "-I", os.path.join(ROOT, "include"), "-c", "--cuda-device-only", "-save-temps", "-Rpass-analysis=kernel-resource-usage",
                             src, "-o", os.path.join(d, "probe.o")], capture_output=True, text=True, cwd=d)
         if r.returncode != 0:
@@ -49,11 +49,13 @@ def analyse(sel="3", overlap="true", gres="false", tpw="4"):
             d = int(m2.group(1)) if m2 else (d if re.search(r"Loop", txt) else 0)
         depth.append(d)
     instr = [i for i, l in enumerate(lines) if re.match(r"\s+[a-z]", l)]
-    tot, moves = collections.Counter(), collections.Counter()
+    tot, moves, scratch = collections.Counter(), collections.Counter(), collections.Counter()
     for i in instr:
         tot[depth[i]] += 1
         if "v_readlane" in lines[i] or "v_writelane" in lines[i]:
             moves[depth[i]] += 1
+        if re.match(r"\s+scratch_", lines[i]):
+            scratch[depth[i]] += 1
     # the edge loop: from the header of the loop that holds the first hand-placed s_load_dwordx16 batch to its back branch
     edge = None
     first = next((i for i in instr if "s_load_dwordx16" in lines[i]), None)
@@ -63,10 +65,10 @@ def analyse(sel="3", overlap="true", gres="false", tpw="4"):
         backs = [i for i, l in enumerate(lines) if re.search(r"s_c?branch\S*\s+" + re.escape(label) + r"\b", l)]
         if backs and max(backs) > first:
             body = [lines[i] for i in instr if max(hdrs) <= i <= max(backs)]
-            mix = [("instructions", r"."), ("f64 arithmetic", r"_f64"), ("v_cndmask", r"v_cndmask"), ("v_mov", r"v_mov_b"), ("v_cmp", r"v_cmp"), ("lane moves", r"v_readlane|v_writelane"),
+            mix = [("instructions", r"."), ("f64 arithmetic", r"_f64"), ("v_cndmask", r"v_cndmask"), ("v_mov", r"v_mov_b"), ("v_cmp", r"v_cmp"), ("lane moves", r"v_readlane|v_writelane"), ("scratch", r"^\s+scratch_"),
                    ("salu", r"^\s+s_(?!waitcnt|load|cbranch|branch|nop)"), ("branches", r"s_c?branch"), ("s_load", r"s_load"), ("lds", r"\bds_")]
             edge = {n: sum(1 for l in body if re.search(p, l)) for n, p in mix}
-    return {"resources": res, "instructions": dict(tot), "lane_moves": dict(moves), "edge_loop": edge}
+    return {"resources": res, "instructions": dict(tot), "lane_moves": dict(moves), "scratch_ops": dict(scratch), "edge_loop": edge}
 
 
 def main():
@@ -74,9 +76,9 @@ def main():
     a = analyse(sel, overlap, gres, tpw)
     res = a["resources"]
     print("k_distance<%s, %s, %s, %s>: %s" % (sel, overlap, gres, tpw, ", ".join("%s %s" % (k, res[k]) for k in ("VGPRs", "TotalSGPRs", "SGPRs Spill", "VGPRs Spill", "Occupancy") if k in res)))
-    print("loop depth   instructions   v_readlane + v_writelane")
+    print("loop depth   instructions   v_readlane + v_writelane   scratch loads + stores")
     for k in sorted(a["instructions"]):
-        print("%10d %14d %10d" % (k, a["instructions"][k], a["lane_moves"].get(k, 0)))
+        print("%10d %14d %10d %22d" % (k, a["instructions"][k], a["lane_moves"].get(k, 0), a["scratch_ops"].get(k, 0)))
     if a["edge_loop"]:
         print("edge loop: " + ", ".join("%s %d" % kv for kv in a["edge_loop"].items()))
 
