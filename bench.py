@@ -117,7 +117,9 @@ def strong_scaling_one_gpu(M, torch, lib, dev, stream, cfg, steps=6, parts=(2, 4
     for name, (batch, xfs) in config4_sets().items():
         if only and name != only:
             continue
-        whole, kd, kc = step_ms(M, torch, lib, dev, stream, batch, xfs, 48, 48, cfg, steps)
+        # (the whole set twice, 2x the steps, the faster run counts: a single short run of it right behind another workload read 3.9 / 5.0 / 5.6 ms on three boxes
+        # where tools/bench_configs.py measures 3.7-3.8 -- and an inflated T(8192) flatters every efficiency below)
+        whole, kd, kc = min((step_ms(M, torch, lib, dev, stream, batch, xfs, 48, 48, cfg, 2*steps, warmup=3) for _ in range(2)), key=lambda r: r[0])
         row = {"ms_whole_set": round(whole, 3), "glyphs_per_s_1gpu": round(batch.n_glyphs/whole*1e3), "kernel_ms": {"distance": round(kd, 3), "error_correction": round(kc, 3)}}
         for cut, n in [("contiguous", n) for n in parts]+[("dealt", 8)]:
             lists = shard_indices(batch, n, 48, 48, cut)
