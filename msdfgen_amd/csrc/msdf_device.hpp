@@ -1056,7 +1056,6 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
     }
     const double innerScalar = resolve<SEL>(innerD);
     const double outerScalar = resolve<SEL>(outerD);
-#if defined(MSDF_EPILOGUE_VALUES)                                   // rounds 1-4 (A/B): the running choice carried as its NCH values
     double dist[NCH];
     for (int ch = 0; ch < NCH; ++ch)
         dist[ch] = -DBL_MAX;
@@ -1122,72 +1121,6 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
     for (int ch = 0; ch < NCH; ++ch)
         out[ch] = dist[ch];
     profAdd(edges, 11, profNow(edges)-te0);
-#else
-    // Round 5: the running choice of contour-combiners.cpp:104-133 is carried as WHICH distance it is (a contour's index; -1 / -2: the merged inner / outer
-    // selector of a second walk) plus its median dm -- the comparisons only ever look at medians -- and its NCH values are read back once at the end (the
-    // same stored values the loops compared: bit-identical). Carrying the values themselves made `dist` one live range with innerD / outerD, which cross the
-    // walk: at 128 VGPRs the allocator kept that range in scratch and re-stored it inside these loops (44-58 scratch operations per tile, 117 spilled dwords;
-    // now 27 / 61).
-    int winding = 0, which;
-    double dm;
-    if (innerScalar >= 0 && fabs(innerScalar) <= fabs(outerScalar)) {
-        which = nInner == 1 ? firstInner : -1;                   // (one member: the merged selector IS that contour's, whose values are in res)
-        dm = innerScalar;
-        winding = 1;
-        for (int c = 0; c < C; ++c)
-            if (windings[c] > 0) {
-                double cd[NCH];
-                for (int ch = 0; ch < NCH; ++ch)
-                    cd[ch] = res[(c*NCH+ch)*rstride];
-                const double cm = resolve<SEL>(cd);
-                if (fabs(cm) < fabs(outerScalar) && cm > dm) {
-                    which = c;
-                    dm = cm;
-                }
-            }
-    } else if (outerScalar <= 0 && fabs(outerScalar) < fabs(innerScalar)) {
-        which = nOuter == 1 ? firstOuter : -2;
-        dm = outerScalar;
-        winding = -1;
-        for (int c = 0; c < C; ++c)
-            if (windings[c] < 0) {
-                double cd[NCH];
-                for (int ch = 0; ch < NCH; ++ch)
-                    cd[ch] = res[(c*NCH+ch)*rstride];
-                const double cm = resolve<SEL>(cd);
-                if (fabs(cm) < fabs(innerScalar) && cm < dm) {
-                    which = c;
-                    dm = cm;
-                }
-            }
-    } else {
-        for (int ch = 0; ch < NCH; ++ch)
-            out[ch] = shapeD[ch];
-        profAdd(edges, 11, profNow(edges)-te0);
-        return;
-    }
-    for (int c = 0; c < C; ++c)
-        if (windings[c] != winding) {
-            double cd[NCH];
-            for (int ch = 0; ch < NCH; ++ch)
-                cd[ch] = res[(c*NCH+ch)*rstride];
-            const double cm = resolve<SEL>(cd);
-            if (cm*dm >= 0 && fabs(cm) < fabs(dm)) {
-                which = c;
-                dm = cm;
-            }
-        }
-    if (dm == resolve<SEL>(shapeD)) {
-        for (int ch = 0; ch < NCH; ++ch)
-            out[ch] = shapeD[ch];
-    } else if (which >= 0) {
-        for (int ch = 0; ch < NCH; ++ch)
-            out[ch] = res[(which*NCH+ch)*rstride];
-    } else
-        for (int ch = 0; ch < NCH; ++ch)
-            out[ch] = which == -1 ? innerD[ch] : outerD[ch];
-    profAdd(edges, 11, profNow(edges)-te0);
-#endif
 }
 
 // -------------------------------------------------------------------------------------------------------- transform
