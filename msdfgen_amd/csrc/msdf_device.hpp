@@ -967,9 +967,15 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
     enum { NCH = SelTraits<SEL>::NCH };
     Selector<SEL> acc;                               // pass 0: the shape selector; pass 1 / 2: the inner / outer selector of the lanes that need one
     int nInner = 0, nOuter = 0, firstInner = 0, firstOuter = 0;
+    // What the epilogue needs from the passes -- shapeD (pass 0), innerD / outerD (passes 1 / 2, only in the lanes with nInner / nOuter >= 2) -- is NOT carried
+    // around the pass loop in registers: as loop-carried values these nine doubles cross the walk, and the 128-VGPR build (four wavefronts per SIMD) kept them
+    // in scratch, stored at the top of every tile and re-stored at the end of every pass iteration (2.4 GB of scratch stores per 8 192-glyph pass). Instead:
+    // when no lane of the wavefront needs a second walk (the usual case) the shape selector `acc` is still intact after the loop and shapeD is taken from it
+    // THEN; only when a second walk runs are the passes' results parked in `parked` (private memory on the device: volatile, so that it stays memory) --
+    // `second` is wave-uniform.
     double shapeD[NCH], innerD[NCH], outerD[NCH];
-    for (int ch = 0; ch < NCH; ++ch)
-        shapeD[ch] = innerD[ch] = outerD[ch] = -DBL_MAX;
+    volatile double parked[3*NCH];
+    bool second = false;
     MSDF_NOUNROLL
     for (int pass = 0; pass < 3; ++pass) {
         const bool mine = pass == 1 ? nInner >= 2 : nOuter >= 2;
@@ -1036,11 +1042,26 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
                 selMerge(acc, sel);
             profAdd(edges, 9, profNow(edges)-tw1);
         }
-        if (pass == 0)
-            selDistance(acc, shapeD);
-        else if (mine)
-            selDistance(acc, pass == 1 ? innerD : outerD);
+        if (pass == 0) {
+            second = MSDF_WAVE_ANY(nInner >= 2 || nOuter >= 2);
+            if (second) {
+                double t[NCH];
+                selDistance(acc, t);
+                for (int ch = 0; ch < NCH; ++ch)
+                    parked[ch] = t[ch];
+            }
+        } else if (mine) {
+            double t[NCH];
+            selDistance(acc, t);
+            for (int ch = 0; ch < NCH; ++ch)
+                parked[pass*NCH+ch] = t[ch];
+        }
     }
+    if (!second)
+        selDistance(acc, shapeD);                                 // (no pass after the first ran: acc is still the shape selector)
+    else
+        for (int ch = 0; ch < NCH; ++ch)
+            shapeD[ch] = parked[ch];
 #if defined(MSDF_ABLATE_EPILOGUE)                                   // measurement only: what the combiner's selection loops over the stored distances cost
     for (int ch = 0; ch < NCH; ++ch)
         out[ch] = shapeD[ch]+(double) (nInner+nOuter+firstInner+firstOuter);
@@ -1049,10 +1070,14 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
     const unsigned long long te0 = profNow(edges);
     // merged selector with exactly one member == that member's own selector; with none, the initial state (every channel -DBL_MAX)
     for (int ch = 0; ch < NCH; ++ch) {
-        if (nInner == 1)
-            innerD[ch] = res[(firstInner*NCH+ch)*rstride];
-        if (nOuter == 1)
-            outerD[ch] = res[(firstOuter*NCH+ch)*rstride];
+        innerD[ch] = nInner == 1 ? res[(firstInner*NCH+ch)*rstride] : -DBL_MAX;
+        outerD[ch] = nOuter == 1 ? res[(firstOuter*NCH+ch)*rstride] : -DBL_MAX;
+        if (second) {                                            // (wave-uniform; a lane reads what ITS second walk parked)
+            if (nInner >= 2)
+                innerD[ch] = parked[NCH+ch];
+            if (nOuter >= 2)
+                outerD[ch] = parked[2*NCH+ch];
+        }
     }
     const double innerScalar = resolve<SEL>(innerD);
     const double outerScalar = resolve<SEL>(outerD);

@@ -722,8 +722,15 @@ __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restr
         const int yn = gd.flip ? height-1-y : y;                    // output.reorient(shape orientation), msdfgen.cpp:55
         float *px = toScratch ? dst+(((size_t) wk.g*height+yn)*width+x)*NCH
                               : dst+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) NCH*x;
-        for (int ch = 0; ch < NCH; ++ch)
-            px[ch] = mapDistance(t, d[ch]);                         // msdfgen.cpp:20-48
+        for (int ch = 0; ch < NCH; ++ch) {
+#if !defined(MSDF_PLAIN_TILE_STORES)
+            // streaming (nontemporal) stores: 400 MB of tiles per pass otherwise push the 128-VGPR kernels' scratch lines out of L2 (round 5, A/B: the pass's
+            // FETCH_SIZE 361 -> 160 MB, WRITE_SIZE 2.98 -> 2.80 GB, step 5.47 -> 5.39 ms)
+            __builtin_nontemporal_store(mapDistance(t, d[ch]), &px[ch]);   // msdfgen.cpp:20-48
+#else
+            px[ch] = mapDistance(t, d[ch]);
+#endif
+        }
 #if defined(MSDF_PROFILE_WAITS) && !defined(MSDF_LAZY_RECORDS)
         {
             MSDF_STAMP(tTile1);

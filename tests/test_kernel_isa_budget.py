@@ -16,8 +16,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
 
 
-@pytest.mark.parametrize("inst,occupancy,max_vgpr_spill", [(("3", "true", "false", "4"), 4, 130),    # LDS class: 2+ contours, combiner scratch in LDS, four tiles per wavefront
-                                                             (("3", "true", "true", "1"), 4, 110),     # global-scratch class (persistent grid): many contours
+@pytest.mark.parametrize("inst,occupancy,max_vgpr_spill", [(("3", "true", "false", "4"), 4, 40),    # LDS class: 2+ contours, combiner scratch in LDS, four tiles per wavefront
+                                                             (("3", "true", "true", "1"), 4, 40),     # global-scratch class (persistent grid): many contours
                                                              (("3", "false", "false", "4"), 5, 0)])    # one-contour class: simple combiner
 def test_edge_loop_of_k_distance_has_no_spills(inst, occupancy, max_vgpr_spill):
     """The overlapping-combiner instantiations run at FOUR wavefronts per SIMD (128 VGPRs) and spill ~100 dwords to scratch -- which pays only because every
@@ -29,7 +29,7 @@ def test_edge_loop_of_k_distance_has_no_spills(inst, occupancy, max_vgpr_spill):
     assert int(res["VGPRs Spill"]) <= max_vgpr_spill, res
     deep_moves = {d: n for d, n in a["lane_moves"].items() if d >= 4 and n}
     deep_scratch = {d: n for d, n in a["scratch_ops"].items() if d >= 4 and n}
-    assert sum(deep_moves.values()) <= 2, "SGPR-spill lane moves inside the edge loop: %s (by loop depth; resources %s)" % (deep_moves, res)
+    assert sum(deep_moves.values()) <= 4, "SGPR-spill lane moves inside the edge loop: %s (by loop depth; resources %s)" % (deep_moves, res)
     assert not deep_scratch, "scratch loads / stores inside the edge loop: %s (by loop depth; resources %s)" % (deep_scratch, res)
     e = a["edge_loop"]
-    assert e is not None and e["lane moves"] <= 2 and e["scratch"] == 0 and e["f64 arithmetic"] > 300, e
+    assert e is not None and e["lane moves"] <= 4 and e["scratch"] == 0 and e["f64 arithmetic"] > 300, e

@@ -56,18 +56,20 @@ def analyse(sel="3", overlap="true", gres="false", tpw="4"):
             moves[depth[i]] += 1
         if re.match(r"\s+scratch_", lines[i]):
             scratch[depth[i]] += 1
-    # the edge loop: from the header of the loop that holds the first hand-placed s_load_dwordx16 batch to its back branch
+    # the edge loop: the contiguous run of instructions, around the first hand-placed s_load_dwordx16 batch, that sit at that batch's loop depth or deeper
     edge = None
     first = next((i for i in instr if "s_load_dwordx16" in lines[i]), None)
-    hdrs = [i for i in range(first or 0) if re.match(r"\.LBB\d+_\d+:", lines[i]) and "Loop Header" in "".join(lines[i:i+4])]
-    if first is not None and hdrs:
-        label = re.match(r"(\.LBB\d+_\d+):", lines[max(hdrs)]).group(1)
-        backs = [i for i, l in enumerate(lines) if re.search(r"s_c?branch\S*\s+" + re.escape(label) + r"\b", l)]
-        if backs and max(backs) > first:
-            body = [lines[i] for i in instr if max(hdrs) <= i <= max(backs)]
-            mix = [("instructions", r"."), ("f64 arithmetic", r"_f64"), ("v_cndmask", r"v_cndmask"), ("v_mov", r"v_mov_b"), ("v_cmp", r"v_cmp"), ("lane moves", r"v_readlane|v_writelane"), ("scratch", r"^\s+scratch_"),
-                   ("salu", r"^\s+s_(?!waitcnt|load|cbranch|branch|nop)"), ("branches", r"s_c?branch"), ("s_load", r"s_load"), ("lds", r"\bds_")]
-            edge = {n: sum(1 for l in body if re.search(p, l)) for n, p in mix}
+    if first is not None and depth[first] > 0:
+        d0 = depth[first]
+        lo = hi = instr.index(first)
+        while lo > 0 and depth[instr[lo-1]] >= d0:
+            lo -= 1
+        while hi+1 < len(instr) and depth[instr[hi+1]] >= d0:
+            hi += 1
+        body = [lines[i] for i in instr[lo:hi+1]]
+        mix = [("instructions", r"."), ("f64 arithmetic", r"_f64"), ("v_cndmask", r"v_cndmask"), ("v_mov", r"v_mov_b"), ("v_cmp", r"v_cmp"), ("lane moves", r"v_readlane|v_writelane"),
+               ("scratch", r"^\s+scratch_"), ("salu", r"^\s+s_(?!waitcnt|load|cbranch|branch|nop)"), ("branches", r"s_c?branch"), ("s_load", r"s_load"), ("lds", r"\bds_")]
+        edge = {n: sum(1 for l in body if re.search(p, l)) for n, p in mix}
     return {"resources": res, "instructions": dict(tot), "lane_moves": dict(moves), "scratch_ops": dict(scratch), "edge_loop": edge}
 
 
