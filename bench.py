@@ -601,9 +601,9 @@ def main():
                          "algorithmic_bytes_per_launch": ab, "avg_launch_ms": dist_ms, "launches_timed": launches,
                          "note": "arithmetic intensity ~400 fp64 flop/B: the pass is fp64-VALU bound, not HBM bound (SURVEY.md 8d); "
                                  "the HBM fraction is reported as the contract asks, the binding resource is in `valu_fp64`. `traffic`: since round 5 the overlapping-combiner "
-                                 "kernels run at four wavefronts per SIMD (128 VGPRs) and spill ~100 dwords per lane OUTSIDE their edge loop; those scratch stores are "
-                                 "most of WRITE_SIZE (about 2.5 GB per pass next to 0.4 GB of tiles: 8.9x the algorithmic bytes, 0.85 TB/s) and the pass is 6 % faster for "
-                                 "them (3.70 -> 3.48 ms); a -DMSDF_DISTANCE_WAVES_PER_SIMD=3 build is round 4's 1.41x / 3.70 ms (DESIGN.md 3.1)"},
+                                 "kernels run at four wavefronts per SIMD (128 VGPRs) and spill 10-24 dwords per lane OUTSIDE their edge loop; those scratch stores are "
+                                 "about 0.6 GB of WRITE_SIZE next to 0.4 GB of tiles (2.8x the algorithmic bytes; the first 128-VGPR build wrote 3 GB, a 3-wave build 0.47: "
+                                 "DESIGN.md 3.1)"},
             "valu_fp64": {"achieved": gflops, "peak": FP64_VECTOR_PEAK_GFLOPS, "unit": "GFLOP/s (algorithmic ESTIMATE: SURVEY.md 8d's per-edge flop figures over ALL edges; the "
                                                                                       "kernels cull most of them -- not an achieved rate, see measured_*)", "frac": gflops/FP64_VECTOR_PEAK_GFLOPS,
                           "measured_gflops": prof.get("fp64_gflops_pmc") if prof else None,
