@@ -20,8 +20,9 @@ pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.ex
                                                              (("3", "true", "true", "1"), 4, 40),     # global-scratch class (persistent grid): many contours
                                                              (("3", "false", "false", "4"), 5, 0)])    # one-contour class: simple combiner
 def test_edge_loop_of_k_distance_has_no_spills(inst, occupancy, max_vgpr_spill):
-    """The overlapping-combiner instantiations run at FOUR wavefronts per SIMD (128 VGPRs) and spill ~100 dwords to scratch -- which pays only because every
-    spill sits outside the edge loop (5 / 6 wavefronts per SIMD put a handful inside: 7.5 / 8.9 instead of 5.4 ms per step)."""
+    """The overlapping-combiner instantiations run at FOUR wavefronts per SIMD (128 VGPRs) and spill 10-24 dwords to scratch -- which pays only because every
+    spill sits outside the edge loop (5 / 6 wavefronts per SIMD put a handful inside: 7.5 / 8.9 instead of 5.4 ms per step), and only since the combiner's pass
+    results are no longer loop-carried across the walk (94-164 dwords before: 2.4 GB of scratch stores per pass)."""
     from isa_loop_depth import analyse
     a = analyse(*inst)
     res = a["resources"]
