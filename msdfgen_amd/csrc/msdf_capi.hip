@@ -412,12 +412,21 @@ int setLds(K kernel, size_t bytes) {
 // chain -- rocprofv3 shows `__amd_rocclr_fillBufferAligned` at 49 us on average (up to 83) per step: it waits for wavefront slots next to the other classes'
 // launches like every small kernel between large ones. A batch now owns TWO sets of counters and its launches alternate between them: a launch draws from one
 // and zeroes the other (distanceBody), so the host zeroes them once, when a batch (or pipeline view) first needs them. (Launches on one batch are ordered
-// on the caller's stream, as they always had to be: they share the batch's workspaces.)
-int ensureWorkQueue(const MsdfHipBatch *b, unsigned **out) {
+// on the caller's stream, as they always had to be: they share the batch's workspaces.) Their one-time zeroing goes onto the stream of the first launch.
+int ensureWorkQueue(const MsdfHipBatch *b, unsigned **out, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(b->scratchMutex);
     if (!b->dWorkQueue) {
         HIPCHK(hipMalloc((void **) &b->dWorkQueue, 256));
-        HIPCHK(hipMemset(b->dWorkQueue, 0, 256));                 // (synchronous: visible to every stream that will ever launch on it)
+        // Zeroed ON THE STREAM of the launch that needs it first, i.e. ordered in front of that launch. (hipMemset would run on the legacy default stream, which
+        // a non-blocking stream does not wait for, and may return before it has run: the counters could be zeroed UNDER the first launch -- the race the
+        // sanitizer run of round 4 found in the single-call arenas, DESIGN.md 3.9. Later launches on this batch are ordered behind the first by the caller, as
+        // they always had to be: they share the batch's workspaces.)
+        const hipError_t e = hipMemsetAsync(b->dWorkQueue, 0, 256, stream);
+        if (e != hipSuccess) {
+            hipFree(b->dWorkQueue);
+            b->dWorkQueue = NULL;
+            return fail(MSDFHIP_ERR_HIP, "work queue of the persistent launch: %s", hipGetErrorString(e));
+        }
     }
     *out = b->dWorkQueue;
     return MSDFHIP_OK;
@@ -484,7 +493,7 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
                 chunk = (size_t) tuning().persistentGrid;            // (A/B: a fixed grid)
             rc = ensureGres(b, chunk*plan.resBytes, &gres);
             if (rc == MSDFHIP_OK)
-                rc = ensureWorkQueue(b, &queue);
+                rc = ensureWorkQueue(b, &queue, stream);
             if (rc != MSDFHIP_OK)
                 return rc;
             queue += b->queueParity ? 16 : 0;                    // (the kernel finds the other set at `queue ^ 64 bytes`)
