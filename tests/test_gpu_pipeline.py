@@ -376,3 +376,31 @@ def test_candidate_overflow_in_a_pipeline_chunk_reruns_the_call(glyphs):
     finally:
         del os.environ["MSDFHIP_PIPELINE_OVERFLOW_PASS"]
         lib.msdfhip_reload_tuning()
+
+
+def test_automatic_chunk_schedules_at_full_tile_size():
+    """The output-specific chunk schedules (float tiles: a quarter chunk, half chunks, ...; 8-bit atlas: 3/8 chunk, full chunks, a falling tail -- msdf_capi.hip:
+    runPipelineOnce) only engage with AUTOMATIC chunks and at least two of them: 5 000 glyphs at 64x64 (chunks of 2 048), streamed from host arrays and from a
+    resident batch, against the device batch. (tools/stream_sizes_check.py runs 3 000 .. 20 000 glyphs at 32 and 64.)"""
+    z = load_npz("dejavu8192.npz")
+    full = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
+                      z["colors"].astype(np.int32), np.zeros(len(z["names"]), bool), [str(n) for n in z["names"]])
+    n = 5000
+    idx = [(7*i) % 8192 for i in range(n)]
+    sub, xfs = full.select(idx), z["xf64"][idx]
+    L.load().msdfhip_set_pipeline_chunk(0)
+    want = M.GlyphBatch(sub).generate(M.MODE_MSDF, 64, 64, xfs).cpu().numpy()
+    assert (bits(M.generate_stream(sub, M.MODE_MSDF, 64, 64, xfs)) == bits(want)).all()
+    conv = (255-(np.float32(255.5)-np.float32(255)*np.clip(want, np.float32(0), np.float32(1))).astype(np.int32)).astype(np.uint8)
+    offs = np.arange(n, dtype=np.int64)*64*64*3
+    a8 = np.zeros((n, 64, 64, 3), np.uint8)
+    M.generate_stream(sub, M.MODE_MSDF, 64, 64, xfs, atlas=a8, out_offsets=offs, row_stride=64*3)
+    assert (a8 == conv).all()
+    hb = M.HostBatch(sub)
+    try:
+        assert (bits(hb.generate_host(M.MODE_MSDF, 64, 64, xfs)) == bits(want)).all()
+        b8 = np.zeros_like(a8)
+        hb.generate_bytes_host(M.MODE_MSDF, 64, 64, xfs, b8, offs, 64*3)
+        assert (b8 == conv).all()
+    finally:
+        hb.close()
