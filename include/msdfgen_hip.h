@@ -257,7 +257,7 @@ int msdfhip_generate_stream_csr(int device, int mode, int width, int height, int
 int msdfhip_set_host_threads(int threads);
 /* GPU_MAX_HW_QUEUES as the host process exported it (0: not set -- the HIP runtime then multiplexes all streams onto 4 hardware queues and the chunks of the
  * generators above wait behind one another's copies: 12.0 instead of 10.2 ms per 8 192 glyphs). The library does not touch the environment; a host that
- * runs the pipeline with fewer than 8 gets ONE note on stderr (MSDFHIP_QUIET=1 silences it). Figures in README.md / DESIGN.md assume GPU_MAX_HW_QUEUES=8. */
+ * runs the pipeline with fewer than 8 gets ONE note on stderr if MSDFHIP_VERBOSE is set (a drop-in library stays silent by default). Figures in README.md / DESIGN.md assume GPU_MAX_HW_QUEUES=8. */
 int msdfhip_hw_queues_env(void);
 /* How often a host-output / streamed call was run a second time because a glyph's distance-check candidates overflowed their segment (more than 1/16 of its
  * texels needed a check: overlapping strokes rendered without overlap support, ALWAYS_CHECK_DISTANCE on noise). The chunks of those calls do not launch the
@@ -355,6 +355,9 @@ int msdfhip_reload_tuning(void);
  * distance checks of the error correction (-DMSDF_PROFILE_QUERY, tools/profile_query.py; reset = 2 reads its second page); a regular build
  * reports zeros. out24: 24 counters. reset = 1 clears the table after reading. */
 int msdfhip_debug_wait_profile(unsigned long long *out24, int reset);
+/* Measurement builds only (tools/isa_bbcount.py: -DMSDF_BBCOUNT, counter bumps inserted into the kernels' gfx950 assembly): execution counts per basic block of
+ * the instrumented kernels since the last reset. Returns the number of counters written to `out` (at most `cap`); a regular build returns 0. */
+int msdfhip_debug_bbcount(unsigned *out, int cap, int reset);
 /* Fused single-shape launches (k_single_call): out8[0] = calls since the last reset (+ 1e-6 x the shader clock in MHz the launches ran at), out8[1..6] = microseconds per call, as seen by workgroup 0, of:
  * digest | its own distance tile | waiting for all tiles (grid barrier) | its own correction sweep | waiting for all sweeps | distance checks,
  * out8[7] = start of workgroup 0 to the last workgroup's end. Diagnostics (tools/host_call_latency.py). */

@@ -496,13 +496,18 @@ int launchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, in
                 rc = ensureWorkQueue(b, &queue, stream);
             if (rc != MSDFHIP_OK)
                 return rc;
+            // The parity is read and flipped under the batch's scratch mutex, and flipped only once the launch has been ISSUED: a launch that fails to
+            // be issued has neither dirtied its own set nor zeroed the other, so the next launch must draw from the same (still zero) set again --
+            // flipped up front, it would draw from the set the last successful launch left dirty and render no tile of the class.
+            // Launches on one batch are ordered by the caller (they share the batch's workspaces).
+            std::lock_guard<std::mutex> lock(b->scratchMutex);
             queue += b->queueParity ? 16 : 0;                    // (the kernel finds the other set at `queue ^ 64 bytes`)
-            b->queueParity ^= 1u;
             if (tuning().queueMemset)                            // (A/B: round 4's memset in front of the launch)
                 HIPCHK(hipMemsetAsync(queue, 0, 8*sizeof(unsigned), stream));
             args.gres = gres, args.gresStride = stride, args.workQueue = queue, args.workItems = (unsigned) blocks;
             launchDistanceKernel<SEL, OVERLAP, GRES, TPW_>((unsigned) chunk, plan.bytes, stream, args);
             HIPCHK(hipGetLastError());
+            b->queueParity ^= 1u;
             return MSDFHIP_OK;
         }
         chunk = GRES_WORKSPACE_CAP/plan.resBytes;
@@ -1043,7 +1048,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     // (a wavefront that finds the list empty leaves after one atomic; still, a single 64x64 glyph should not launch thousands of them)
     const size_t wanted = allTexels/512;
     const unsigned queryBlocks = (unsigned) (wanted < 64 ? 64 : wanted > 8192 ? 8192 : wanted);
-    if (!b->ecParamsAhead)
+    if (paramsOnly || !b->ecParamsAhead)                         // (the ahead call ALWAYS launches it: a flag left over from a failed call cannot make both calls skip it)
         hipLaunchKernelGGL(k_ec_params, dim3((unsigned) b->nGlyphs), dim3(WAVE), 0, stream, b->dEcParams, viewOf(b), dGlyphs, cfg,
                            reinterpret_cast<unsigned *>(deferred), corners, offsets+ecSizesAt(b->nGlyphs));   // also zeroes the candidate header
     const int *ecOrder = NULL;                                   // glyphs heaviest first for the distance checks' work list (NULL: batch order)
@@ -1899,6 +1904,7 @@ static void sliceBatch(const MsdfHipBatch *b, MsdfHipBatch &v, int g0, int n) {
     }
     v.maxContours = maxC, v.maxEdges = maxE;
     v.bucketLimit = -1;                                          // the class lists are per glyph range
+    v.ecParamsAhead = false;
     v.serialClasses = !tuning().pipelineConcurrentClasses;       // pipeline chunks overlap each other; side streams per chunk only alias the few hardware queues
 }
 
@@ -1950,9 +1956,10 @@ struct HostJob {
     std::function<void(int)> fn;
     int count;
     std::atomic<int> next, done;
+    std::atomic<bool> cancelled;                                 // items not yet started are taken but not run (HostPool::cancelAndWait)
     std::mutex m;
     std::condition_variable cv;
-    HostJob() : count(0), next(0), done(0) { }
+    HostJob() : count(0), next(0), done(0), cancelled(false) { }
 };
 
 class HostPool {
@@ -1962,7 +1969,8 @@ class HostPool {
     std::vector<std::thread> workers;
     static void runItems(HostJob &job) {
         for (int i; (i = job.next.fetch_add(1)) < job.count; ) {
-            job.fn(i);
+            if (!job.cancelled.load())
+                job.fn(i);
             if (job.done.fetch_add(1)+1 == job.count) {
                 std::lock_guard<std::mutex> lock(job.m);
                 job.cv.notify_all();
@@ -2010,6 +2018,12 @@ public:
         while (job.done.load() < job.count)
             job.cv.wait(lock);
     }
+    // A call that ends early: no further item of the job starts, and the items already running on pool threads have returned when this does --
+    // nothing of the job touches the caller's objects or the call's buffers afterwards.
+    static void cancelAndWait(HostJob &job) {
+        job.cancelled.store(true);
+        wait(job);
+    }
 };
 static std::mutex gHostPoolMutex;
 static HostPool *gHostPool = NULL;
@@ -2031,6 +2045,7 @@ static HostPool &hostPool() {
 // -- while the device works on the chunks before it.
 struct ChunkFeeder {
     virtual ~ChunkFeeder() { }
+    virtual void drain() { }                                     // no host work of the feeder is running or will start after this (every exit of runPipelineOnce)
     virtual int begin(PipeSlot *slots, const std::vector<int> &lengths) = 0;
     virtual int prepare(PipeSlot &p, int slot, size_t chunkIndex, int g0, int n, hipStream_t stream) = 0;
 };
@@ -2053,11 +2068,21 @@ struct StreamFeeder : ChunkFeeder {
     std::vector<long long> contourBase, edgeBase;                // prefix sums over the whole list (nG+1)
     std::vector<int> chunkStart, chunkLen;
     std::vector<std::shared_ptr<HostJob> > jobs;                 // flatten job of chunk k
-    std::vector<int> badType;                                    // per chunk: a glyph whose fill produced an edge type outside 1..3 (-1: none)
+    std::unique_ptr<std::atomic<int>[]> badType;                 // per chunk: a glyph whose fill produced an edge type outside 1..3 (-1: none); written by pool threads
     PipeSlot *slots;
     enum { GRAIN = 32 };                                         // glyphs per flatten item
 
     StreamFeeder(const MsdfHipShapeSource *source, int n) : src(source), nG(n), slots(NULL) { }
+    ~StreamFeeder() { drain(); }
+
+    // The flatten jobs run on the detached pool threads, capture `this`, call the caller's fill callbacks and write into the leased pipe's pinned staging:
+    // when the pipeline leaves early (a bad glyph, a HIP error inside the chunk loop) the jobs of the chunks ahead must not outlive the call.
+    void drain() {
+        for (size_t ci = 0; ci < jobs.size(); ++ci)
+            if (jobs[ci])
+                HostPool::cancelAndWait(*jobs[ci]);
+        jobs.clear();
+    }
 
     int count() {                                                // parallel over the glyphs; then the prefix sums
         hContours.assign((size_t) nG, 0), hEdges.assign((size_t) nG, 0);
@@ -2118,7 +2143,7 @@ struct StreamFeeder : ChunkFeeder {
                 for (int e = 0; e < nE && ok; ++e)
                     ok = types[eRel+e] >= 1 && types[eRel+e] <= 3;
                 if (!ok)
-                    badType[ci] = g;                             // (any thread may write it: one int, the value only says which glyph to name)
+                    badType[ci].store(g);                        // (any thread may write it: the value only says which glyph to name)
             }
         }
     }
@@ -2144,7 +2169,9 @@ struct StreamFeeder : ChunkFeeder {
             needIn = l.bytes > needIn ? l.bytes : needIn, needC = nC > needC ? nC : needC, needE = nE > needE ? nE : needE;
         }
         jobs.assign(lengths.size(), std::shared_ptr<HostJob>());
-        badType.assign(lengths.size(), -1);
+        badType.reset(new std::atomic<int>[lengths.size() ? lengths.size() : 1]);
+        for (size_t ci = 0; ci < lengths.size(); ++ci)
+            badType[ci].store(-1);
         const size_t recBytes = (sizeof(EdgeRec)*(needE ? needE : 1)+255)/256*256, devNeed = needIn+recBytes+(needC ? needC : 1)+256;
         for (int k = 0; k < PIPE_SLOTS; ++k) {                   // every slot can take the largest chunk (grown once, kept with the pooled pipe)
             PipeSlot &p = slots[k];
@@ -2174,8 +2201,8 @@ struct StreamFeeder : ChunkFeeder {
 
     int prepare(PipeSlot &p, int slot, size_t ci, int g0, int n, hipStream_t stream) {
         HostPool::wait(*jobs[ci]);
-        if (badType[ci] >= 0)
-            return fail(MSDFHIP_ERR_INVALID, "shape source: glyph %d did not deliver the contours / edges it counted, or an edge type outside 1..3", badType[ci]);
+        if (badType[ci].load() >= 0)
+            return fail(MSDFHIP_ERR_INVALID, "shape source: glyph %d did not deliver the contours / edges it counted, or an edge type outside 1..3", badType[ci].load());
         // keep the host threads two chunks ahead of the device: chunk ci+2 goes into the staging of the slot chunk ci+2-PIPE_SLOTS used -- that chunk's
         // upload (queued long ago) must have left it
         const size_t ahead = ci+2;
@@ -2217,6 +2244,7 @@ struct StreamFeeder : ChunkFeeder {
         }
         v.maxContours = maxC, v.maxEdges = maxE;
         v.bucketLimit = -1;
+        v.ecParamsAhead = false;
         v.serialClasses = !tuning().pipelineConcurrentClasses;
         return digest(&v, stream);
     }
@@ -2240,7 +2268,7 @@ static void scatterPending(PipeSlot &p, const MsdfHipGlyph *glyphs, char *dst, s
 // + blit into the caller's 8-bit atlas (out_offset / row_stride in bytes). Exactly one of the two.
 // b: a resident batch (its chunks are views of it), or NULL with `feeder` = a shape source whose chunks are flattened, uploaded and digested as they come.
 // GPU_MAX_HW_QUEUES as the host process set it (0: unset -- the runtime's default of 4). The library never changes the environment (see the top of this
-// file); a multi-chunk pipeline call of a host that left the default says so ONCE on stderr (MSDFHIP_QUIET silences it): its chunk streams alias on the
+// file); a multi-chunk pipeline call of a host that left the default says so ONCE on stderr when MSDFHIP_VERBOSE is set: its chunk streams alias on the
 // 4 queues and a chunk's kernels wait behind another chunk's copy back (measured 12.0 instead of 10.2 ms per 8 192 glyphs, INTEGRATION.md "environment").
 static int hwQueuesEnv() {
     const char *env = getenv("GPU_MAX_HW_QUEUES");
@@ -2249,9 +2277,9 @@ static int hwQueuesEnv() {
 static void hintHwQueuesOnce() {
     static std::atomic<bool> said(false);
     const int q = hwQueuesEnv();
-    if ((q == 0 || q < 8) && !getenv("MSDFHIP_QUIET") && !said.exchange(true))
+    if ((q == 0 || q < 8) && getenv("MSDFHIP_VERBOSE") && !said.exchange(true))    // opt-in: a drop-in library does not write to its host's stderr; msdfhip_hw_queues_env() reports the same
         fprintf(stderr, "msdfgen_hip: note: GPU_MAX_HW_QUEUES is %s; the host-output pipeline overlaps its chunks on distinct hardware queues -- export "
-                        "GPU_MAX_HW_QUEUES=8 before the process starts (INTEGRATION.md, \"environment\"; MSDFHIP_QUIET=1 silences this note)\n", q ? "below 8" : "not set (HIP uses 4)");
+                        "GPU_MAX_HW_QUEUES=8 before the process starts (INTEGRATION.md, \"environment\")\n", q ? "below 8" : "not set (HIP uses 4)");
 }
 
 // mirrorOverflow: the chunks' correction passes do not launch the per-texel overflow pass (k_ec_slow: a launch at the END of every chunk's chain that almost
@@ -2281,6 +2309,15 @@ static int runPipelineOnce(const MsdfHipBatch *b, ChunkFeeder *feeder, int devic
     ResidentFeeder resident(b);
     if (!feeder)
         feeder = &resident;
+    struct FeederDrain {                                         // declared after the lease: runs BEFORE the pipe goes back to the pool, on every exit (HIPCHK returns included)
+        ChunkFeeder *f;
+        PipeSlot *slots;
+        ~FeederDrain() {
+            f->drain();
+            for (int k = 0; slots && k < PIPE_SLOTS; ++k)
+                slots[k].view.ecParamsAhead = false;             // (a call that failed between prepareAhead and its correction pass must not leave the flag to the pipe's next user)
+        }
+    } drainGuard = { feeder, lease.p->slot };
     PipeSlot *pipe = lease.p->slot;
     const size_t texels = (size_t) w*h, tile = texels*N;         // floats per tile; also bytes per 8-bit tile
     const size_t total = out ? outFloats : atlasBytes, elem = out ? sizeof(float) : 1;
@@ -2360,6 +2397,13 @@ static int runPipelineOnce(const MsdfHipBatch *b, ChunkFeeder *feeder, int devic
                 lengths.push_back(chunk);
         if (rem > 0)
             lengths.push_back(rem);
+        // Every slot (device tiles, descriptors, pinned staging) holds `chunk` glyphs. The schedule's rounded pieces can exceed that when `chunk` is not a
+        // multiple of 64 (msdfhip_set_pipeline_chunk(171), 450 glyphs: 64, 171, 192, 23 -- ADVICE r5): an oversized piece is cut, the cut-off part follows it.
+        for (size_t i = 0; i < lengths.size(); ++i)
+            if (lengths[i] > chunk) {
+                lengths.insert(lengths.begin()+(ptrdiff_t) i+1, lengths[i]-chunk);
+                lengths[i] = chunk;
+            }
     }
     if (lengths.size() > 1)
         hintHwQueuesOnce();
@@ -3904,6 +3948,30 @@ int msdfhip_kernel_timing(double *avgDistance, double *avgCorrection, int *launc
 }
 
 } // extern "C"
+
+// Measurement builds only (-DMSDF_BBCOUNT=<counters>, tools/isa_bbcount.py): the execution count of every basic block of the instrumented kernels. The tool
+// compiles this file to gfx950 assembly, inserts a counter bump at the top of every basic block of the chosen kernels (one lane of a few extra VGPRs per
+// block; exec- and SCC-neutral), flushes the lanes into this table with atomics at s_endpgm, and assembles the result back into a library -- the kernels'
+// own instruction stream is the production one. A regular build has no table and reports 0 counters.
+#if defined(MSDF_BBCOUNT)
+extern "C" __device__ __attribute__((used)) unsigned msdfhip_bbcount[MSDF_BBCOUNT];
+#endif
+extern "C" int msdfhip_debug_bbcount(unsigned *out, int cap, int reset) {
+#if defined(MSDF_BBCOUNT)
+    const int n = cap < (int) MSDF_BBCOUNT ? cap : (int) MSDF_BBCOUNT;
+    HIPCHK(hipDeviceSynchronize());
+    if (out && n > 0)
+        HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(msdfhip_bbcount), sizeof(unsigned)*(size_t) n));
+    if (reset) {
+        static const std::vector<unsigned> zero((size_t) MSDF_BBCOUNT, 0u);
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(msdfhip_bbcount), zero.data(), sizeof(unsigned)*zero.size()));
+    }
+    return n;
+#else
+    (void) out, (void) cap, (void) reset;
+    return 0;
+#endif
+}
 
 // Measurement builds only (-DMSDF_PROFILE_WAITS, tools/profile_waits.py): reads (and optionally clears) the per-wavefront cycle table of
 // k_distance. A regular build has no such table and reports zeros.

@@ -104,6 +104,7 @@ _PROTOS = {
     "msdfhip_front_door_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "msdfhip_debug_wait_profile": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "msdfhip_debug_single_call_phases": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
+    "msdfhip_debug_bbcount": (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.c_int]),
     "msdfhip_generate_stream": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.POINTER(Config)]),
     "msdfhip_generate_stream_csr": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, _bp, _bp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp,
                                               C.POINTER(Config)]),

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -311,7 +312,14 @@ int main(int argc, char **argv) {
             EXPECT(bad.load() == 0);
         }
         src.lieAt = 57;                                                       // fill delivers one edge fewer than count promised: refused, nothing read past the staging
+        const long fillsBefore = src.fills.load();
         EXPECT(msdfhip_generate_stream(-1, MSDFHIP_MODE_MSDF, W, W, G, &source, gd.data(), got.data(), got.size(), NULL, 0, NULL, &cfg) == MSDFHIP_ERR_INVALID);
+        {                                                                     // the flatten jobs of the chunks AHEAD of the failing one must not outlive the call --
+            const long fillsAtReturn = src.fills.load();                      // no callback into the caller's objects after the API has returned (and, under ASan, no write
+            std::this_thread::sleep_for(std::chrono::milliseconds(100));      // into a feeder / a staging area that is gone)
+            EXPECT(src.fills.load() == fillsAtReturn);
+            EXPECT(fillsAtReturn-fillsBefore < (long) G);                     // and the failing call stopped early (chunks of 16, glyph 57 lies): it did not flatten the whole list
+        }
         src.lieAt = -1;
         EXPECT(msdfhip_generate_stream(-1, MSDFHIP_MODE_MSDF, W, W, G, &source, gd.data(), got.data(), got.size(), NULL, 0, NULL, &cfg) == MSDFHIP_OK);   // and the pipe is usable afterwards
         EXPECT(memcmp(got.data(), want.data(), sizeof(float)*got.size()) == 0);

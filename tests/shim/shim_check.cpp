@@ -138,11 +138,11 @@ template <> void batchCall<byte, 1>(int mode, const std::vector<BitmapSection<by
 template <> void batchCall<byte, 3>(int, const std::vector<BitmapSection<byte, 3> > &o, const Dump &d, int first, int n) { msdfgen_hip::generateMSDFBatch(o.data(), d.ptrs.data()+first, d.xf.data()+first, n); }
 template <> void batchCall<byte, 4>(int, const std::vector<BitmapSection<byte, 4> > &o, const Dump &d, int first, int n) { msdfgen_hip::generateMTSDFBatch(o.data(), d.ptrs.data()+first, d.xf.data()+first, n); }
 
-// shim_check batch <dump> <mode> <w> <h> [max glyphs]: every glyph through its OWN generate*() call (the per-call drop-in) and the whole list through
+// shim_check batch <dump> <mode> <w> <h> [max glyphs [file for the packed float tiles]]: every glyph through its OWN generate*() call (the per-call drop-in) and the whole list through
 // generate*Batch() -- packed float tiles, float rectangles of an atlas with gaps / both orientations / two bitmap sizes, and an 8-bit atlas; the batch results must equal
 // the per-call results byte for byte (the 8-bit ones: pixelFloatToByte of them, core/pixel-conversion.hpp:8-10). Prints one JSON line.
 template <int N>
-static int batchCheck(const Dump &d, int mode, int w, int h, int limit) {
+static int batchCheck(const Dump &d, int mode, int w, int h, int limit, const char *packedOut = NULL) {
     const int n = limit > 0 && limit < (int) d.shapes.size() ? limit : (int) d.shapes.size();
     const size_t tile = (size_t) w*h*N;
     std::vector<float> want((size_t) n*tile), packed((size_t) n*tile, -7.f);
@@ -155,6 +155,12 @@ static int batchCheck(const Dump &d, int mode, int w, int h, int limit) {
     long long packedDiff = 0;
     for (size_t i = 0; i < want.size(); ++i)
         packedDiff += memcmp(&want[i], &packed[i], 4) != 0;
+    if (packedOut) {                                                     // the batch entry's packed tiles as they are: the test hashes them against the REFERENCE's tiles
+        FILE *f = fopen(packedOut, "wb");
+        if (!f || fwrite(packed.data(), sizeof(float), packed.size(), f) != packed.size())
+            return 5;
+        fclose(f);
+    }
     // an atlas with a one-texel gutter around every cell, cells of every fifth glyph four texels smaller in both directions (a second launch group),
     // every other cell addressed bottom-up through a negative row stride
     const int cols = 16, cw = w+2, ch = h+2, rows = (n+cols-1)/cols;
@@ -255,7 +261,8 @@ int main(int argc, char **argv) {
             if (!strcmp(argv[1], "e2e"))
                 return e2eBench(d, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]));
             const int mode = atoi(argv[3]), w = atoi(argv[4]), h = atoi(argv[5]), limit = argc > 6 ? atoi(argv[6]) : 0;
-            return mode <= 2 ? batchCheck<1>(d, mode, w, h, limit) : mode == 3 ? batchCheck<3>(d, mode, w, h, limit) : batchCheck<4>(d, mode, w, h, limit);
+            const char *packedOut = argc > 7 ? argv[7] : NULL;
+            return mode <= 2 ? batchCheck<1>(d, mode, w, h, limit, packedOut) : mode == 3 ? batchCheck<3>(d, mode, w, h, limit, packedOut) : batchCheck<4>(d, mode, w, h, limit, packedOut);
         } catch (const std::exception &e) {
             fprintf(stderr, "%s\n", e.what());
             return 4;

@@ -29,6 +29,11 @@ def glyphs():
     idx = list(range(0, 7500, 5))
     sub = full.select(idx)
     want = M.GlyphBatch(sub).generate(M.MODE_MSDF, 48, 48, z["xf48"][idx]).cpu().numpy()
+    # `want` is what every test of this module compares the plumbing with -- itself pinned here to the compiled REFERENCE's sha256 per tile (the fixture's
+    # sha48, tools/make_golden_full.py), so that a defect common to the device batch and the pipelines cannot pass unnoticed.
+    import hashlib
+    for k, g in enumerate(idx):
+        assert (np.frombuffer(hashlib.sha256(np.ascontiguousarray(want[k]).tobytes()).digest(), np.uint8) == z["sha48"][g]).all(), (g, sub.names[k])
     return sub, z["xf48"][idx], want
 
 
@@ -139,6 +144,32 @@ def test_bytes_pipeline_matches_pixel_float_to_byte(glyphs, oracle):
     for g in range(0, n, 7):
         y0, x0 = (g//cols)*48, (g % cols)*48
         assert (atlas[y0:y0+48, x0:x0+48] == ref[g]).all(), g
+
+
+@pytest.mark.parametrize("chunk,n", [(171, 450), (180, 700), (100, 333), (65, 1500)])
+def test_bytes_pipeline_with_chunk_sizes_that_are_not_multiples_of_64(glyphs, oracle, chunk, n):
+    """the 8-bit tail schedule rounds its pieces to 64 glyphs; with msdfhip_set_pipeline_chunk(171) and 450 glyphs it scheduled 64, 171, 192, 23 --
+    a 192-glyph piece in slots sized for 171 (device tiles, descriptors, pinned staging). Every scheduled piece is now cut to the slot capacity; the resident
+    and the streamed pipeline, 8-bit and float, against the device batch."""
+    sub, xfs, want = glyphs
+    part = sub.select(list(range(n)))
+    ref = oracle.pixel_float_to_byte(want[:n])
+    offs = np.arange(n, dtype=np.int64)*48*48*3
+    lib = L.load()
+    hb = M.HostBatch(part)
+    try:
+        lib.msdfhip_set_pipeline_chunk(chunk)
+        packed = np.zeros((n, 48, 48, 3), np.uint8)
+        hb.generate_bytes_host(M.MODE_MSDF, 48, 48, xfs[:n], packed, offs, 48*3)
+        assert (packed == ref).all()
+        a8 = np.zeros((n, 48, 48, 3), np.uint8)
+        M.generate_stream(part, M.MODE_MSDF, 48, 48, xfs[:n], atlas=a8, out_offsets=offs, row_stride=48*3)
+        assert (a8 == ref).all()
+        assert (bits(hb.generate_host(M.MODE_MSDF, 48, 48, xfs[:n])) == bits(want[:n])).all()
+        assert (bits(M.generate_stream(part, M.MODE_MSDF, 48, 48, xfs[:n])) == bits(want[:n])).all()
+    finally:
+        lib.msdfhip_set_pipeline_chunk(0)
+        hb.close()
 
 
 def test_sharded_over_the_same_device_is_byte_identical(glyphs):

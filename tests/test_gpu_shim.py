@@ -119,14 +119,26 @@ def test_batch_entry_of_the_shim_equals_per_call_results(tmp_path, mode, size, c
     z = load_npz("dejavu8192.npz")
     full = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
                       z["colors"].astype(np.int32), np.zeros(len(z["names"]), bool), [str(n) for n in z["names"]])
-    sub = full.select(list(range(0, 8192, 5)) if count == 0 else list(range(3, 8192, 8192//count))[:count])
+    idx = list(range(0, 8192, 5)) if count == 0 else list(range(3, 8192, 8192//count))[:count]
+    sub = full.select(idx)
     sub.inverse_y = (np.arange(sub.n_glyphs) % 7 == 3).astype(np.uint8)          # some shapes Y-down: the flip flag is per glyph
-    xfs = np.stack([autoframe(sub.shape(g).bounds(), size, size, 4) for g in range(sub.n_glyphs)])
+    pinned = (mode, size) == (3, 64)                                               # the fixture holds the REFERENCE's sha256 per msdf 64x64 tile (xf64 = the same framing)
+    xfs = z["xf64"][idx] if pinned else np.stack([autoframe(sub.shape(g).bounds(), size, size, 4) for g in range(sub.n_glyphs)])
     path = tmp_path/"shapes.bin"
     sub.dump(str(path), xfs)
-    r = subprocess.run([BIN, "batch", str(path), str(mode), str(size), str(size)], capture_output=True, text=True, timeout=600)
+    packed = tmp_path/"packed.f32"
+    r = subprocess.run([BIN, "batch", str(path), str(mode), str(size), str(size)] + (["0", str(packed)] if pinned else []), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
     res = json.loads(r.stdout.strip().splitlines()[-1])
     print(res)
     assert res["glyphs"] == sub.n_glyphs
     assert res["packed_values_differing"] == 0 and res["atlas_values_differing"] == 0 and res["byte_values_differing"] == 0 and res["gutter_bytes_touched"] == 0
+    if pinned:
+        # ... and not only against the HIP path's own per-call results: the batch entry's packed tiles against the compiled reference's
+        # hashes of the same glyphs (tools/make_golden_full.py). A tile whose bitmap orientation differs from its shape's comes back with its rows reversed.
+        import hashlib
+        tiles = np.fromfile(packed, np.float32).reshape(sub.n_glyphs, size, size, 3)
+        for g in range(sub.n_glyphs):
+            flipped = bool(sub.inverse_y[g]) != (g % 3 == 1)                       # shim_check renders every third bitmap Y_DOWNWARD
+            tile = np.ascontiguousarray(tiles[g, ::-1] if flipped else tiles[g])
+            assert (np.frombuffer(hashlib.sha256(tile.tobytes()).digest(), np.uint8) == z["sha64"][idx[g]]).all(), (g, sub.names[g], flipped)
