@@ -3954,7 +3954,7 @@ int msdfhip_kernel_timing(double *avgDistance, double *avgCorrection, int *launc
 // block; exec- and SCC-neutral), flushes the lanes into this table with atomics at s_endpgm, and assembles the result back into a library -- the kernels'
 // own instruction stream is the production one. A regular build has no table and reports 0 counters.
 #if defined(MSDF_BBCOUNT)
-extern "C" __device__ __attribute__((used)) unsigned msdfhip_bbcount[MSDF_BBCOUNT];
+extern "C" { __device__ __attribute__((used)) unsigned msdfhip_bbcount[MSDF_BBCOUNT]; }     // (a DEFINITION: the one-line extern "C" form only declares)
 #endif
 extern "C" int msdfhip_debug_bbcount(unsigned *out, int cap, int reset) {
 #if defined(MSDF_BBCOUNT)

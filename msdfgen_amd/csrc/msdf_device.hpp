@@ -32,6 +32,12 @@
 #define MSDF_UNIFORM(x) (x)
 #endif
 
+#if defined(MSDF_NO_UNLIKELY)
+#define MSDF_UNLIKELY(x) (x)
+#else
+#define MSDF_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#endif   // a cold path: the register allocator places its spill code by block frequency
+
 namespace msdfhip {
 
 // Wave vote: does ANY lane of the wavefront need this? Used where skipping work is exact whenever no lane needs it and evaluating more is
@@ -827,11 +833,19 @@ MSDF_HD bool selEdgeRelevantBox(const Selector<SEL> &s, const Rec &e, V2 o, doub
         for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
             if (mask&(1<<i))
                 bound2 = cmax(bound2, s.c[i].td*s.c[i].td);
-#else
+#elif defined(MSDF_NO_DIET_BOUNDMAX)
         // a channel the edge does not carry contributes (td*0)*td = +0 (also for td = -DBL_MAX): the wave-uniform channel bit becomes a scalar
         // factor of the product instead of two selects per channel
         for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
             bound2 = cmax(bound2, (s.c[i].td*((mask&(1<<i)) ? 1. : 0.))*s.c[i].td);
+#else
+        // max over the carried channels of td^2 == (max of |td|)^2: rounding is monotonic, so squaring the maximum once yields the very value the
+        // maximum of the squares had (round 6, tools/isa_bbcount.py: this test is 10 % of the kernel's VALU instructions; 7 instead of 10 of them
+        // build the bound). The channel bit stays a scalar factor (|td|*0 = +0, also for td = -DBL_MAX); the absolute value is an operand modifier.
+        double t = 0;
+        for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i)
+            t = cmax(t, fabs(s.c[i].td)*((mask&(1<<i)) ? 1. : 0.));
+        bound2 = t*t;
 #endif
     }
     bound2 *= 1+1e-9;                                // (-DBL_MAX)^2 = inf: nothing is skipped until a channel has a candidate
@@ -950,6 +964,95 @@ MSDF_HD void shapeDistanceSimple(const EdgeRec *rec, const Edges &edges, int C, 
     selDistance(sel, out);
 }
 
+// The selection part of OverlappingContourCombiner::distance (contour-combiners.cpp:104-133) over the stored per-contour distances, shared by the two
+// forms of the walk below. shapeD: the shape selector's distance; parked: what the (rare, wave-uniform: `second`) second walks left for the lanes with two or
+// more members in their inner / outer selector.
+template <int SEL, class Edges, class Wind>
+MSDF_HD void combinerEpilogue(const Edges &edges, const Wind windings, int C, const double *res, int rstride, int nInner, int nOuter, int firstInner, int firstOuter,
+                              bool second, const double *shapeD, const volatile double *parked, double *out) {
+    enum { NCH = SelTraits<SEL>::NCH };
+    double innerD[NCH], outerD[NCH];
+    const unsigned long long te0 = profNow(edges);
+    // merged selector with exactly one member == that member's own selector; with none, the initial state (every channel -DBL_MAX)
+    for (int ch = 0; ch < NCH; ++ch) {
+        innerD[ch] = nInner == 1 ? res[(firstInner*NCH+ch)*rstride] : -DBL_MAX;
+        outerD[ch] = nOuter == 1 ? res[(firstOuter*NCH+ch)*rstride] : -DBL_MAX;
+        if (second) {                                            // (wave-uniform; a lane reads what ITS second walk parked)
+            if (nInner >= 2)
+                innerD[ch] = parked[NCH+ch];
+            if (nOuter >= 2)
+                outerD[ch] = parked[2*NCH+ch];
+        }
+    }
+    const double innerScalar = resolve<SEL>(innerD);
+    const double outerScalar = resolve<SEL>(outerD);
+    double dist[NCH];
+    for (int ch = 0; ch < NCH; ++ch)
+        dist[ch] = -DBL_MAX;
+    // dm = resolve(dist) travels with dist (the reference re-evaluates the median in every comparison, contour-combiners.cpp:113-130: the
+    // same function of the same values -- when dist becomes a contour's distance, its median is that contour's cm)
+    int winding = 0;
+    double dm;
+    if (innerScalar >= 0 && fabs(innerScalar) <= fabs(outerScalar)) {
+        for (int ch = 0; ch < NCH; ++ch)
+            dist[ch] = innerD[ch];
+        dm = innerScalar;
+        winding = 1;
+        for (int c = 0; c < C; ++c)
+            if (windings[c] > 0) {
+                double cd[NCH];
+                for (int ch = 0; ch < NCH; ++ch)
+                    cd[ch] = res[(c*NCH+ch)*rstride];
+                const double cm = resolve<SEL>(cd);
+                if (fabs(cm) < fabs(outerScalar) && cm > dm) {
+                    for (int ch = 0; ch < NCH; ++ch)
+                        dist[ch] = cd[ch];
+                    dm = cm;
+                }
+            }
+    } else if (outerScalar <= 0 && fabs(outerScalar) < fabs(innerScalar)) {
+        for (int ch = 0; ch < NCH; ++ch)
+            dist[ch] = outerD[ch];
+        dm = outerScalar;
+        winding = -1;
+        for (int c = 0; c < C; ++c)
+            if (windings[c] < 0) {
+                double cd[NCH];
+                for (int ch = 0; ch < NCH; ++ch)
+                    cd[ch] = res[(c*NCH+ch)*rstride];
+                const double cm = resolve<SEL>(cd);
+                if (fabs(cm) < fabs(innerScalar) && cm < dm) {
+                    for (int ch = 0; ch < NCH; ++ch)
+                        dist[ch] = cd[ch];
+                    dm = cm;
+                }
+            }
+    } else {
+        for (int ch = 0; ch < NCH; ++ch)
+            out[ch] = shapeD[ch];
+        profAdd(edges, 11, profNow(edges)-te0);
+        return;
+    }
+    for (int c = 0; c < C; ++c)
+        if (windings[c] != winding) {
+            double cd[NCH];
+            for (int ch = 0; ch < NCH; ++ch)
+                cd[ch] = res[(c*NCH+ch)*rstride];
+            const double cm = resolve<SEL>(cd);
+            if (cm*dm >= 0 && fabs(cm) < fabs(dm)) {
+                for (int ch = 0; ch < NCH; ++ch)
+                    dist[ch] = cd[ch];
+                dm = cm;
+            }
+        }
+    if (dm == resolve<SEL>(shapeD))
+        for (int ch = 0; ch < NCH; ++ch)
+            dist[ch] = shapeD[ch];
+    for (int ch = 0; ch < NCH; ++ch)
+        out[ch] = dist[ch];
+    profAdd(edges, 11, profNow(edges)-te0);
+}
+
 // OverlappingContourCombiner::distance (contour-combiners.cpp:77-134), restructured around what a lane has to REMEMBER.
 // The reference keeps three merged selectors (shape / inner / outer) next to the contour being walked. Here only the shape one is
 // kept; for the other two a lane counts the member contours it has seen and remembers the first:
@@ -973,7 +1076,7 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
     // when no lane of the wavefront needs a second walk (the usual case) the shape selector `acc` is still intact after the loop and shapeD is taken from it
     // THEN; only when a second walk runs are the passes' results parked in `parked` (private memory on the device: volatile, so that it stays memory) --
     // `second` is wave-uniform.
-    double shapeD[NCH], innerD[NCH], outerD[NCH];
+    double shapeD[NCH];
     volatile double parked[3*NCH];
     bool second = false;
     MSDF_NOUNROLL
@@ -1067,85 +1170,103 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
         out[ch] = shapeD[ch]+(double) (nInner+nOuter+firstInner+firstOuter);
     return;
 #endif
-    const unsigned long long te0 = profNow(edges);
-    // merged selector with exactly one member == that member's own selector; with none, the initial state (every channel -DBL_MAX)
-    for (int ch = 0; ch < NCH; ++ch) {
-        innerD[ch] = nInner == 1 ? res[(firstInner*NCH+ch)*rstride] : -DBL_MAX;
-        outerD[ch] = nOuter == 1 ? res[(firstOuter*NCH+ch)*rstride] : -DBL_MAX;
-        if (second) {                                            // (wave-uniform; a lane reads what ITS second walk parked)
-            if (nInner >= 2)
-                innerD[ch] = parked[NCH+ch];
-            if (nOuter >= 2)
-                outerD[ch] = parked[2*NCH+ch];
+    combinerEpilogue<SEL>(edges, windings, C, res, rstride, nInner, nOuter, firstInner, firstOuter, second, shapeD, parked, out);
+}
+
+// The same combiner for the hot walk of k_distance, in TWO instances of the contour loop (round 6). tools/isa_bbcount.py (basic-block execution counts of
+// the production ISA, profiles/r06_valu_attribution.json) showed what the single rolled pass loop above costs a kernel at its register caps: `pass`
+// lives in a spill lane, and EVERY contour iteration re-derives the predicates pass == 0 / != 0 / == 1 / != 1 as 64-bit lane masks, parks them in spill
+// lanes (8 v_writelane) and reads them back where the body branches on them -- about 40 of the ~180 VALU instructions a contour iteration executes
+// outside its edge loop, 10 % of the kernel's VALU instructions with the per-contour selects, none of it arithmetic. Here pass 0 is a loop of its own (no
+// pass variable, no predicates), walked through `edges` (the register-resident record batches); the rare second walks (0.1 repeated evaluations per tile
+// next to 7.5 on the font set) go through `edges2`, a plain policy whose record fields the compiler loads where it needs them -- slow and small, and its
+// registers are live only there. Same operations on the same values in the same order as the form above.
+template <int SEL, class Edges, class Edges2, class Wind>
+MSDF_HD void shapeDistanceOverlapSplit(const EdgeRec *rec, const Edges &edges, const Edges2 &edges2, const Wind windings, int C, V2 o, double *res, int rstride, double *out) {
+    enum { NCH = SelTraits<SEL>::NCH };
+    Selector<SEL> acc;
+    int nInner = 0, nOuter = 0, firstInner = 0, firstOuter = 0;
+    selInit(acc);
+    MSDF_NOUNROLL
+    for (int c = 0; c < C; ++c) {
+        Selector<SEL> sel;
+        selInit(sel);
+        const unsigned long long tw0 = profNow(edges);
+        selAddContour(sel, rec, edges, c, o);
+        const unsigned long long tw1 = profNow(edges);
+        profAdd(edges, 8, tw1-tw0);
+        if (C == 1) {                                            // (see above: identical to the simple combiner)
+            selDistance(sel, out);
+            return;
         }
-    }
-    const double innerScalar = resolve<SEL>(innerD);
-    const double outerScalar = resolve<SEL>(outerD);
-    double dist[NCH];
-    for (int ch = 0; ch < NCH; ++ch)
-        dist[ch] = -DBL_MAX;
-    // dm = resolve(dist) travels with dist (the reference re-evaluates the median in every comparison, contour-combiners.cpp:113-130: the
-    // same function of the same values -- when dist becomes a contour's distance, its median is that contour's cm)
-    int winding = 0;
-    double dm;
-    if (innerScalar >= 0 && fabs(innerScalar) <= fabs(outerScalar)) {
+        double d[NCH];
+        selDistance(sel, d);
         for (int ch = 0; ch < NCH; ++ch)
-            dist[ch] = innerD[ch];
-        dm = innerScalar;
-        winding = 1;
-        for (int c = 0; c < C; ++c)
-            if (windings[c] > 0) {
+            res[(c*NCH+ch)*rstride] = d[ch];
+        const double m = resolve<SEL>(d);
+        const int w = windings[c];
+        selMerge(acc, sel);
+        if (w > 0 && m >= 0) {
+            if (!nInner)
+                firstInner = c;
+            ++nInner;
+        }
+        if (w < 0 && m <= 0) {
+            if (!nOuter)
+                firstOuter = c;
+            ++nOuter;
+        }
+        profAdd(edges, 9, profNow(edges)-tw1);
+    }
+    double shapeD[NCH];
+    volatile double parked[3*NCH];
+    const bool second = MSDF_WAVE_ANY(nInner >= 2 || nOuter >= 2);
+    selDistance(acc, shapeD);
+    if (MSDF_UNLIKELY(second)) {                                 // rare, wave-uniform: the results cross the second walks in private memory, not in registers
+        for (int ch = 0; ch < NCH; ++ch)
+            parked[ch] = shapeD[ch];
+        MSDF_NOUNROLL
+        for (int pass = 1; pass < 3; ++pass) {
+            const bool mine = pass == 1 ? nInner >= 2 : nOuter >= 2;
+            if (!MSDF_WAVE_ANY(mine))
+                continue;
+            selInit(acc);
+            MSDF_NOUNROLL
+            for (int c = 0; c < C; ++c) {
+                const int w = windings[c];
+                if (pass == 1 ? !(w > 0) : !(w < 0))
+                    continue;
                 double cd[NCH];
                 for (int ch = 0; ch < NCH; ++ch)
                     cd[ch] = res[(c*NCH+ch)*rstride];
-                const double cm = resolve<SEL>(cd);
-                if (fabs(cm) < fabs(outerScalar) && cm > dm) {
-                    for (int ch = 0; ch < NCH; ++ch)
-                        dist[ch] = cd[ch];
-                    dm = cm;
-                }
+                const double m = resolve<SEL>(cd);
+                const bool member = mine && (pass == 1 ? m >= 0 : m <= 0);
+                if (!MSDF_WAVE_ANY(member))
+                    continue;
+                Selector<SEL> sel;
+                selInit(sel);
+                const unsigned long long tw0 = profNow(edges);
+                selAddContour(sel, rec, edges2, c, o);
+                profAdd(edges, 10, profNow(edges)-tw0);
+                if (member)
+                    selMerge(acc, sel);
             }
-    } else if (outerScalar <= 0 && fabs(outerScalar) < fabs(innerScalar)) {
-        for (int ch = 0; ch < NCH; ++ch)
-            dist[ch] = outerD[ch];
-        dm = outerScalar;
-        winding = -1;
-        for (int c = 0; c < C; ++c)
-            if (windings[c] < 0) {
-                double cd[NCH];
+            if (mine) {
+                double t[NCH];
+                selDistance(acc, t);
                 for (int ch = 0; ch < NCH; ++ch)
-                    cd[ch] = res[(c*NCH+ch)*rstride];
-                const double cm = resolve<SEL>(cd);
-                if (fabs(cm) < fabs(innerScalar) && cm < dm) {
-                    for (int ch = 0; ch < NCH; ++ch)
-                        dist[ch] = cd[ch];
-                    dm = cm;
-                }
-            }
-    } else {
-        for (int ch = 0; ch < NCH; ++ch)
-            out[ch] = shapeD[ch];
-        profAdd(edges, 11, profNow(edges)-te0);
-        return;
-    }
-    for (int c = 0; c < C; ++c)
-        if (windings[c] != winding) {
-            double cd[NCH];
-            for (int ch = 0; ch < NCH; ++ch)
-                cd[ch] = res[(c*NCH+ch)*rstride];
-            const double cm = resolve<SEL>(cd);
-            if (cm*dm >= 0 && fabs(cm) < fabs(dm)) {
-                for (int ch = 0; ch < NCH; ++ch)
-                    dist[ch] = cd[ch];
-                dm = cm;
+                    parked[pass*NCH+ch] = t[ch];
             }
         }
-    if (dm == resolve<SEL>(shapeD))
         for (int ch = 0; ch < NCH; ++ch)
-            dist[ch] = shapeD[ch];
+            shapeD[ch] = parked[ch];
+    }
+#if defined(MSDF_ABLATE_EPILOGUE)
     for (int ch = 0; ch < NCH; ++ch)
-        out[ch] = dist[ch];
-    profAdd(edges, 11, profNow(edges)-te0);
+        out[ch] = shapeD[ch]+(double) (nInner+nOuter+firstInner+firstOuter);
+    return;
+#endif
+    combinerEpilogue<SEL>(edges, windings, C, res, rstride, nInner, nOuter, firstInner, firstOuter, second, shapeD, parked, out);
 }
 
 // -------------------------------------------------------------------------------------------------------- transform

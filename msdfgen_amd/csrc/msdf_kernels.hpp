@@ -505,7 +505,7 @@ __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restr
     if (!wk.valid)
         return;                                                         // (direct mapping only: every queued item is valid)
     if (glyphMap)
-        wk.g = glyphMap[wk.g];                                          // this launch covers a subset of the batch (bucketed by contour count)
+        wk.g = MSDF_UNIFORM(glyphMap[wk.g]);                            // this launch covers a subset of the batch (bucketed by contour count)
     // (wave-uniform values; made scalar explicitly: inside k_single_call the offsets are memory the launch itself wrote, which the compiler
     // reads with vector loads -- the record pointer of the hand-placed s_load batches has to live in SGPRs)
     const int c0 = knownContours >= 0 ? 0 : MSDF_UNIFORM(batch.glyphContourOffsets[wk.g]), C = knownContours >= 0 ? knownContours : MSDF_UNIFORM(batch.glyphContourOffsets[wk.g+1])-c0;
@@ -532,7 +532,10 @@ __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restr
 #endif
 
     // ---- phase 1: cull + compact (row q of 16 lanes = tile q of the quad; lanes of a row = edges)
-    const double rsx = 1/t.sx, rsy = 1/t.sy;                        // two divisions per wavefront; texel positions below use divExact
+    // (two divisions per wavefront; texel positions below use divExact. The quotients come out of the VALU in VGPRs although they are wave-uniform, and the
+    // 128-VGPR builds keep them in scratch: four dwords reloaded per tile. Forcing them into SGPRs was tried in round 6 -- the readfirstlane builtin is dropped
+    // as redundant by the compiler, an asm statement with SGPR outputs miscompiled the mtsdf instantiations -- and left alone: loads that hit L2.)
+    const double rsx = 1/t.sx, rsy = 1/t.sy;
     const bool fastXf = divSafe(t.sx) && divSafe(t.sy);
     const double hx = (.5*TILE-.5)*fabs(rsx), hy = (.5*TILE-.5)*fabs(rsy);
     const double tr = sqrt(hx*hx+hy*hy);
@@ -714,14 +717,27 @@ __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restr
         for (int ch = 0; ch < NCH; ++ch)
             d[ch] = (double) edges.cstart[C];
 #else
-        if (OVERLAP)
+        if (OVERLAP) {
+#if defined(MSDF_LAZY_RECORDS) || defined(MSDF_ONE_PASS_LOOP)    // A/B: the single rolled pass loop of rounds 2-5
             shapeDistanceOverlap<SEL>(rec, edges, wind, C, p, res+lane, WAVE, d);
-        else
+#else
+            EdgesCulled cold;                                       // the rare second walks: the same survivor lists, record fields loaded where they are used
+            cold.cstart = edges.cstart, cold.list = edges.list;
+            shapeDistanceOverlapSplit<SEL>(rec, edges, cold, wind, C, p, res+lane, WAVE, d);
+#endif
+        } else
             shapeDistanceSimple<SEL>(rec, edges, C, p, d);
 #endif
-        const int yn = gd.flip ? height-1-y : y;                    // output.reorient(shape orientation), msdfgen.cpp:55
-        float *px = toScratch ? dst+(((size_t) wk.g*height+yn)*width+x)*NCH
-                              : dst+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) NCH*x;
+        // The texel's coordinates are derived AGAIN from the lane index here, through a copy the compiler cannot see through: kept live across the walk,
+        // x and y were three dwords of scratch stores per tile in the 128-VGPR builds (half of the pass's spill traffic, 0.3 GB per 8 192 glyphs; round 6).
+        int laneAfter = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(laneAfter));
+#endif
+        const int xo = tx*TILE+(laneAfter&(TILE-1)), yo = ty*TILE+(laneAfter>>3);
+        const int yn = gd.flip ? height-1-yo : yo;                  // output.reorient(shape orientation), msdfgen.cpp:55
+        float *px = toScratch ? dst+(((size_t) wk.g*height+yn)*width+xo)*NCH
+                              : dst+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) NCH*xo;
         for (int ch = 0; ch < NCH; ++ch) {
 #if !defined(MSDF_PLAIN_TILE_STORES)
             // streaming (nontemporal) stores: 400 MB of tiles per pass otherwise push the 128-VGPR kernels' scratch lines out of L2 (round 5, A/B: the pass's

@@ -16,21 +16,19 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
 
 
-@pytest.mark.parametrize("inst,occupancy,max_vgpr_spill", [(("3", "true", "false", "4"), 4, 40),    # LDS class: 2+ contours, combiner scratch in LDS, four tiles per wavefront
-                                                             (("3", "true", "true", "1"), 4, 40),     # global-scratch class (persistent grid): many contours
+@pytest.mark.parametrize("inst,occupancy,max_vgpr_spill", [(("3", "true", "false", "4"), 4, 56),    # LDS class: 2+ contours, combiner scratch in LDS, four tiles per wavefront
+                                                             (("3", "true", "true", "1"), 4, 96),     # global-scratch class (persistent grid): many contours
                                                              (("3", "false", "false", "4"), 5, 0)])    # one-contour class: simple combiner
 def test_edge_loop_of_k_distance_has_no_spills(inst, occupancy, max_vgpr_spill):
-    """The overlapping-combiner instantiations run at FOUR wavefronts per SIMD (128 VGPRs) and spill 10-24 dwords to scratch -- which pays only because every
-    spill sits outside the edge loop (5 / 6 wavefronts per SIMD put a handful inside: 7.5 / 8.9 instead of 5.4 ms per step), and only since the combiner's pass
-    results are no longer loop-carried across the walk (94-164 dwords before: 2.4 GB of scratch stores per pass)."""
+    """The overlapping-combiner instantiations run at FOUR wavefronts per SIMD (128 VGPRs) and spill a few dozen dwords to scratch -- which pays only because
+    every spill sits outside the HOT edge loop (5 / 6 wavefronts per SIMD put a handful inside: 7.5 / 8.9 instead of 5.4 ms per step). Round 6: the combiner has
+    two instances of the contour loop (msdf_device.hpp: shapeDistanceOverlapSplit) -- the hot one, whose edge loop holds the hand-placed s_load_dwordx16 batches,
+    and the rare second walks, which may spill as they like. The static spill count went UP with the cold instance (24 -> 42 / 66 dwords) while the scratch bytes
+    the pass really writes went DOWN (585 -> 334 MB per 8 192 glyphs, tools/isa_bbcount.py: dynamic counts): what is pinned here is the hot loop."""
     from isa_loop_depth import analyse
     a = analyse(*inst)
     res = a["resources"]
     assert int(res["Occupancy"]) == occupancy, res
     assert int(res["VGPRs Spill"]) <= max_vgpr_spill, res
-    deep_moves = {d: n for d, n in a["lane_moves"].items() if d >= 4 and n}
-    deep_scratch = {d: n for d, n in a["scratch_ops"].items() if d >= 4 and n}
-    assert sum(deep_moves.values()) <= 4, "SGPR-spill lane moves inside the edge loop: %s (by loop depth; resources %s)" % (deep_moves, res)
-    assert not deep_scratch, "scratch loads / stores inside the edge loop: %s (by loop depth; resources %s)" % (deep_scratch, res)
-    e = a["edge_loop"]
+    e = a["edge_loop"]                                   # the loop around the first s_load_dwordx16 batch = the hot walk
     assert e is not None and e["lane moves"] <= 4 and e["scratch"] == 0 and e["f64 arithmetic"] > 300, e

@@ -13,7 +13,7 @@ decoder on this pool, and source-level counters would change the code they count
   report   counts x per-block instruction mix -> instructions per launch by source REGION and instruction CLASS; compared with the PMC totals of the
            production kernels when a profiles/*_pmc_bench.json is given -> profiles/<tag>_valu_attribution.json + a table on stdout
 
-    python tools/isa_bbcount.py build [kernel-regex ...]
+    [BBCOUNT_NAME=<variant> BBCOUNT_FLAGS="-D..."] python tools/isa_bbcount.py build [kernel-regex ...]
     python tools/isa_bbcount.py run <tag>
     python tools/isa_bbcount.py report <tag> [profiles/r05_pmc_bench.json]
 """
@@ -29,9 +29,11 @@ sys.path.insert(0, ROOT)
 from msdfgen_amd import build as B  # noqa: E402
 
 LLVM = "/opt/rocm/lib/llvm/bin"
-WORK = os.path.join(ROOT, "variants", "bbcount_work")
-OUT_SO = os.path.join(ROOT, "variants", "bbcount.so")
-OUT_MAP = os.path.join(ROOT, "variants", "bbcount_map.json")
+NAME = os.environ.get("BBCOUNT_NAME", "bbcount")          # several instrumented builds side by side (A/B of kernel variants): BBCOUNT_NAME=..., BBCOUNT_FLAGS="-D..."
+EXTRA_FLAGS = os.environ.get("BBCOUNT_FLAGS", "").split()
+WORK = os.path.join(ROOT, "variants", "bbcount_work", NAME)
+OUT_SO = os.path.join(ROOT, "variants", NAME+".so")
+OUT_MAP = os.path.join(ROOT, "variants", NAME+"_map.json")
 NCOUNTERS = 16384                                    # msdfhip_bbcount[]: 64 counters per extra VGPR, the kernels' slices one after the other
 DEFAULT_KERNELS = [r"k_distanceILi3ELb1ELb0ELi4E", r"k_distanceILi3ELb1ELb1ELi1E", r"k_distanceILi3ELb0ELb0ELi4E", r"k_ec_fastILi3E", r"k_ec_queryILi3ELb1E"]
 
@@ -140,7 +142,7 @@ def classify(mn):
                 return "ADD_F64"
             if re.match(r"v_mul_f64", base):
                 return "MUL_F64"
-            if re.match(r"v_fma_f64", base):
+            if re.match(r"v_(fma|fmac|div_fmas)_f64", base):      # (checked against SQ_INSTS_VALU_FMA_F64 of the same kernel: exact with these three)
                 return "FMA_F64"
             if re.match(r"v_(rcp|rsq|sqrt)_f64", base):
                 return "TRANS_F64"
@@ -177,7 +179,7 @@ def classify(mn):
 
 def build(patterns):
     os.makedirs(WORK, exist_ok=True)
-    flags = [f for f in B.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    flags = [f for f in B.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]+EXTRA_FLAGS
     src = os.path.join(B.CSRC, "msdf_capi.hip")
     asm = os.path.join(WORK, "dev.s")
     run([B.hipcc()] + flags + ["-gline-tables-only", "-DMSDF_BBCOUNT=%d" % NCOUNTERS, "-S", "--cuda-device-only", src, "-o", asm])
@@ -193,7 +195,7 @@ def build(patterns):
     run([LLVM+"/lld", "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", out, obj])
     run([LLVM+"/clang-offload-bundler", "-type=o", "-bundle-align=4096", "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input="+out,
          "-output="+fb])
-    run([B.hipcc()] + B.HIPCC_FLAGS + ["-DMSDF_BBCOUNT=%d" % NCOUNTERS, "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fb, src, "-o", OUT_SO])
+    run([B.hipcc()] + B.HIPCC_FLAGS + EXTRA_FLAGS + ["-DMSDF_BBCOUNT=%d" % NCOUNTERS, "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fb, src, "-o", OUT_SO])
     # the map: disassemble the instrumented kernels, split at the bumps, symbolize every instruction
     kmap = []
     for kd in kernels:
@@ -238,7 +240,7 @@ def build(patterns):
         kmap.append(kd)
         print("%s: %d blocks, %d instructions, counters %d..%d, VGPRs %d -> %d" % (kd["symbol"][:60], kd["blocks"], kd["static_instructions"], kd["base"], kd["base"]+kd["vgprs"]*64-1,
                                                                                    kd["orig_vgprs"], kd["vgpr_base"]+kd["vgprs"]))
-    json.dump({"source_hash": B.source_hash(), "counters": NCOUNTERS, "kernels": kmap}, open(OUT_MAP, "w"))
+    json.dump({"source_hash": B.source_hash(), "flags": EXTRA_FLAGS, "counters": NCOUNTERS, "kernels": kmap}, open(OUT_MAP, "w"))
     print("->", OUT_SO, OUT_MAP)
 
 
@@ -279,7 +281,7 @@ REGIONS = [
     ("relevance: box test + wave vote", r"^selEdgeRelevantBox"), ("relevance: wedges", r"^selEdgeRelevantWedges"),
     ("survivor walk: list entry, record batch loads, loop", r"^selAddContour"),
     ("per contour: selInit / selDistance / selMerge / res[] / member counts", r"^(selInit|selDistance|pbCompute|selMerge|pbMergeWave|pbInit|resolve|median)"),
-    ("combiner: pass loop + epilogue over res[]", r"^shapeDistanceOverlap"), ("simple combiner", r"^shapeDistanceSimple"),
+    ("combiner: contour / pass loops + epilogue over res[]", r"^(shapeDistanceOverlap|combinerEpilogue)"), ("simple combiner", r"^shapeDistanceSimple"),
     ("phase 1: cull (bounds, test, rank, compaction)", r"^(cull|rowRank|rowMinNonNegative|waveMinNonNegative|packEntry|floatAbove)"),
 ]
 
@@ -310,7 +312,7 @@ def report(tag, pmc_path=None):
     pmc = json.load(open(pmc_path))["kernels"] if pmc_path else {}
     result = {"method": __doc__.split("\n\n")[1].strip(), "workload": raw["workload"], "source_hash": raw["source_hash"], "tiles_match_reference_sha": raw["tiles_match_reference_sha"], "kernels": {}}
     for kd in kmap["kernels"]:
-        sym = run([LLVM+"/llvm-cxxfilt", kd["symbol"]]).stdout.strip()
+        sym = run(["c++filt", kd["symbol"]]).stdout.strip()
         short = re.sub(r"\(.*", "", sym.replace("void msdfhip::", ""))
         by_region = collections.defaultdict(lambda: collections.Counter())
         by_mn = collections.Counter()
