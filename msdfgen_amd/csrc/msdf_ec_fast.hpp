@@ -156,10 +156,17 @@ MSDF_HD int diagonalPairFast(const FastCtx &cx, float am, float dm, const float 
 }
 
 // 3x3 neighbourhood of a texel in NATIVE row order, loaded once into registers: v[dy+1][dx+1][channel]; valid bit (dy+1)*3+(dx+1).
+// dev[dy+1][dx+1] = fabsf(median(v) - .5f) of that texel: both first-level tests (protectEdges' radius test :201, findErrors' "the texel farther from
+// the edge reports" :335, :349) compare only these. A texel's value is computed ONCE -- k_ec_fast does it while it stages the halo in LDS (round 6:
+// every lane used to recompute the medians of all eight neighbours, twice: 18 medians of 8 instructions per texel, 15 % of the kernel's VALU stream by
+// tools/isa_bbcount.py) -- with the reference's own expression, so the comparisons see the same floats.
 struct Neighbourhood {
     float v[3][3][3];
+    float dev[3][3];
     unsigned valid;
 };
+
+MSDF_HD float ecTexelDeviation(const float *t) { return fabsf(medianf(t[0], t[1], t[2])-.5f); }
 
 MSDF_HD void loadNeighbourhood(Neighbourhood &nb, const SdfView &sdf, int x, int yn) {
     nb.valid = 0;
@@ -171,6 +178,7 @@ MSDF_HD void loadNeighbourhood(Neighbourhood &nb, const SdfView &sdf, int x, int
             const bool in = nx >= 0 && ny >= 0 && nx < sdf.w && ny < sdf.h;
             const float *t = sdf.native(in ? nx : x, in ? ny : yn);
             nb.v[dy+1][dx+1][0] = t[0], nb.v[dy+1][dx+1][1] = t[1], nb.v[dy+1][dx+1][2] = t[2];
+            nb.dev[dy+1][dx+1] = ecTexelDeviation(t);
             if (in)
                 nb.valid |= 1u<<((dy+1)*3+(dx+1));
         }
@@ -182,8 +190,7 @@ MSDF_HD void loadNeighbourhood(Neighbourhood &nb, const SdfView &sdf, int x, int
 // stage 2 (evaluateProtectPair) runs edgeBetweenTexels on such a pair -- up to three fp64 divisions -- and is queued by the kernel.
 template <class Emit>
 MSDF_HD void texelProtectPairs(const Neighbourhood &nb, const EcParams &p, Emit &emit) {
-    const float *self = nb.v[1][1];
-    const float sdev = fabsf(medianf(self[0], self[1], self[2])-.5f);
+    const float sdev = nb.dev[1][1];
     MSDF_UNROLL
     for (int dy = -1; dy <= 1; ++dy) {
         MSDF_UNROLL
@@ -193,8 +200,7 @@ MSDF_HD void texelProtectPairs(const Neighbourhood &nb, const EcParams &p, Emit 
             if (!(nb.valid&(1u<<((dy+1)*3+(dx+1)))))
                 continue;
             const float radius = dy == 0 ? p.radiusH : dx == 0 ? p.radiusV : p.radiusD;
-            const float *other = nb.v[dy+1][dx+1];
-            const float odev = fabsf(medianf(other[0], other[1], other[2])-.5f);
+            const float odev = nb.dev[dy+1][dx+1];
             const bool selfIsA = dy > 0 || (dy == 0 && dx > 0);
             const float sum = selfIsA ? sdev+odev : odev+sdev;                     // fabsf(am-.5f)+fabsf(bm-.5f)
             if (sum < radius)
@@ -244,14 +250,14 @@ MSDF_HD int ecNeighbourDy(int k) { return k < 4 ? (k == 1 ? -1 : k == 3 ? 1 : 0)
 template <class Emit>
 MSDF_HD void texelCandidatePairs(const Neighbourhood &nb, Emit &emit) {
     const float *c = nb.v[1][1];
-    const float cdev = fabsf(medianf(c[0], c[1], c[2])-.5f);
+    const float cdev = nb.dev[1][1];
     MSDF_UNROLL
     for (int k = 0; k < 4; ++k) {
         const int dx = k == 0 ? -1 : k == 2 ? 1 : 0, dy = k == 1 ? -1 : k == 3 ? 1 : 0;
         if (!(nb.valid&(1u<<((dy+1)*3+(dx+1)))))
             continue;
         const float *b = nb.v[dy+1][dx+1];
-        if (!(cdev >= fabsf(medianf(b[0], b[1], b[2])-.5f)))
+        if (!(cdev >= nb.dev[dy+1][dx+1]))
             continue;
         MSDF_UNROLL
         for (int j = 0; j < 3; ++j) {
@@ -267,7 +273,7 @@ MSDF_HD void texelCandidatePairs(const Neighbourhood &nb, Emit &emit) {
         if (!(nb.valid&(1u<<((dy+1)*3+(dx+1)))))
             continue;
         const float *d = nb.v[dy+1][dx+1];
-        if (!(cdev >= fabsf(medianf(d[0], d[1], d[2])-.5f)))
+        if (!(cdev >= nb.dev[dy+1][dx+1]))
             continue;
         const float *b = nb.v[1][dx+1], *cc = nb.v[dy+1][1];
         MSDF_UNROLL

@@ -1068,6 +1068,11 @@ __device__ __forceinline__ void ecFastBody(const BatchView &batch, const MsdfHip
     int *itemCount = verdictLds+WAVE;
     unsigned short *queue = reinterpret_cast<unsigned short *>(itemCount+4);               // [EC_QUEUE_CAP]: lane | k<<6 | j<<9
     unsigned short *protectQueue = queue+EC_QUEUE_CAP;                                      // [EC_PROTECT_QUEUE_CAP]: lane | m<<6
+    // |median - .5| of every halo texel, computed once while the halo is staged (msdf_ec_fast.hpp: Neighbourhood::dev). The table overlays the TAIL of the
+    // item queue: every lane has its nine values in registers before the wavefront pushes its first item (one wavefront, LDS operations in program order, a
+    // wave barrier between the reads and the pushes) -- no LDS is added, the kernel keeps its seven wavefronts per SIMD.
+    float *devLds = reinterpret_cast<float *>(queue+EC_QUEUE_CAP)-EC_HALO*EC_HALO;
+    static_assert((EC_QUEUE_CAP*sizeof(unsigned short))%sizeof(float) == 0 && EC_QUEUE_CAP*sizeof(unsigned short) >= EC_HALO*EC_HALO*sizeof(float), "devLds overlays the queue's tail");
     const int lane = threadIdx.x;
     const MsdfHipGlyph gd = glyphs[wk.g];
     EcParams p;
@@ -1112,8 +1117,10 @@ __device__ __forceinline__ void ecFastBody(const BatchView &batch, const MsdfHip
         const int hx = tx*TILE+idx%EC_HALO-1, hy = ty*TILE+idx/EC_HALO-1;
         if (hx >= 0 && hy >= 0 && hx < width && hy < height) {
             const float *t = field+((size_t) hy*width+hx)*N;
+            float tv[N];
             for (int ch = 0; ch < N; ++ch)
-                halo[idx*N+ch] = t[ch];
+                tv[ch] = t[ch], halo[idx*N+ch] = tv[ch];
+            devLds[idx] = ecTexelDeviation(tv);
         }
     }
     if (lane < 2)
@@ -1126,12 +1133,13 @@ __device__ __forceinline__ void ecFastBody(const BatchView &batch, const MsdfHip
     const bool inside = x < width && yn < height;
     int st = 0;
 #if defined(MSDF_EC_ABLATE) && MSDF_EC_ABLATE == 1                          // measurement only: halo load + store, no classification
-    if (false) {
+    const bool classify = false;
 #else
-    if (inside) {
+    const bool classify = inside;
 #endif
-        Neighbourhood nb;
-        nb.valid = 0;
+    Neighbourhood nb;
+    nb.valid = 0;
+    if (classify) {
         MSDF_UNROLL
         for (int dy = -1; dy <= 1; ++dy) {
             MSDF_UNROLL
@@ -1140,10 +1148,14 @@ __device__ __forceinline__ void ecFastBody(const BatchView &batch, const MsdfHip
                 const bool in = nx >= 0 && ny >= 0 && nx < width && ny < height;
                 const float *t = halo+((ly+1+(in ? dy : 0))*EC_HALO+lx+1+(in ? dx : 0))*N;
                 nb.v[dy+1][dx+1][0] = t[0], nb.v[dy+1][dx+1][1] = t[1], nb.v[dy+1][dx+1][2] = t[2];
+                nb.dev[dy+1][dx+1] = devLds[(ly+1+(in ? dy : 0))*EC_HALO+lx+1+(in ? dx : 0)];
                 if (in)
                     nb.valid |= 1u<<((dy+1)*3+(dx+1));
             }
         }
+    }
+    waveSync();                                                         // devLds is dead from here on: the queue may grow into it
+    if (classify) {
         if (p.mode == EC_MODE_EDGE_PRIORITY) {
             if (cornerTexel)
                 st |= EC_PROTECTED;
