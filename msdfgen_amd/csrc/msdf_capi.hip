@@ -3045,7 +3045,7 @@ extern "C++" {
 template <int SEL, bool OVERLAP>
 static int fusedBlocksPerCu(size_t lds) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(k_single_call<SEL, OVERLAP>), WAVE, lds) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(k_single_call<SEL, OVERLAP>), WAVE*SINGLE_TEAM, lds) != hipSuccess) {
         (void) hipGetLastError();
         return 0;
     }
@@ -3214,6 +3214,10 @@ static int runGroup(ShapeCall *const *calls, int n) {
         lds = lds > ecFastLdsBytes(maxE, channels) ? lds : ecFastLdsBytes(maxE, channels);
         lds = lds > queryLds ? lds : queryLds;
     }
+    // the exchange areas of a tile's team of wavefronts (msdf_kernels.hpp: TeamExchange) behind everything the phases use
+    const size_t teamXchgOffset = (lds+15)/16*16;
+    if (SINGLE_TEAM > 1)
+        lds = teamXchgOffset+(size_t) (SINGLE_TEAM-1)*TEAM_XCHG_DOUBLES*WAVE*sizeof(double);
     bool fusedOK = fusedShape && !tuning().noFusedSingle && !cfg->sign_correction && cfg->ec_stage_limit == 0 &&
                    lds <= (size_t) 64*1024 && (!overlapEff || resInLds || gresNeed >= tilesAll*resBytes);
     FusedReservation fusedSlots;                                 // (see fusedCapacity: all workgroups of the launch must be resident together)
@@ -3304,6 +3308,7 @@ static int runGroup(ShapeCall *const *calls, int n) {
             sa.corners = correct ? reinterpret_cast<int *>(b.dDeferred+ecHeaderRecords((int) tilesAll)+tilesAll*SINGLE_TILE_SEGMENT) : NULL;
             sa.sizes = NULL;
             sa.slotCap = slotCap, sa.slotOffset = slotOffset;
+            sa.teamXchgOffset = (unsigned) teamXchgOffset;
             const unsigned groups = (unsigned) tilesAll+(correct ? 1u : 0u);
             sa.barrier = a.barrier, sa.barrierBase = a.barrierEpoch, sa.doneBase = a.doneCount;
             sa.doneValue = a.doneEpoch+1u ? a.doneEpoch+1u : 1u;
@@ -3326,14 +3331,14 @@ static int runGroup(ShapeCall *const *calls, int n) {
             else
                 HIPCHK(hipMemsetAsync(a.dev+hStatus, 0, 64, a.stream));
             switch (mode*2+(overlapEff ? 1 : 0)) {
-                case 2: hipLaunchKernelGGL((k_single_call<1, false>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
-                case 3: hipLaunchKernelGGL((k_single_call<1, true>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
-                case 4: hipLaunchKernelGGL((k_single_call<2, false>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
-                case 5: hipLaunchKernelGGL((k_single_call<2, true>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
-                case 6: hipLaunchKernelGGL((k_single_call<3, false>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
-                case 7: hipLaunchKernelGGL((k_single_call<3, true>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
-                case 8: hipLaunchKernelGGL((k_single_call<4, false>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
-                default: hipLaunchKernelGGL((k_single_call<4, true>), dim3(groups), dim3(WAVE), lds, a.stream, sa); break;
+                case 2: hipLaunchKernelGGL((k_single_call<1, false>), dim3(groups), dim3(WAVE*SINGLE_TEAM), lds, a.stream, sa); break;
+                case 3: hipLaunchKernelGGL((k_single_call<1, true>), dim3(groups), dim3(WAVE*SINGLE_TEAM), lds, a.stream, sa); break;
+                case 4: hipLaunchKernelGGL((k_single_call<2, false>), dim3(groups), dim3(WAVE*SINGLE_TEAM), lds, a.stream, sa); break;
+                case 5: hipLaunchKernelGGL((k_single_call<2, true>), dim3(groups), dim3(WAVE*SINGLE_TEAM), lds, a.stream, sa); break;
+                case 6: hipLaunchKernelGGL((k_single_call<3, false>), dim3(groups), dim3(WAVE*SINGLE_TEAM), lds, a.stream, sa); break;
+                case 7: hipLaunchKernelGGL((k_single_call<3, true>), dim3(groups), dim3(WAVE*SINGLE_TEAM), lds, a.stream, sa); break;
+                case 8: hipLaunchKernelGGL((k_single_call<4, false>), dim3(groups), dim3(WAVE*SINGLE_TEAM), lds, a.stream, sa); break;
+                default: hipLaunchKernelGGL((k_single_call<4, true>), dim3(groups), dim3(WAVE*SINGLE_TEAM), lds, a.stream, sa); break;
             }
             {
                 const hipError_t launched = hipGetLastError();

@@ -955,12 +955,43 @@ template <int SEL> MSDF_HD void selAddContour(Selector<SEL> &sel, const EdgeRec 
 template <class Edges> MSDF_HD void profAdd(const Edges &, int, unsigned long long) { }
 template <class Edges> MSDF_HD unsigned long long profNow(const Edges &) { return 0; }
 
-template <int SEL, class Edges>
-MSDF_HD void shapeDistanceSimple(const EdgeRec *rec, const Edges &edges, int C, V2 o, double *out) { // contour-combiners.cpp:34-50
+// A TEAM of wavefronts may share one texel tile's walk (msdf_kernels.hpp: TeamExchange, k_single_call): every member walks ITS share of a contour's
+// survivors into a partial selector, afterWalk() hands the helpers' partial selectors to the leader, which merges them (selMergePartial) and carries on
+// alone; a helper gets `false` and has nothing else to do for that contour. The default is a team of one.
+struct NoTeam {
+    template <int SEL> MSDF_HD bool afterWalk(Selector<SEL> &) const { return true; }
+    MSDF_HD bool isHelper() const { return false; }
+};
+
+// Two partial selectors of the SAME contour over DISJOINT sets of its edges -> the selector the reference builds from the union: the minimum true distance
+// by SignedDistance < with the explicit visit-index tie-break (sdReplaces: a total order, so the union's winner is the better of the two partial winners;
+// the initial state loses to any edge), the converted distance travelling with it; max / min of the perpendicular distances do not depend on order.
+template <int SEL>
+MSDF_HD void selMergePartial(Selector<SEL> &a, const Selector<SEL> &b) {
+    if (SEL == 1) {
+        if (sdReplaces(b.m, b.idx[0], a.m, a.idx[0]))
+            a.m = b.m, a.idx[0] = b.idx[0];
+        return;
+    }
+    for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i) {
+        SD x = { b.c[i].td, b.c[i].tdot }, y = { a.c[i].td, a.c[i].tdot };
+        if (sdReplaces(x, b.idx[i], y, a.idx[i]))
+            a.c[i].td = b.c[i].td, a.c[i].tdot = b.c[i].tdot, a.c[i].perp = b.c[i].perp, a.idx[i] = b.idx[i];
+        if (b.c[i].neg > a.c[i].neg)
+            a.c[i].neg = b.c[i].neg;
+        if (b.c[i].pos < a.c[i].pos)
+            a.c[i].pos = b.c[i].pos;
+    }
+}
+
+template <int SEL, class Edges, class Team = NoTeam>
+MSDF_HD void shapeDistanceSimple(const EdgeRec *rec, const Edges &edges, int C, V2 o, double *out, const Team &team = Team()) { // contour-combiners.cpp:34-50
     Selector<SEL> sel;
     selInit(sel);
     for (int c = 0; c < C; ++c)
         selAddContour(sel, rec, edges, c, o);
+    if (!team.afterWalk(sel))
+        return;
     selDistance(sel, out);
 }
 
@@ -1181,8 +1212,9 @@ MSDF_HD void shapeDistanceOverlap(const EdgeRec *rec, const Edges &edges, const 
 // pass variable, no predicates), walked through `edges` (the register-resident record batches); the rare second walks (0.1 repeated evaluations per tile
 // next to 7.5 on the font set) go through `edges2`, a plain policy whose record fields the compiler loads where it needs them -- slow and small, and its
 // registers are live only there. Same operations on the same values in the same order as the form above.
-template <int SEL, class Edges, class Edges2, class Wind>
-MSDF_HD void shapeDistanceOverlapSplit(const EdgeRec *rec, const Edges &edges, const Edges2 &edges2, const Wind windings, int C, V2 o, double *res, int rstride, double *out) {
+template <int SEL, class Edges, class Edges2, class Wind, class Team = NoTeam>
+MSDF_HD void shapeDistanceOverlapSplit(const EdgeRec *rec, const Edges &edges, const Edges2 &edges2, const Wind windings, int C, V2 o, double *res, int rstride, double *out,
+                                       const Team &team = Team()) {
     enum { NCH = SelTraits<SEL>::NCH };
     Selector<SEL> acc;
     int nInner = 0, nOuter = 0, firstInner = 0, firstOuter = 0;
@@ -1195,6 +1227,8 @@ MSDF_HD void shapeDistanceOverlapSplit(const EdgeRec *rec, const Edges &edges, c
         selAddContour(sel, rec, edges, c, o);
         const unsigned long long tw1 = profNow(edges);
         profAdd(edges, 8, tw1-tw0);
+        if (!team.afterWalk(sel))                                // (a helper wavefront of a team: its share of the contour is with the leader now)
+            continue;
         if (C == 1) {                                            // (see above: identical to the simple combiner)
             selDistance(sel, out);
             return;
@@ -1218,6 +1252,8 @@ MSDF_HD void shapeDistanceOverlapSplit(const EdgeRec *rec, const Edges &edges, c
         }
         profAdd(edges, 9, profNow(edges)-tw1);
     }
+    if (team.isHelper())
+        return;
     double shapeD[NCH];
     volatile double parked[3*NCH];
     const bool second = MSDF_WAVE_ANY(nInner >= 2 || nOuter >= 2);

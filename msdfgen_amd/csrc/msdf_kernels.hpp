@@ -333,6 +333,7 @@ struct EdgesCulledPacked {              // survivors of the per-tile cull as pac
     const int *cstart;                  // C+1 compacted offsets
     const int *list;                    // packed entries (LDS)
     int total;                          // cstart[C]
+    int first, step;                    // this wavefront walks entries first, first+step, ... of every contour's segment (0, 1: all of them; a team of wavefronts: its rank, the team's size)
 #if defined(MSDF_PROFILE_WAITS)
     mutable unsigned long long prof[16]; // [8] contour walks of pass 0 [9] per-contour bookkeeping after a walk [10] second walks [11] combiner epilogue [12] tile prologue [13] tile stores | [0] batch cycles [1] batches [2] E batch cycles [3] E batches [4] eval cycles [5] evals [6] relevance cycles [7] slow batches (>1000) | (>3000)<<32
 #endif
@@ -350,12 +351,12 @@ __device__ inline unsigned long long profNow(const EdgesCulledPacked &) { return
 template <int SEL>
 __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, const EdgesCulledPacked &edges, int c, V2 o) {
     const int e = edges.end(c);
-    int k = edges.begin(c);
+    int k = edges.begin(c)+edges.first;
     if (k >= e)
         return;
     unsigned cur = (unsigned) MSDF_UNIFORM(edges.list[k]);
     MSDF_NOUNROLL
-    for (; k < e; ++k) {
+    for (; k < e; k += edges.step) {
         const EdgeRec *rp = rec+(cur&ENTRY_INDEX_MASK);
         EdgeRegs r;
         r.meta = cur;
@@ -363,7 +364,7 @@ __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, con
         // LDS byte address of the next entry = the LOW 32 bits of its flat address: on gfx9-family devices (gfx950 included) a flat address
         // inside the shared aperture is { src_shared_base (high dword) | LDS offset (low dword) } -- the aperture is 4 GB-aligned, so the
         // truncation is the address-space cast the compiler itself emits for flat -> LDS. This library is built for gfx950 only (build.py).
-        const unsigned nextAddr = (unsigned) (size_t) (edges.list+k+1);
+        const unsigned nextAddr = (unsigned) (size_t) (edges.list+k+edges.step);
 #if defined(MSDF_PROFILE_WAITS)
         MSDF_STAMP(t0);
 #endif
@@ -375,7 +376,7 @@ __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, con
         if (t1-t0 > 1000) edges.prof[7] += 1;
         if (t1-t0 > 3000) edges.prof[7] += 1ull<<32;
 #endif
-        const unsigned next = k+1 < edges.total ? (unsigned) __builtin_amdgcn_readfirstlane((int) nextV) : cur;
+        const unsigned next = k+edges.step < edges.total ? (unsigned) __builtin_amdgcn_readfirstlane((int) nextV) : cur;
         // (Requesting the NEXT survivor's lines here without waiting for them -- a scalar-cache warm-up -- was measured: no change, 6.26 vs
         // 6.28 ms per step; a batch lands in 380 cycles on average, 4 % of a wavefront's life. It also cannot be made safe in C++: the
         // dummy destination of an unwaited s_load may be copied or spilled by the register allocator and its register reused while the
@@ -447,6 +448,58 @@ __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, con
     }
 }
 
+// ---- a TEAM of wavefronts on one tile (k_single_call, round 6) -----------------------------------------------------------------------------------
+// A single-shape call runs 64 tiles on 1 024 SIMDs: a tile's wavefront is alone on its SIMD and what the call waits for is the serial walk of its busiest
+// tile (33 of the launch's 67 us). With TEAM wavefronts per tile, member r walks survivors r, r+TEAM, ... of every contour's (nearest-first) segment into a
+// partial selector; the helpers park theirs in LDS, the leader merges them -- selMergePartial: selection by (|d|, dot, visit index) does not depend on how the
+// edges were dealt -- and carries on alone with the contour's distance, the combiner and the stores. Two workgroup barriers per contour.
+// x: TEAM-1 areas of TEAM_XCHG_DOUBLES x 64 doubles, field-major (lane-consecutive 8-byte accesses).
+enum { TEAM_XCHG_DOUBLES = 17 };                                    // 3 channels x (td, tdot, perp, neg, pos) + 3 visit indices (two doubles' worth)
+template <int SEL> __device__ inline void teamPut(const Selector<SEL> &s, double *x, int lane) {
+    if (SEL == 1) {
+        x[lane] = s.m.d, x[WAVE+lane] = s.m.dot;
+        reinterpret_cast<int *>(x+15*WAVE)[lane] = s.idx[0];
+        return;
+    }
+    for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i) {
+        x[(5*i+0)*WAVE+lane] = s.c[i].td, x[(5*i+1)*WAVE+lane] = s.c[i].tdot, x[(5*i+2)*WAVE+lane] = s.c[i].perp;
+        x[(5*i+3)*WAVE+lane] = s.c[i].neg, x[(5*i+4)*WAVE+lane] = s.c[i].pos;
+        reinterpret_cast<int *>(x+15*WAVE)[i*WAVE+lane] = s.idx[i];
+    }
+}
+template <int SEL> __device__ inline void teamGet(Selector<SEL> &s, const double *x, int lane) {
+    selInit(s);
+    if (SEL == 1) {
+        s.m.d = x[lane], s.m.dot = x[WAVE+lane];
+        s.idx[0] = reinterpret_cast<const int *>(x+15*WAVE)[lane];
+        return;
+    }
+    for (int i = 0; i < (int) SelTraits<SEL>::NPB; ++i) {
+        s.c[i].td = x[(5*i+0)*WAVE+lane], s.c[i].tdot = x[(5*i+1)*WAVE+lane], s.c[i].perp = x[(5*i+2)*WAVE+lane];
+        s.c[i].neg = x[(5*i+3)*WAVE+lane], s.c[i].pos = x[(5*i+4)*WAVE+lane];
+        s.idx[i] = reinterpret_cast<const int *>(x+15*WAVE)[i*WAVE+lane];
+    }
+}
+template <int TEAM>
+struct TeamExchange {
+    double *x;
+    int lane, rank;
+    template <int SEL> __device__ bool afterWalk(Selector<SEL> &s) const {
+        if (rank != 0)
+            teamPut(s, x+(size_t) (rank-1)*TEAM_XCHG_DOUBLES*WAVE, lane);
+        __syncthreads();
+        if (rank == 0)
+            for (int r = 1; r < TEAM; ++r) {
+                Selector<SEL> other;
+                teamGet(other, x+(size_t) (r-1)*TEAM_XCHG_DOUBLES*WAVE, lane);
+                selMergePartial(s, other);
+            }
+        __syncthreads();                                            // the areas are free for the next contour
+        return rank == 0;
+    }
+    __device__ bool isHelper() const { return rank != 0; }
+};
+
 enum { QUAD = 4 };   // tiles per wavefront of the LDS-scratch variant (the global-scratch variant, GRES, takes one: measured faster there)
 
 #ifndef MSDF_SIMPLE_WAVES_PER_SIMD
@@ -469,11 +522,15 @@ struct DistanceArgs {
 
 // The body of k_distance as a device function: k_distance is its only caller per instantiation (inlined: the kernel's code is what it was);
 // k_single_call (msdf_single.hpp) runs the same body as one phase of a fused launch. blockId = the workgroup's index in the launch.
-template <int SEL, bool OVERLAP, bool GRES, int TPW_ = (GRES ? 1 : (int) QUAD)>
+template <int SEL, bool OVERLAP, bool GRES, int TPW_ = (GRES ? 1 : (int) QUAD), int TEAM = 1>
 __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const int32_t *__restrict__ contourOffsets, const EdgeRec *__restrict__ recs,
            const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, int tilesX, int tilesPerGlyph, int maxEdges,
            float *__restrict__ dst, int toScratch, unsigned blockBase, double *__restrict__ gres, size_t gresStride, const int *__restrict__ glyphMap, int nMapped,
-           unsigned *__restrict__ workQueue, unsigned workItems, const unsigned blockId, double *smem, const int knownContours = -1, const int knownEdges = -1) {
+           unsigned *__restrict__ workQueue, unsigned workItems, const unsigned blockId, double *smem, const int knownContours = -1, const int knownEdges = -1,
+           double *teamXchg = NULL) {
+    // (TEAM > 1: a workgroup of TEAM wavefronts on ONE tile -- see TeamExchange; the leader culls, every member walks its share, the leader stores)
+    static_assert(TEAM == 1 || (TPW_ == 1 && !GRES), "teams take one tile, combiner scratch in LDS");
+    const int teamRank = TEAM > 1 ? MSDF_UNIFORM((int) (threadIdx.x>>6)) : 0;   // (wave-uniform, and said so: the walk's record pointers must be scalar)
     // (knownContours / knownEdges >= 0: a launch over ONE glyph whose counts are kernel arguments -- k_single_call -- skips the dependent loads of the offsets)
     // (every pointer __restrict__: the survivor records are read with SCALAR loads only while the compiler can prove that none of the
     // kernel's own stores -- tiles, workspace, and in the persistent form those of the previous item -- may have clobbered them)
@@ -511,7 +568,7 @@ __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restr
     const int c0 = knownContours >= 0 ? 0 : MSDF_UNIFORM(batch.glyphContourOffsets[wk.g]), C = knownContours >= 0 ? knownContours : MSDF_UNIFORM(batch.glyphContourOffsets[wk.g+1])-c0;
     const int32_t *coff = batch.contourOffsets+c0;
     const int e0 = knownContours >= 0 ? 0 : MSDF_UNIFORM(coff[0]);
-    const int lane = threadIdx.x;
+    const int lane = TEAM > 1 ? (int) (threadIdx.x&(WAVE-1)) : (int) threadIdx.x;
     const EdgeRec *rec = batch.recs+e0;
 
     double *res = GRES ? gres+(size_t) blockId*gresStride : smem; // [C][NCH][64] (overlap only)
@@ -539,7 +596,7 @@ __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restr
     const bool fastXf = divSafe(t.sx) && divSafe(t.sy);
     const double hx = (.5*TILE-.5)*fabs(rsx), hy = (.5*TILE-.5)*fabs(rsy);
     const double tr = sqrt(hx*hx+hy*hy);
-    {
+    if (TEAM == 1 || teamRank == 0) {
         const int q = lane/ROW, col = lane%ROW;
         const int tileQ = wk.tile*TPW+q;
         const bool tileValid = tileQ < tilesPerGlyph;
@@ -660,6 +717,8 @@ __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restr
             cstart[C] = nSurv;
     }
     waveSync();
+    if (TEAM > 1)
+        __syncthreads();                                            // the leader's lists are the team's
 #if defined(MSDF_PROFILE_WAITS)
     MSDF_STAMP(pPhase2);
 #endif
@@ -712,6 +771,11 @@ __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restr
 #endif
         edges.cstart = cstarts+(size_t) q*(C+1);
         edges.list = lists+(size_t) q*maxEdges;
+#if !defined(MSDF_LAZY_RECORDS)
+        edges.first = teamRank, edges.step = TEAM;
+#endif
+        TeamExchange<TEAM> team;
+        team.x = teamXchg, team.lane = lane, team.rank = teamRank;
         double d[NCH];
 #if defined(MSDF_ABLATE_PHASE2)                                     // measurement only: what phase 1 + the launch cost alone
         for (int ch = 0; ch < NCH; ++ch)
@@ -723,11 +787,18 @@ __device__ __forceinline__ void distanceBody(int nGlyphs, const int32_t *__restr
 #else
             EdgesCulled cold;                                       // the rare second walks: the same survivor lists, record fields loaded where they are used
             cold.cstart = edges.cstart, cold.list = edges.list;
-            shapeDistanceOverlapSplit<SEL>(rec, edges, cold, wind, C, p, res+lane, WAVE, d);
+            if (TEAM > 1)
+                shapeDistanceOverlapSplit<SEL>(rec, edges, cold, wind, C, p, res+lane, WAVE, d, team);
+            else
+                shapeDistanceOverlapSplit<SEL>(rec, edges, cold, wind, C, p, res+lane, WAVE, d);
 #endif
-        } else
+        } else if (TEAM > 1)
+            shapeDistanceSimple<SEL>(rec, edges, C, p, d, team);
+        else
             shapeDistanceSimple<SEL>(rec, edges, C, p, d);
 #endif
+        if (TEAM > 1 && teamRank != 0)
+            continue;                                               // a helper: the leader holds the tile's distances and stores them
         // The texel's coordinates are derived AGAIN from the lane index here, through a copy the compiler cannot see through: kept live across the walk,
         // x and y were three dwords of scratch stores per tile in the 128-VGPR builds (half of the pass's spill traffic, 0.3 GB per 8 192 glyphs; round 6).
         int laneAfter = lane;

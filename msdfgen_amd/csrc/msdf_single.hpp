@@ -32,7 +32,10 @@
 
 namespace msdfhip {
 
-enum { SINGLE_TILE_SEGMENT = 64 };     // distance-check candidates a tile may leave (default config: ~0.1 per tile; beyond, the call is rerun through the batched path)
+#ifndef MSDF_SINGLE_TEAM
+#define MSDF_SINGLE_TEAM 4             // wavefronts per tile in the distance phase of k_single_call (msdf_kernels.hpp: TeamExchange); 1 = round 5's single wavefront
+#endif
+enum { SINGLE_TILE_SEGMENT = 64, SINGLE_TEAM = MSDF_SINGLE_TEAM };     // distance-check candidates a tile may leave (default config: ~0.1 per tile; beyond, the call is rerun through the batched path)
 
 struct SingleArgs {
     // the shape as the CALLER staged it: CSR arrays of ONE glyph, read once in phase 0 -- device memory or pinned host memory (zero copy:
@@ -74,7 +77,8 @@ struct SingleArgs {
     // PCIe round trips, ~8 of the ~11 us the digest took): payloadBytes != 0 -> contour offsets | points | types | colors | descriptor at
     // the given offsets of `payload`, and the src* pointers above are not used.
     unsigned payloadBytes, payOffsets, payPoints, payTypes, payColors, payGlyph;
-    alignas(16) unsigned char payload[3456];
+    unsigned teamXchgOffset;           // byte offset of the team's exchange areas in the workgroup's LDS (behind everything the phases use)
+    alignas(16) unsigned char payload[3440];
 };
 static_assert(sizeof(SingleArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -163,11 +167,13 @@ __device__ __forceinline__ void singleCallChecks(const SingleArgs &a, const Edge
 }
 
 template <int SEL, bool OVERLAP>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(WAVE*SINGLE_TEAM)
 k_single_call(SingleArgs a) {
     enum { N = SelTraits<SEL>::NCH };
     extern __shared__ __attribute__((aligned(16))) double smemSingle[];
-    const int lane = threadIdx.x;
+    // A workgroup is SINGLE_TEAM wavefronts: the helpers (rank > 0) only share the walk of the distance phase (distanceBody<..., TEAM>) and leave; digest,
+    // correction sweep, distance checks and all bookkeeping are the leader's, lane = its thread index as before.
+    const int lane = threadIdx.x&(WAVE-1), teamRank = MSDF_UNIFORM((int) (threadIdx.x>>6));
     const unsigned blk = blockIdx.x, groups = gridDim.x;
     const unsigned T = (unsigned) a.tiles;
     // (status[0] / [1] -- candidate overflow, a barrier that gave up -- are zeroed by the HOST before the launch and only ever raised here)
@@ -181,7 +187,7 @@ k_single_call(SingleArgs a) {
     int8_t *windings = reinterpret_cast<int8_t *>(mine+a.privWindings);
     int32_t *contourOffsets = reinterpret_cast<int32_t *>(mine+a.privOffsets), *glyphContourOffsets = reinterpret_cast<int32_t *>(mine+a.privGlyphOffsets);
     MsdfHipGlyph *glyph = reinterpret_cast<MsdfHipGlyph *>(mine+a.privGlyph);
-    {
+    if (teamRank == 0) {
         // (the payload is addressed through the kernarg segment pointer: taking the address of a member of `a` would make the compiler copy
         // the whole 4 KB struct to scratch)
         const unsigned char *pay = (const unsigned char *) __builtin_amdgcn_kernarg_segment_ptr()+offsetof(SingleArgs, payload);
@@ -216,13 +222,15 @@ k_single_call(SingleArgs a) {
             ctx.lane = lane;
             contourWindingsWave(ctx, smemSingle+(a.nContours+2+1)/2, 0, a.nContours, coLds, srcPoints, srcTypes, srcColors, windings);
         }
-        // the area is this wavefront's own: its stores only have to have LEFT the wavefront (they are written through to the XCD's L2, which
+        // the area is this workgroup's own: its stores only have to have LEFT the wavefront (they are written through to the XCD's L2, which
         // also backs the scalar cache) before the phases below read them back; no other workgroup is involved
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         waveSync();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)\n\tbuffer_inv sc0" ::: "memory");
     }
+    if (SINGLE_TEAM > 1)
+        __syncthreads();                                            // the helpers read what the leader digested
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)\n\tbuffer_inv sc0" ::: "memory");
     stampPhase(a, 1);
 
     BatchView batch;
@@ -231,20 +239,30 @@ k_single_call(SingleArgs a) {
     // ---- phase 1: distance field, one tile per workgroup; the extra workgroup prepares the correction pass
     if (blk < T) {
         // the overlapping combiner's per-contour distances in LDS where they fit (a dependent L2 round trip per contour and pass otherwise)
+        double *teamXchg = reinterpret_cast<double *>(reinterpret_cast<char *>(smemSingle)+a.teamXchgOffset);
         if (OVERLAP && a.gres == NULL)
-            distanceBody<SEL, OVERLAP, false, 1>(1, glyphContourOffsets, contourOffsets, recs, windings, glyph, a.width, a.height, a.tilesX, a.tiles, a.listStride,
+            distanceBody<SEL, OVERLAP, false, 1, SINGLE_TEAM>(1, glyphContourOffsets, contourOffsets, recs, windings, glyph, a.width, a.height, a.tilesX, a.tiles, a.listStride,
                                                  a.correct ? a.scratch : a.out, a.correct, 0u, (double *) NULL, 0, (const int *) NULL, 0, (unsigned *) NULL, 0u, blk, smemSingle,
-                                                 a.nContours, a.nEdges);
-        else
-            distanceBody<SEL, OVERLAP, true, 1>(1, glyphContourOffsets, contourOffsets, recs, windings, glyph, a.width, a.height, a.tilesX, a.tiles, a.listStride,
-                                                a.correct ? a.scratch : a.out, a.correct, 0u, a.gres, a.gresStride, (const int *) NULL, 0, (unsigned *) NULL, 0u, blk, smemSingle,
-                                                a.nContours, a.nEdges);
+                                                 a.nContours, a.nEdges, teamXchg);
+        else if (OVERLAP) {                                           // (combiner scratch in the global workspace: many contours -- the leader alone, as before)
+            if (teamRank == 0)
+                distanceBody<SEL, OVERLAP, true, 1>(1, glyphContourOffsets, contourOffsets, recs, windings, glyph, a.width, a.height, a.tilesX, a.tiles, a.listStride,
+                                                    a.correct ? a.scratch : a.out, a.correct, 0u, a.gres, a.gresStride, (const int *) NULL, 0, (unsigned *) NULL, 0u, blk, smemSingle,
+                                                    a.nContours, a.nEdges);
+        } else
+            distanceBody<SEL, OVERLAP, false, 1, SINGLE_TEAM>(1, glyphContourOffsets, contourOffsets, recs, windings, glyph, a.width, a.height, a.tilesX, a.tiles, a.listStride,
+                                                a.correct ? a.scratch : a.out, a.correct, 0u, (double *) NULL, 0, (const int *) NULL, 0, (unsigned *) NULL, 0u, blk, smemSingle,
+                                                a.nContours, a.nEdges, teamXchg);
     }
+    else if (teamRank != 0)
+        return;
     else if constexpr (SEL >= 3) {
         ecParamsBody(a.ecParams, batch, glyph, a.cfg, (unsigned *) NULL, a.corners, a.sizes, 0, lane);
         for (unsigned i = (unsigned) lane; i <= T; i += WAVE)       // the tiles' candidate counters ([0]: overflow flag)
             reinterpret_cast<unsigned *>(a.cands)[i] = 0;
     }
+    if (teamRank != 0)
+        return;                                                         // the helpers' part is over; everything below is per tile = per leader
     stampPhase(a, 2);
     if constexpr (SEL >= 3) {
         if (a.correct) {
