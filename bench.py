@@ -77,7 +77,7 @@ def global_list(batch, xfs, glyphs_per_gpu, world):
 
 def rank_shard(batch, xfs, glyphs_per_gpu, world, rank, w, h):
     """(sub-batch, xfs, (lo, hi), bounds) of `rank`: contiguous cut of the global list into ranges of equal modelled cost (msdfgen_amd.shard:
-    per-class cost model fitted to measured kernel times, profiles/r03_cost_model.json)."""
+    per-class cost model fitted to measured kernel times, profiles/r06_cost_model.json)."""
     from msdfgen_amd.shard import partition_contiguous, glyph_costs
     idx = global_list(batch, xfs, glyphs_per_gpu, world)
     bounds = partition_contiguous(glyph_costs(batch, w, h)[idx], world)

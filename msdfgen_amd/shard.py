@@ -14,13 +14,15 @@ from .shape import ShapeBatch
 
 # Microseconds per glyph at 64x64 (msdf, library-default config) = a + b*E + c*C + d*E*C with one coefficient set per KERNEL CLASS of the glyph
 # (E edges, C contours; classes as msdf_capi.hip: ensureBuckets sorts them): least squares over (contours, edges) bins of the 8 192 distinct
-# DejaVu glyphs, each bin timed on an MI355X -- tools/fit_cost_model.py, profiles/r03_cost_model.json (rms error of the fit: 5 percent).
-# Round 2 balanced by W*H*(E+1); the measured cost is far from linear in E alone (0.22 us for a one-contour glyph, 0.66 us in the LDS
-# class, 3.5 us in the global-workspace class). The same numbers live in msdf_capi.hip: glyphCost.
+# DejaVu glyphs, each bin timed on an MI355X -- tools/fit_cost_model.py. Refitted in round 6 for the kernels of rounds 5 / 6 (four wavefronts per SIMD, the
+# LDS class up to 5 contours, the combiner's split contour loop): profiles/r06_cost_model.json, rms error of the fit 4.3 percent (round 3's table priced the
+# global-workspace class at twice what it costs now). The same numbers live in msdf_capi.hip: glyphCost.
+# What the model does NOT say: a shard of ~1 000 glyphs lasts max(sum of these, ~17x the cost of its heaviest glyph -- that glyph's 64 tiles are one
+# serial walk each) + ~0.3 ms of launch chain; no cut of the list changes the second term.
 COST_MODEL = {
-    "one_contour": [0.2768, 0.01348, 0.0, 0.0],      # <= 1 contour: simple-combiner kernel
-    "lds": [0.44322, 0.00935, -0.01895, 0.0042],     # 2..7 contours and <= 128 edges: per-contour distances in LDS
-    "global": [2.33907, 0.02717, -0.18818, 0.00156],  # the rest: per-contour distances in the global workspace
+    "one_contour": [0.25625, 0.01190, 0.0, 0.0],        # <= 1 contour: simple-combiner kernel
+    "lds": [0.38398, 0.00846, -0.02755, 0.003446],      # 2..5 contours and <= 128 edges: per-contour distances in LDS
+    "global": [1.11611, 0.015776, -0.05039, 0.000681],  # the rest: per-contour distances in the global workspace
 }
 
 

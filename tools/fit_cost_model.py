@@ -6,12 +6,12 @@ distance field + error correction, the bench step) and timed with HIP events. Le
 
     microseconds per glyph = (W*H/4096) * (a_k + b_k*E + c_k*C + d_k*E*C)      k = the kernel class of the glyph
 
-(E edges, C contours; classes as msdf_capi.hip: ensureBuckets sorts them: one contour -> simple-combiner kernel; 2..7 contours and <= 128
+(E edges, C contours; classes as msdf_capi.hip: ensureBuckets sorts them: one contour -> simple-combiner kernel; 2..5 contours and <= 128
 edges -> per-contour distances in LDS; the rest -> global workspace. The overlapping combiner walks every contour's survivors at every
 tile, hence the E*C term). Then: the 2-way and 8-way contiguous splits of the glyph list by the OLD cost W*H*(E+1) and by
 the fitted one, each part timed on the GPU -- the imbalance is max/mean-1 of the measured part times.
 
-    python tools/fit_cost_model.py > profiles/r03_cost_model.json
+    python tools/fit_cost_model.py > profiles/r06_cost_model.json        (round 6: refitted for the round-5 / 6 kernels -- four wavefronts per SIMD, LDS class up to 5 contours)
 """
 import json
 import os
@@ -58,7 +58,7 @@ def main():
         return a.elapsed_time(b)/reps, len(idx)
 
     bins = []
-    c_edges = [(1, 1), (2, 2), (3, 3), (4, 5), (6, 8), (9, 14), (15, 64)]
+    c_edges = [(1, 1), (2, 2), (3, 3), (4, 5), (6, 8), (9, 14), (15, 64)]         # (4, 5) ends the LDS class, (6, 8) starts the global one
     e_edges = [(1, 12), (13, 20), (21, 32), (33, 56), (57, 100), (101, 600)]
     for clo, chi in c_edges:
         for elo, ehi in e_edges:
@@ -70,8 +70,9 @@ def main():
                          "mean_edges_x_extra_contours": float((n_e[idx]*np.maximum(n_c[idx]-1, 0)).mean()), "us_per_glyph": 1e3*ms/n})
     # piecewise by the kernel class a glyph runs in (msdf_capi.hip: ensureBuckets): one contour -> simple combiner; 2..7 contours and <= 128
     # edges -> per-contour distances in LDS; the rest -> global workspace. Within a class: a + b*E + c*C + d*E*C.
+    from msdfgen_amd.shard import LDS_MAX_CONTOURS, LDS_MAX_EDGES     # the class boundaries the launches use (round 5: 5 contours at the 10 KB LDS budget)
     def klass(c, e):
-        return 0 if c <= 1 else 1 if (c <= 7 and e <= 128) else 2
+        return 0 if c <= 1 else 1 if (c <= LDS_MAX_CONTOURS and e <= LDS_MAX_EDGES) else 2
     fitted, pred, y = {}, np.zeros(len(bins)), np.array([b["us_per_glyph"] for b in bins])
     for k, name in enumerate(("one_contour", "lds", "global")):
         sel = [i for i, b in enumerate(bins) if klass(b["contours"][0], b["edges"][0]) == k]
