@@ -37,6 +37,10 @@ class Emu:
         c8 = np.ascontiguousarray(s.colors, np.uint8)
         return (co, pts, t8, c8), (s.n_contours, _p(co, C.c_int32), _p(pts, C.c_double), _p(t8, C.c_uint8), _p(c8, C.c_uint8))
 
+    def set_combiner_form(self, form):
+        """0: the rolled pass loop (shapeDistanceOverlap); 1: the kernels' two instances of the contour loop (shapeDistanceOverlapSplit)."""
+        self.lib.emu_set_combiner_form(int(form))
+
     def windings(self, s, wave=None):
         """wave: the forms the digest kernels run since round 4 (contourWindingsWave: lanes = edges, ordered sums) -- "single" = k_single_call's (all
         contours in one cooperative walk), "batch" = k_prep_records' (a lane per contour, long contours by the wavefront together); None: a contour per lane."""

@@ -140,13 +140,19 @@ TileCull cullTile(const Digest &d, const int32_t *co, int nC, bool overlap, cons
 
 static long g_cullKept = 0, g_cullTotal = 0;
 
+// Which form of the overlapping combiner the tile walk below takes (emu_set_combiner_form): 0 the single rolled pass loop (shapeDistanceOverlap), 1 the two
+// instances of the contour loop the kernels use (shapeDistanceOverlapSplit).
+static int g_combinerForm = 0;
+
 // k_distance for one texel of a tile whose cull result is given (phase 2, lanes = texels).
 template <int SEL>
 void distanceAtCulled(const Digest &d, const TileCull &tcull, int nC, bool overlap, V2 p, double *res, double *out) {
     EdgesCulled edges;
     edges.cstart = tcull.cstart.data();
     edges.list = tcull.list.data();
-    if (overlap)
+    if (overlap && g_combinerForm == 1)
+        shapeDistanceOverlapSplit<SEL>(d.recs.data(), edges, edges, d.windings.data(), nC, p, res, 1, out);
+    else if (overlap)
         shapeDistanceOverlap<SEL>(d.recs.data(), edges, d.windings.data(), nC, p, res, 1, out);
     else
         shapeDistanceSimple<SEL>(d.recs.data(), edges, nC, p, out);
@@ -290,13 +296,15 @@ void emu_windings_wave(int nC, const int32_t *co, const double *points, const ui
 void emu_shape_distance(int sel, int overlap, int nC, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors,
                         int n, const double *pts, double *out) {
     Digest d = digest(nC, co, points, types, colors);
-    std::vector<double> res((size_t) (nC+1)*4);
+    std::vector<double> res((size_t) (nC+1)*5);
     for (int i = 0; i < n; ++i) {
         double o[4] = { 0, 0, 0, 0 };
         distanceAtSel(sel, d, co, nC, overlap != 0, mk(pts[2*i], pts[2*i+1]), res.data(), o);
         memcpy(out+4*i, o, sizeof(o));
     }
 }
+
+void emu_set_combiner_form(int form) { g_combinerForm = form; }
 
 // Mirrors msdfhip_generate / msdfhip_error_correction (correctionOnly): xf = {sx, sy, tx, ty, mapScale, mapTranslate}.
 void emu_generate(int mode, int correctionOnly, float *pixels, int w, int h, int rowStride, int flip, int nC, const int32_t *co, const double *points,
@@ -305,7 +313,7 @@ void emu_generate(int mode, int correctionOnly, float *pixels, int w, int h, int
     const int N = correctionOnly ? mode : (mode <= 2 ? 1 : mode);
     Digest d = digest(nC, co, points, types, colors);
     const int nE = co[nC];
-    std::vector<double> res((size_t) (nC+1)*4);
+    std::vector<double> res((size_t) (nC+1)*5);
     Xform t = { xf[0], xf[1], xf[2], xf[3], xf[4], xf[5] };
     std::vector<float> tile((size_t) w*h*N);
     if (correctionOnly) {
@@ -547,7 +555,7 @@ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const EdgesCoopE
 extern "C" void emu_psdf_cooperative(int overlap, int nC, const int32_t *co, const double *points, const uint8_t *types, const uint8_t *colors,
                                      int n, const double *pts, double *out) {
     Digest d = digest(nC, co, points, types, colors);
-    std::vector<double> res((size_t) (nC+1)*4);
+    std::vector<double> res((size_t) (nC+1)*5);
     EdgesCoopEmu edges;
     edges.coff = co;
     edges.slotted = overlap >= 2;

@@ -294,3 +294,28 @@ def test_combiner_restructuring_on_nested_and_overlapping_contours(emu, oracle):
     logo = synth.logo_shape(5)
     xf = autoframe(logo.bounds(), 48, 48, 4)
     assert_bit_equal(emu.generate(logo, 3, 48, 48, xf), oracle.generate(logo, 3, 48, 48, xf), "logo 48x48")
+
+
+def test_split_form_of_the_combiner_matches_oracle(emu, oracle):
+    """The form of the overlapping combiner the kernels actually instantiate since round 6 -- two instances of the contour loop (msdf_device.hpp:
+    shapeDistanceOverlapSplit; contour-combiners.cpp:77-134) -- walked on the host against the oracle: CJK-like shapes (13.7 contours), heavily overlapping
+    blobs (second walks, texels inside several contours), the 40-contour logo, every selector."""
+    form = 1
+    emu.set_combiner_form(form)
+    try:
+        for i in range(6):
+            s = synth.cjk_like_shape(20000+37*i)
+            xf = autoframe(s.bounds(), 32, 32, 3)
+            for mode in (3, 4):
+                assert_bit_equal(emu.generate(s, mode, 32, 32, xf, ec_mode=0), oracle.generate(s, mode, 32, 32, xf, ec_mode=0), "cjk-like %d mode %d form %d" % (i, mode, form))
+        for seed in range(6):
+            s = synth.random_shape(300+seed, n_contours=3+seed, spread=.2)
+            xf = autoframe(s.bounds(), 28, 28, 3)
+            for mode in (1, 2, 3, 4):
+                assert_bit_equal(emu.generate(s, mode, 28, 28, xf), oracle.generate(s, mode, 28, 28, xf), "blobs %d mode %d form %d" % (seed, mode, form))
+        logo = synth.logo_shape(5)
+        xf = autoframe(logo.bounds(), 40, 40, 4)
+        for mode in (3, 4):
+            assert_bit_equal(emu.generate(logo, mode, 40, 40, xf), oracle.generate(logo, mode, 40, 40, xf), "logo mode %d form %d" % (mode, form))
+    finally:
+        emu.set_combiner_form(0)

@@ -255,18 +255,35 @@ def gpu_run(tag):
     from msdfgen_amd.shape import ShapeBatch
     M.init(0)
     lib = L.load()
-    z = load_npz("dejavu8192.npz")
-    batch = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
-                       z["colors"].astype(np.int32), np.zeros(len(z["names"]), bool), [str(n) for n in z["names"]])
-    gb = M.GlyphBatch(batch)
-    gb.generate(M.MODE_MSDF, 64, 64, z["xf64"])                      # warm-up: class lists, workspaces
-    buf = (C.c_uint32*NCOUNTERS)()
-    assert lib.msdfhip_debug_bbcount(buf, NCOUNTERS, 1) == NCOUNTERS
-    out = gb.generate(M.MODE_MSDF, 64, 64, z["xf64"]).cpu().numpy()
-    n = lib.msdfhip_debug_bbcount(buf, NCOUNTERS, 1)
     import hashlib
-    ok = all((np.frombuffer(hashlib.sha256(np.ascontiguousarray(out[g]).tobytes()).digest(), np.uint8) == z["sha64"][g]).all() for g in range(0, 8192, 97))
-    res = {"workload": "8192 distinct DejaVu glyphs, msdf 64x64, library defaults: ONE step (digest + distance + error correction)", "tiles_match_reference_sha": bool(ok),
+    buf = (C.c_uint32*NCOUNTERS)()
+    if os.environ.get("BBCOUNT_WORKLOAD") == "cjk":                  # BASELINE config 4's CJK-like set (tools/bench_configs.py), pinned by tests/golden/cjk512.npz
+        from msdfgen_amd import synth
+        from msdfgen_amd.shape import autoframe
+        zc = load_npz("cjk512.npz")
+        base = [synth.cjk_like_shape(20000+i) for i in range(512)]
+        batch = ShapeBatch.from_shapes([base[i % 512] for i in range(8192)])
+        xf = np.stack([autoframe(s.bounds(), 48, 48, 4) for s in base])[np.arange(8192) % 512]
+        gb = M.GlyphBatch(batch)
+        gb.generate(M.MODE_MSDF, 48, 48, xf)
+        assert lib.msdfhip_debug_bbcount(buf, NCOUNTERS, 1) == NCOUNTERS
+        out = gb.generate(M.MODE_MSDF, 48, 48, xf).cpu().numpy()
+        n = lib.msdfhip_debug_bbcount(buf, NCOUNTERS, 1)
+        sha = zc["sha48"] if "sha48" in zc else zc["sha"]
+        ok = all((np.frombuffer(hashlib.sha256(np.ascontiguousarray(out[g]).tobytes()).digest(), np.uint8) == sha[g % 512]).all() for g in range(0, 8192, 97))
+        name = "8192 CJK-like synthetic glyphs (512 distinct), msdf 48x48, library defaults: ONE step (digest + distance + error correction)"
+    else:
+        z = load_npz("dejavu8192.npz")
+        batch = ShapeBatch(z["glyph_contour_offsets"].astype(np.int32), z["contour_offsets"].astype(np.int32), z["points"], z["types"].astype(np.int32),
+                           z["colors"].astype(np.int32), np.zeros(len(z["names"]), bool), [str(n) for n in z["names"]])
+        gb = M.GlyphBatch(batch)
+        gb.generate(M.MODE_MSDF, 64, 64, z["xf64"])                      # warm-up: class lists, workspaces
+        assert lib.msdfhip_debug_bbcount(buf, NCOUNTERS, 1) == NCOUNTERS
+        out = gb.generate(M.MODE_MSDF, 64, 64, z["xf64"]).cpu().numpy()
+        n = lib.msdfhip_debug_bbcount(buf, NCOUNTERS, 1)
+        ok = all((np.frombuffer(hashlib.sha256(np.ascontiguousarray(out[g]).tobytes()).digest(), np.uint8) == z["sha64"][g]).all() for g in range(0, 8192, 97))
+        name = "8192 distinct DejaVu glyphs, msdf 64x64, library defaults: ONE step (digest + distance + error correction)"
+    res = {"workload": name, "tiles_match_reference_sha": bool(ok),
            "source_hash": json.load(open(OUT_MAP))["source_hash"], "counts": list(buf[:n])}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", "%s_bbcount_raw.json" % tag), "w"))
