@@ -600,10 +600,13 @@ def main():
                                             "(not collected in this run)" % prof.get("commit", "?")) if prof else None,
                          "algorithmic_bytes_per_launch": ab, "avg_launch_ms": dist_ms, "launches_timed": launches,
                          "note": "arithmetic intensity ~400 fp64 flop/B: the pass is fp64-VALU bound, not HBM bound (SURVEY.md 8d); "
-                                 "the HBM fraction is reported as the contract asks, the binding resource is in `valu_fp64`. `traffic`: since round 5 the overlapping-combiner "
-                                 "kernels run at four wavefronts per SIMD (128 VGPRs) and spill 10-24 dwords per lane OUTSIDE their edge loop; those scratch stores are "
-                                 "about 0.6 GB of WRITE_SIZE next to 0.4 GB of tiles (2.8x the algorithmic bytes; the first 128-VGPR build wrote 3 GB, a 3-wave build 0.47: "
-                                 "DESIGN.md 3.1)"},
+                                 "the HBM fraction is reported as the contract asks, the binding resource is in `valu_fp64`. `traffic`: the overlapping-combiner "
+                                 "kernels run at four wavefronts per SIMD (128 VGPRs) and spill OUTSIDE their edge loop; WRITE_SIZE minus the tiles (`non_tile_write_bytes`) is "
+                                 "those scratch stores + the global-scratch class's workspace -- two thirds of the spill stores execute in the rare second walks of the "
+                                 "combiner (tools/scratch_by_source.py, DESIGN.md 3.1)",
+                         "traffic_over_algorithmic": prof.get("traffic_over_algorithmic") if prof else None,
+                         "write_over_algorithmic": prof.get("write_over_algorithmic") if prof else None,
+                         "non_tile_write_bytes": prof.get("non_tile_write_bytes") if prof else None},
             "valu_fp64": {"achieved": gflops, "peak": FP64_VECTOR_PEAK_GFLOPS, "unit": "GFLOP/s (algorithmic ESTIMATE: SURVEY.md 8d's per-edge flop figures over ALL edges; the "
                                                                                       "kernels cull most of them -- not an achieved rate, see measured_*)", "frac": gflops/FP64_VECTOR_PEAK_GFLOPS,
                           "measured_gflops": prof.get("fp64_gflops_pmc") if prof else None,

@@ -35,6 +35,10 @@ def counter_per_step(cur, counter, like):
     return sum(v for name, v, _ in rows if like in name)/steps, steps
 
 
+TILES = 8192*64*64*3*4
+ALGORITHMIC = 8192*(64*64*3*4+48)+72*189191
+
+
 def main():
     tag, commit = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "?"
     like = "k_distance"
@@ -71,6 +75,12 @@ def main():
            "FETCH_SIZE_raw_KiB": fetch, "WRITE_SIZE_raw_KiB": write,
            "hbm_read_bytes_range": [fetch*1024, 2*fetch*1024], "hbm_write_bytes": write*1024,
            "hbm_bytes_per_launch": 2*fetch*1024+write*1024,
+           # W*H*N*4 + 72*E + 48 per glyph = 8192 x (64*64*3*4 + 48) + 72 x 189 191 edges of the bench workload
+           "algorithmic_bytes_per_launch": ALGORITHMIC, "tile_bytes_per_launch": TILES,
+           "traffic_over_algorithmic": round((2*fetch*1024+write*1024)/ALGORITHMIC, 3), "write_over_algorithmic": round(write*1024/ALGORITHMIC, 3),
+           "non_tile_write_bytes": write*1024-TILES,
+           "non_tile_write_note": "WRITE_SIZE minus the tiles: scratch (spill) stores of the two 128-VGPR instantiations + the global-scratch class's workspace slices; "
+                                  "tools/scratch_by_source.py splits the spill part by source function from basic-block counts",
            "correction": "counters in KiB (calibrated: profiles/r03_valu_calibration.json); WRITE_SIZE exact; FETCH_SIZE x2 for vector loads, x0.88 for scalar loads -- "
                          "the kernel mixes both, the x2 end is used",
            "valu_busy_frac_calibrated": round(busy_w, 4),

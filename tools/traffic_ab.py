@@ -1,5 +1,5 @@
 """HBM-side traffic of the distance pass for a library variant: sums the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the k_distance launches of a bench step.
-    python tools/traffic_ab.py <dir with fetch/ and write/ rocprofv3 outputs>      (tools/r05_call15.sh makes them)"""
+    python tools/traffic_ab.py <dir with fetch/ and write/ rocprofv3 outputs>      (bash tools/r06_call.sh <tag> traffic:<variant> makes them and calls this)"""
 import glob
 import os
 import sqlite3
