@@ -72,6 +72,7 @@ struct Tuning {
     int microbatch;                  // MSDFHIP_MICROBATCH          0 / 1 disables the grouping of concurrent single-shape calls; N caps the group
     int sidePriority;                // MSDFHIP_SIDE_PRIORITY       queue priority of the side-class streams: low (-1, default) / none (0) / high (+1) / one (-2) / rest (-3)
     bool noClassSort;                // MSDFHIP_NO_CLASS_SORT       glyph classes in batch order instead of heaviest first (A/B)
+    int queryGridSteps;              // MSDFHIP_QUERY_GRID          grid form of the distance checks: edges a lane may walk per item (0 = off: the two older forms only)
     int queryBatch;                  // MSDFHIP_QUERY_BATCH         cooperative distance checks a wavefront of k_ec_query takes per ticket (default 1: more only lengthens the tail)
     bool noArgPayloadSingle;         // MSDFHIP_NO_ARG_PAYLOAD_SINGLE k_single_call reads small shapes from the staging area instead of its kernel arguments (A/B)
     bool noZeroCopySingle;           // MSDFHIP_NO_ZERO_COPY_SINGLE k_single_call on uploaded inputs / device outputs + one copy back (A/B)
@@ -129,6 +130,7 @@ void readTuning() {
     t.devices[0] = 0;
     t.sidePriority = (env = getenv("MSDFHIP_SIDE_PRIORITY")) ? (env[0] == 'l' ? -1 : env[0] == 'h' ? 1 : env[0] == 'o' ? -2 : env[0] == 'r' ? -3 : 0) : -1;
     t.noClassSort = getenv("MSDFHIP_NO_CLASS_SORT") != NULL;
+    t.queryGridSteps = (env = getenv("MSDFHIP_QUERY_GRID")) ? atoi(env) : 16;
     t.queryBatch = (env = getenv("MSDFHIP_QUERY_BATCH")) && atoi(env) > 0 ? atoi(env) : 1;
     t.noFusedSingle = getenv("MSDFHIP_NO_FUSED_SINGLE") != NULL;
     t.noZeroCopySingle = getenv("MSDFHIP_NO_ZERO_COPY_SINGLE") != NULL;
@@ -1019,6 +1021,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     // Basic-Latin -- 150 (profiles/r03_ab_notes.md).
     lpcMaxContours.lpcEdgeCost = tuning().qpEdgeCost, lpcMaxContours.lpcMaxEdges = tuning().qpMaxEdges, lpcMaxContours.lpcMinCount = tuning().qpMinCount;   // 150, 48, never
     lpcMaxContours.wideMaxEdges = tuning().qpWideMaxEdges, lpcMaxContours.wideLoad = tuning().qpWideLoad, lpcMaxContours.wideMeanCount = tuning().qpWideMeanCount;                                                   // 128, 4e8 (MSDFHIP_QUERY_POLICY)
+    lpcMaxContours.gridSteps = tuning().queryGridSteps;
     const size_t resLanes = OVERLAP ? (size_t) (lpcMaxContours.lpcMaxContours > 0 ? lpcMaxContours.lpcMaxContours : 1)*WAVE*sizeof(double) : 0;
     const int slotOffset = OVERLAP ? (b->maxContours > 0 ? b->maxContours : 1) : 0;
     const int mergedCap = b->maxContours < slotCap ? (b->maxContours > 0 ? b->maxContours : 1) : slotCap;   // per-contour merged states of a glyph that uses the slots

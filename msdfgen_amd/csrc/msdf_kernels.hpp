@@ -448,6 +448,60 @@ __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, con
     }
 }
 
+// Grid form of the distance checks (k_ec_query, round 6): lanes = (candidate, slice). A lane walks edges slice, slice+S, ... of the contour for its own
+// candidate -- its own record in registers (loadEdgeRegs: one round trip of independent loads), the edge types diverge like in the cooperative form --
+// and the S lanes of a candidate then merge their partial selectors in log2(S) shuffle steps. selMergePartial selects by (|d|, dot, visit index): a total
+// order, so the result does not depend on how the contour's edges were dealt (the same argument, and the same function, as the team of k_single_call).
+// All S lanes of a candidate hold identical values afterwards and take identical branches; xor-shuffles below S never leave the (aligned) group, so
+// divergence BETWEEN candidates (second walks of the combiner) cannot make a lane read an inactive one.
+struct EdgesGrid {
+    const int32_t *coff;
+    int slice, S;
+    __device__ int begin(int c) const { return coff[c]-coff[0]; }
+    __device__ int end(int c) const { return coff[c+1]-coff[0]; }
+};
+
+__device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const EdgesGrid &edges, int c, V2 o) {
+    Selector<2> mine;
+    selInit(mine);
+    const int e = MSDF_UNIFORM(edges.end(c));
+    MSDF_NOUNROLL
+    for (int i = MSDF_UNIFORM(edges.begin(c))+edges.slice; i < e; i += edges.S) {
+        const EdgeRegs r = loadEdgeRegs(rec+i, i);
+        selAddEdge(mine, r, i, o);
+    }
+    MSDF_NOUNROLL
+    for (int off = 1; off < edges.S; off <<= 1) {
+        Selector<2> other;
+        selInit(other);
+        PB &m = mine.c[0], &t = other.c[0];
+        t.td = __shfl_xor(m.td, off), t.tdot = __shfl_xor(m.tdot, off), t.perp = __shfl_xor(m.perp, off);
+        t.neg = __shfl_xor(m.neg, off), t.pos = __shfl_xor(m.pos, off);
+        other.idx[0] = __shfl_xor(mine.idx[0], off);
+        selMergePartial(mine, other);
+    }
+    selMergePartial(sel, mine);                                     // (sel: the caller's running selector -- the initial state in the overlapping combiner, earlier contours in the simple one)
+}
+
+template <bool OVERLAP, class Wind>
+struct PsdfQueryGrid {                                              // PsdfQuery with the lane's slice
+    const EdgeRec *rec;
+    const int32_t *coff;
+    Wind windings;
+    int C, slice, S;
+    double *res;
+    __device__ double operator()(V2 q) const {
+        double out[1];
+        EdgesGrid edges;
+        edges.coff = coff, edges.slice = slice, edges.S = S;
+        if (OVERLAP)
+            shapeDistanceOverlap<2>(rec, edges, windings, C, q, res, WAVE, out);
+        else
+            shapeDistanceSimple<2>(rec, edges, C, q, out);
+        return out[0];
+    }
+};
+
 // ---- a TEAM of wavefronts on one tile (k_single_call, round 6) -----------------------------------------------------------------------------------
 // A single-shape call runs 64 tiles on 1 024 SIMDs: a tile's wavefront is alone on its SIMD and what the call waits for is the serial walk of its busiest
 // tile (33 of the launch's 67 us). With TEAM wavefronts per tile, member r walks survivors r, r+TEAM, ... of every contour's (nearest-first) segment into a
@@ -1335,7 +1389,26 @@ k_ec_fast(BatchView batch, const MsdfHipGlyph *glyphs, int width, int height, in
 //   lane per candidate 64 candidates at a time, every lane walks all edges (uniform control flow, scalar record loads -- the loop of
 //                      k_distance): cost per chunk ~ 340*nE + 1000, whatever the number of live lanes.
 // The first wins for the usual handful of candidates, the second for many (an icon with 186, a 1024x1024 logo with thousands).
-struct EcQueryPolicy { int lpcMaxContours, lpcEdgeCost, lpcMaxEdges, lpcMinCount, wideMaxEdges; float wideLoad, wideMeanCount; };
+//   grid (round 6)     lanes = (candidate, slice): the 64 lanes are J = 64/S candidates x S slices; a lane walks edges slice, slice+S, ... of every contour
+//                      for ITS candidate (its own record in registers, like the cooperative form) and the S lanes of a candidate merge their partial
+//                      selectors with lane shuffles (selMergePartial: a total order, the union's winner is the better of the partial winners). The usual
+//                      glyph (7 candidates, 23 edges: J = 8, S = 8) is ONE item of ~3 evaluation steps per lane, where the forms above spend either a serial
+//                      walk of all 23 edges with 7 of 64 lanes alive, or 7 items with 23 of 64 lanes alive: k_ec_query is a chain of item latencies.
+//                      S = max(64 / pow2(count), pow2(nE / gridSteps)); S = 64 is the cooperative form, S = 1 the lane-per-candidate form -- they stay.
+struct EcQueryPolicy { int lpcMaxContours, lpcEdgeCost, lpcMaxEdges, lpcMinCount, wideMaxEdges; float wideLoad, wideMeanCount; int gridSteps; };
+MSDF_HD int ecQueryGridSlices(unsigned count, int nE, int C, EcQueryPolicy q) {     // S of the grid form, or 0: one of the other two forms
+    if (q.gridSteps <= 0 || C > q.lpcMaxContours || count == 0)      // (the [contour][lane] scratch of the lane-per-candidate form is the grid form's too)
+        return 0;
+    int J = 1;
+    while (J < (int) count && J < WAVE)
+        J <<= 1;
+    int S = WAVE/J, need = 1;
+    while (need*q.gridSteps < nE && need < WAVE)
+        need <<= 1;
+    if (need > S)
+        S = need;
+    return S >= 2 && S <= WAVE/2 ? S : 0;
+}
 MSDF_HD bool ecQueryLanePerCandidate(unsigned count, int nE, int C, EcQueryPolicy q) {
     if (C > q.lpcMaxContours)                                        // its [contour][lane] scratch would not fit the LDS the launch reserved
         return false;
@@ -1348,7 +1421,16 @@ MSDF_HD bool ecQueryLanePerCandidate(unsigned count, int nE, int C, EcQueryPolic
 MSDF_HD int ecQueryItems(unsigned count, unsigned seg, int nE, int C, EcQueryPolicy lpcMaxContours) {     // work items of one glyph; a glyph whose segment overflowed has none (k_ec_slow redoes it)
     if (count > seg)
         return 0;
+    const int S = ecQueryGridSlices(count, nE, C, lpcMaxContours);
+    if (S)
+        return (int) ((count+WAVE/S-1)/(WAVE/S));
     return ecQueryLanePerCandidate(count, nE, C, lpcMaxContours) ? (int) ((count+WAVE-1)/WAVE) : (int) count;
+}
+// ... and whether they are listed with the chunks (the long items, drawn first) or with the cooperative items
+// (round 6: with the grid form the longest single items are the cooperative ones of glyphs with several ROUNDS of edges -- 186 candidates x 9 rounds for the 543-edge
+// symbol of the DejaVu set, 0.15 ms for its 34 largest glyphs alone -- and they were drawn LAST: now they go first, with their glyph's position in the heavy-first order)
+MSDF_HD bool ecQueryListedFirst(unsigned count, int nE, int C, EcQueryPolicy q) {
+    return ecQueryGridSlices(count, nE, C, q) != 0 || ecQueryLanePerCandidate(count, nE, C, q) || (q.gridSteps > 0 && nE > WAVE);
 }
 
 // Prefix sums of the per-glyph work items of k_ec_query (one workgroup). The list is ordered HEAVY FIRST: the lane-per-candidate chunks
@@ -1404,6 +1486,11 @@ k_ec_scan(int nGlyphs, const unsigned *__restrict__ header, unsigned seg, int *_
     const bool dense = lpcMaxContours.wideMeanCount > 0 && totalCount >= lpcMaxContours.wideMeanCount*(float) nGlyphs;
     if ((total > lpcMaxContours.wideLoad || dense) && lpcMaxContours.wideMaxEdges > lpcMaxContours.lpcMaxEdges)
         lpcMaxContours.lpcMaxEdges = lpcMaxContours.wideMaxEdges;
+    // ... and such a launch is throughput bound: the grid form (fewer live edges per instruction than a chunk's uniform walk) is for latency chains only
+    // (CJK-like set with the grid form: correction 2.08 -> 3.17 ms). Published to k_ec_query with the edge bound (bit 30).
+    const bool gridOff = total > lpcMaxContours.wideLoad || dense || lpcMaxContours.gridSteps <= 0;
+    if (gridOff)
+        lpcMaxContours.gridSteps = 0;
     int *coop = offsets+nGlyphs+1;
     int carry[2] = { 0, 0 };                                        // items of the earlier rounds (batches of more than 8 192 glyphs)
     for (int base = 0; base < nGlyphs; base += 1024*PER) {
@@ -1416,7 +1503,7 @@ k_ec_scan(int nGlyphs, const unsigned *__restrict__ header, unsigned seg, int *_
             const int g = p < nGlyphs ? (order ? order[p] : p) : -1;
             const unsigned count = g >= 0 ? header[1+g] : 0u;
             const int nE = g >= 0 ? sizes[2*g] : 0, C = g >= 0 ? sizes[2*g+1] : 0;
-            chunky[k] = g >= 0 && ecQueryLanePerCandidate(count, nE, C, lpcMaxContours);
+            chunky[k] = g >= 0 && ecQueryListedFirst(count, nE, C, lpcMaxContours);
             items[k] = g >= 0 ? ecQueryItems(count, seg, nE, C, lpcMaxContours) : 0;
             sum[chunky[k] ? 0 : 1] += items[k];
         }
@@ -1452,7 +1539,7 @@ k_ec_scan(int nGlyphs, const unsigned *__restrict__ header, unsigned seg, int *_
         offsets[nGlyphs] = carry[0];
         coop[nGlyphs] = carry[1];
         coop[nGlyphs+1] = 0;
-        coop[nGlyphs+2] = lpcMaxContours.lpcMaxEdges;
+        coop[nGlyphs+2] = lpcMaxContours.lpcMaxEdges|(gridOff ? 1<<30 : 0);
     }
 }
 
@@ -1504,7 +1591,9 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
     // ~27 us an item took (55 k items of the DejaVu set over 3 072 resident wavefronts in 0.48 ms: the kernel is this latency chain).
     const int chunks = offsets[batch.nGlyphs], coopItems = offsets[2*batch.nGlyphs+1];
     const int tickets = chunks+(coopItems+itemsPerTicket-1)/itemsPerTicket;   // a ticket = one chunk, or itemsPerTicket consecutive cooperative items
-    lpcMaxContours.lpcMaxEdges = offsets[2*batch.nGlyphs+3];        // as k_ec_scan decided for this launch
+    lpcMaxContours.lpcMaxEdges = offsets[2*batch.nGlyphs+3]&((1<<30)-1);   // as k_ec_scan decided for this launch
+    if (offsets[2*batch.nGlyphs+3]&(1<<30))
+        lpcMaxContours.gridSteps = 0;
 #if defined(MSDF_PROFILE_QUERY)
     MSDF_QSTAMP(qStart);
     unsigned long long qAcc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, qItems[4] = { 0, 0, 0, 0 }, qLongest = 0, qLastWork = 0, qLongestWho = 0;
@@ -1576,9 +1665,31 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
         MSDF_QSTAMP(q3);
         qAcc[2] += q3-q2;
         unsigned long long q4 = q3;
-        const bool qChunk = ecQueryLanePerCandidate(count, nE, C, lpcMaxContours);
+        const bool qChunk = ecQueryListedFirst(count, nE, C, lpcMaxContours);
 #endif
-        if (ecQueryLanePerCandidate(count, nE, C, lpcMaxContours)) {
+        const int gridS = ecQueryGridSlices(count, nE, C, lpcMaxContours);
+        if (gridS) {                                                // lanes = (candidate, slice): 64 / gridS candidates per item
+            PsdfQueryGrid<OVERLAP, WindingMasks> query;
+            query.rec = batch.recs+coff[0], query.coff = coff, query.windings = wind, query.C = C, query.res = smemLds+threadIdx.x;
+            query.S = gridS, query.slice = (int) threadIdx.x&(gridS-1);
+            const unsigned k = (unsigned) item*(unsigned) (WAVE/gridS)+threadIdx.x/(unsigned) gridS;
+            if (k < count) {
+                const EcCandidate cand = segment[k];
+                const size_t texel = cand.texel;
+                const int rem = (int) (texel-(size_t) g*texelsPerGlyph);
+                const int yn = rem/width, x = rem%width;
+                const int ys = gd.flip ? height-1-yn : yn;
+                const bool artifact = ecEvaluateCandidate(sdf, p, x, ys, cand.t, (cand.dir&3)-1, ((cand.dir>>2)&3)-1, query);
+                if (artifact && query.slice == 0) {
+                    const float *in = sdf.native(x, yn);
+                    const float m = medianf(in[0], in[1], in[2]);
+                    float *px = out+gd.out_offset+(ptrdiff_t) gd.row_stride*yn+(ptrdiff_t) N*x;
+                    px[0] = m, px[1] = m, px[2] = m;
+                    if (stencilOut)
+                        stencilOut[stencilIndex(texel, yn, width, height, cfg.stencil_y_down)] |= (uint8_t) EC_ERROR;
+                }
+            }
+        } else if (ecQueryLanePerCandidate(count, nE, C, lpcMaxContours)) {
             PsdfQuery<OVERLAP, WindingMasks, EdgesAllBatched> query;
             query.rec = batch.recs+coff[0], query.coff = coff, query.windings = wind, query.C = C, query.res = smemLds+threadIdx.x;
             const unsigned k = (unsigned) item*WAVE+threadIdx.x;
