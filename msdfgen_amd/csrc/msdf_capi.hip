@@ -72,6 +72,7 @@ struct Tuning {
     int microbatch;                  // MSDFHIP_MICROBATCH          0 / 1 disables the grouping of concurrent single-shape calls; N caps the group
     int sidePriority;                // MSDFHIP_SIDE_PRIORITY       queue priority of the side-class streams: low (-1, default) / none (0) / high (+1) / one (-2) / rest (-3)
     bool noClassSort;                // MSDFHIP_NO_CLASS_SORT       glyph classes in batch order instead of heaviest first (A/B)
+    bool queryStatic;                // MSDFHIP_QUERY_STATIC        0: k_ec_query draws its tickets from an atomic counter (rounds 2-5) instead of the static serpentine deal
     int queryGridSteps;              // MSDFHIP_QUERY_GRID          grid form of the distance checks: edges a lane may walk per item (0 = off: the two older forms only)
     int queryBatch;                  // MSDFHIP_QUERY_BATCH         cooperative distance checks a wavefront of k_ec_query takes per ticket (default 1: more only lengthens the tail)
     bool noArgPayloadSingle;         // MSDFHIP_NO_ARG_PAYLOAD_SINGLE k_single_call reads small shapes from the staging area instead of its kernel arguments (A/B)
@@ -130,6 +131,7 @@ void readTuning() {
     t.devices[0] = 0;
     t.sidePriority = (env = getenv("MSDFHIP_SIDE_PRIORITY")) ? (env[0] == 'l' ? -1 : env[0] == 'h' ? 1 : env[0] == 'o' ? -2 : env[0] == 'r' ? -3 : 0) : -1;
     t.noClassSort = getenv("MSDFHIP_NO_CLASS_SORT") != NULL;
+    t.queryStatic = !((env = getenv("MSDFHIP_QUERY_STATIC")) && atoi(env) == 0);
     t.queryGridSteps = (env = getenv("MSDFHIP_QUERY_GRID")) ? atoi(env) : 16;
     t.queryBatch = (env = getenv("MSDFHIP_QUERY_BATCH")) && atoi(env) > 0 ? atoi(env) : 1;
     t.noFusedSingle = getenv("MSDFHIP_NO_FUSED_SINGLE") != NULL;
@@ -951,6 +953,27 @@ int ensureDeferred(const MsdfHipBatch *b, size_t cap, EcCandidate **out) {
     return MSDFHIP_OK;
 }
 
+// Workgroups of k_ec_query<N, OVERLAP> the device holds at once at this LDS size (its tickets are dealt out statically to that many); 0: unknown.
+template <int N, bool OVERLAP>
+unsigned queryResidentBlocks(int device, size_t lds) {
+    enum { LDS_STEP = 2048, LDS_STEPS = 81 };
+    static std::atomic<int> cache[LDS_STEPS];                    // (one gfx950 is like another: not keyed by device)
+    const size_t step = (lds+LDS_STEP-1)/LDS_STEP;
+    if (step >= LDS_STEPS)
+        return 0;
+    int v = cache[step].load();
+    if (!v) {
+        int perCu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, reinterpret_cast<const void *>(k_ec_query<N, OVERLAP>), WAVE, step*LDS_STEP) != hipSuccess) {
+            (void) hipGetLastError();
+            perCu = 0;
+        }
+        v = perCu > 0 ? perCu*residentSlots(device) : -1;
+        cache[step].store(v);
+    }
+    return v > 0 ? (unsigned) v : 0u;
+}
+
 template <int N, bool OVERLAP, bool GRES>
 int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, const float *src, float *out, uint8_t *stencil,
              const MsdfHipConfig &cfg, hipStream_t stream, bool paramsOnly = false) {
@@ -1052,7 +1075,14 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     // the query kernel is a pool of wavefronts draining one work list: enough of them to fill the device, no more
     // (a wavefront that finds the list empty leaves after one atomic; still, a single 64x64 glyph should not launch thousands of them)
     const size_t wanted = allTexels/512;
-    const unsigned queryBlocks = (unsigned) (wanted < 64 ? 64 : wanted > 8192 ? 8192 : wanted);
+    unsigned queryBlocks = (unsigned) (wanted < 64 ? 64 : wanted > 8192 ? 8192 : wanted);
+    // ... dealt out statically (k_ec_query: no ticket counter) to as many workgroups as the device holds at once
+    const bool staticDeal = tuning().queryStatic;
+    if (staticDeal) {
+        const unsigned resident = queryResidentBlocks<N, OVERLAP>(b->device, queryLds);
+        if (resident && queryBlocks > resident)
+            queryBlocks = resident;
+    }
     if (paramsOnly || !b->ecParamsAhead)                         // (the ahead call ALWAYS launches it: a flag left over from a failed call cannot make both calls skip it)
         hipLaunchKernelGGL(k_ec_params, dim3((unsigned) b->nGlyphs), dim3(WAVE), 0, stream, b->dEcParams, viewOf(b), dGlyphs, cfg,
                            reinterpret_cast<unsigned *>(deferred), corners, offsets+ecSizesAt(b->nGlyphs));   // also zeroes the candidate header
@@ -1072,7 +1102,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     hipLaunchKernelGGL((k_ec_query<N, OVERLAP>), dim3(queryBlocks), dim3(WAVE), queryLds, stream, b->nGlyphs, b->dGlyphContourOffsets, b->dContourOffsets,
                        (const EdgeRec *) viewOf(b).recs, viewOf(b).windings, dGlyphs, w, h, src, out, stencil, cfg,
                        (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, (const int *) offsets, offsets+2*(size_t) b->nGlyphs+2, tuning().queryBatch, slotCap, slotOffset, lpcMaxContours,
-                       b->overflowOut, ecOrder);
+                       b->overflowOut, ecOrder, staticDeal ? 1 : 0);
     if (b->overflowOut)
         b->overflowMirrored = true;                              // the caller looks at the count after its copy back and reruns with the pass below if needed
     else

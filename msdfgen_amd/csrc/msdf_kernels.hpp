@@ -454,6 +454,9 @@ __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, con
 // order, so the result does not depend on how the contour's edges were dealt (the same argument, and the same function, as the team of k_single_call).
 // All S lanes of a candidate hold identical values afterwards and take identical branches; xor-shuffles below S never leave the (aligned) group, so
 // divergence BETWEEN candidates (second walks of the combiner) cannot make a lane read an inactive one.
+#ifndef MSDF_QGRID_ABLATE
+#define MSDF_QGRID_ABLATE 0
+#endif
 struct EdgesGrid {
     const int32_t *coff;
     int slice, S;
@@ -467,8 +470,16 @@ __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const
     const int e = MSDF_UNIFORM(edges.end(c));
     MSDF_NOUNROLL
     for (int i = MSDF_UNIFORM(edges.begin(c))+edges.slice; i < e; i += edges.S) {
+#if MSDF_QGRID_ABLATE == 2                                          // measurement only: every lane evaluates the contour's first record (loads coalesce and hit)
+        const EdgeRegs r = loadEdgeRegs(rec+MSDF_UNIFORM(edges.begin(c)), i);
+#else
         const EdgeRegs r = loadEdgeRegs(rec+i, i);
+#endif
+#if MSDF_QGRID_ABLATE == 1                                          // measurement only: the loads without the evaluation
+        mine.c[0].neg += r.r0[0]+r.r1[1]+r.e0[2]+r.e1[3]+r.e2[4];
+#else
         selAddEdge(mine, r, i, o);
+#endif
     }
     MSDF_NOUNROLL
     for (int off = 1; off < edges.S; off <<= 1) {
@@ -1573,7 +1584,7 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
            const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, const float *__restrict__ src, float *__restrict__ out,
            uint8_t *__restrict__ stencilOut, MsdfHipConfig cfg, const EcGlyphParams *__restrict__ glyphParams, const EcCandidate *__restrict__ cands, unsigned seg,
            const int *__restrict__ offsets, int *__restrict__ counter, int itemsPerTicket, int slotCap, int slotOffset, EcQueryPolicy lpcMaxContours,
-           unsigned *__restrict__ overflowOut, const int *__restrict__ order) {
+           unsigned *__restrict__ overflowOut, const int *__restrict__ order, int staticDeal) {
     // overflowOut (single-shape host calls): the candidate-overflow count is mirrored next to the results, so that the host sees it with the
     // copy back instead of a k_ec_slow launch that does nothing in all but pathological cases (one launch less on a latency-bound path)
     if (overflowOut && blockIdx.x == 0 && threadIdx.x == 0)
@@ -1598,16 +1609,30 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
     MSDF_QSTAMP(qStart);
     unsigned long long qAcc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, qItems[4] = { 0, 0, 0, 0 }, qLongest = 0, qLastWork = 0, qLongestWho = 0;
 #endif
-    for (;;) {
+    // Which tickets a wavefront takes (round 6). They used to be drawn from ONE atomic counter: with the evaluation of every item ablated the launch still took
+    // 0.20 of its 0.28 ms (variants/qab3, profiles/r06_ab_notes.md 12) -- ~17 000 device-scope atomics on one address (8 600 tickets + one failing draw per
+    // workgroup) serialize at ~12 ns each, across eight XCDs. The list is ordered longest items first (k_ec_scan), so a STATIC deal does nearly as well as
+    // the dynamic one without a single atomic: workgroup b of W takes tickets b, 2W-1-b, 2W+b, 4W-1-b, ... (a serpentine: whoever drew the longest items of
+    // one round gets the shortest of the next); W is what the device holds of this kernel at once (msdf_capi.hip: queryResidentBlocks).
+    const int dealt = staticDeal ? (int) gridDim.x : 0;
+    for (int round = 0;; ++round) {
 #if defined(MSDF_PROFILE_QUERY)
         MSDF_QSTAMP(q0);
 #endif
         int ticket = 0;
-        if (threadIdx.x == 0)
-            ticket = atomicAdd(counter, 1);
-        ticket = __builtin_amdgcn_readfirstlane(ticket);
-        if (ticket >= tickets)
-            break;
+        if (dealt) {
+            if ((long long) round*dealt >= tickets)
+                break;
+            ticket = (round&1) ? (round+1)*dealt-1-(int) blockIdx.x : round*dealt+(int) blockIdx.x;
+            if (ticket >= tickets)
+                continue;
+        } else {
+            if (threadIdx.x == 0)
+                ticket = atomicAdd(counter, 1);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            if (ticket >= tickets)
+                break;
+        }
 #if defined(MSDF_PROFILE_QUERY)
         MSDF_QSTAMP(q1);
         qAcc[0] += q1-q0;
@@ -1668,6 +1693,10 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
         const bool qChunk = ecQueryListedFirst(count, nE, C, lpcMaxContours);
 #endif
         const int gridS = ecQueryGridSlices(count, nE, C, lpcMaxContours);
+#if MSDF_QGRID_ABLATE == 3                                          // measurement only: ticket, lookup and glyph state of every item, nothing else
+        if (count != 0xffffffffu)
+            continue;
+#endif
         if (gridS) {                                                // lanes = (candidate, slice): 64 / gridS candidates per item
             PsdfQueryGrid<OVERLAP, WindingMasks> query;
             query.rec = batch.recs+coff[0], query.coff = coff, query.windings = wind, query.C = C, query.res = smemLds+threadIdx.x;
