@@ -455,7 +455,7 @@ __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, con
 // All S lanes of a candidate hold identical values afterwards and take identical branches; xor-shuffles below S never leave the (aligned) group, so
 // divergence BETWEEN candidates (second walks of the combiner) cannot make a lane read an inactive one.
 #ifndef MSDF_QGRID_ABLATE
-#define MSDF_QGRID_ABLATE 0
+#define MSDF_QGRID_ABLATE 0                                         // measurement builds only (profiles/r06_ab_notes.md 12): 1 loads without evaluation, 2 one record for all lanes, 3 no items, 4 no distance query, 5 no loads / evaluation, 6 no shuffles either
 #endif
 struct EdgesGrid {
     const int32_t *coff;
@@ -468,8 +468,11 @@ __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const
     Selector<2> mine;
     selInit(mine);
     const int e = MSDF_UNIFORM(edges.end(c));
+#if MSDF_QGRID_ABLATE >= 5                                          // measurement only: no loads, no evaluation (6: no shuffles either)
+    mine.c[0].td = o.x, mine.c[0].tdot = o.y+e;
+#endif
     MSDF_NOUNROLL
-    for (int i = MSDF_UNIFORM(edges.begin(c))+edges.slice; i < e; i += edges.S) {
+    for (int i = MSDF_UNIFORM(edges.begin(c))+edges.slice; i < (MSDF_QGRID_ABLATE >= 5 ? 0 : e); i += edges.S) {
 #if MSDF_QGRID_ABLATE == 2                                          // measurement only: every lane evaluates the contour's first record (loads coalesce and hit)
         const EdgeRegs r = loadEdgeRegs(rec+MSDF_UNIFORM(edges.begin(c)), i);
 #else
@@ -482,7 +485,7 @@ __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const
 #endif
     }
     MSDF_NOUNROLL
-    for (int off = 1; off < edges.S; off <<= 1) {
+    for (int off = 1; off < (MSDF_QGRID_ABLATE == 6 ? 1 : edges.S); off <<= 1) {
         Selector<2> other;
         selInit(other);
         PB &m = mine.c[0], &t = other.c[0];
@@ -503,6 +506,9 @@ struct PsdfQueryGrid {                                              // PsdfQuery
     double *res;
     __device__ double operator()(V2 q) const {
         double out[1];
+#if MSDF_QGRID_ABLATE == 4                                          // measurement only: candidate, texels, interpolation, stores -- no distance query
+        return q.x+q.y;
+#endif
         EdgesGrid edges;
         edges.coff = coff, edges.slice = slice, edges.S = S;
         if (OVERLAP)

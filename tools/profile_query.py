@@ -55,7 +55,7 @@ def main():
             "wave_cycles_sum_over_span_x_waves_with_work": v[1]/max(span*busy, 1),
             "chunk_items": v[5], "cycles_per_chunk_item": v[6]/max(v[5], 1), "cooperative_items": v[7], "cycles_per_cooperative_item": v[8]/max(v[7], 1),
             "cooperative_rounds_per_item": v[15]/max(v[7], 1), "longest_item_cycles": v[14], "longest_item_over_span": v[14]/max(span, 1),
-            "items_per_wave_with_work": items/busy,
+            "items_per_wave_with_work": items/busy, "longest_wave_cycles": v[18], "mean_wave_cycles": v[1]/waves,
             "frac_ticket": v[9]/acc, "frac_lookup": v[10]/acc, "frac_glyph_state": v[11]/acc, "frac_evaluation": v[12]/acc, "frac_store_barrier": v[13]/acc,
             "cycles_per_item": {"ticket": v[9]/items, "lookup": v[10]/items, "glyph_state": v[11]/items, "evaluation": v[12]/items, "store_barrier": v[13]/items}}
     lib.msdfhip_debug_wait_profile(out, 2)                          # second page: inside the cooperative distance query
