@@ -72,7 +72,7 @@ struct Tuning {
     int microbatch;                  // MSDFHIP_MICROBATCH          0 / 1 disables the grouping of concurrent single-shape calls; N caps the group
     int sidePriority;                // MSDFHIP_SIDE_PRIORITY       queue priority of the side-class streams: low (-1, default) / none (0) / high (+1) / one (-2) / rest (-3)
     bool noClassSort;                // MSDFHIP_NO_CLASS_SORT       glyph classes in batch order instead of heaviest first (A/B)
-    bool queryStatic;                // MSDFHIP_QUERY_STATIC        0: k_ec_query draws its tickets from an atomic counter (rounds 2-5) instead of the static serpentine deal
+    int queryStatic;                 // MSDFHIP_QUERY_STATIC        2: first ticket dealt, the others from eight counters; 0: k_ec_query draws its tickets from an atomic counter (rounds 2-5) instead of the static serpentine deal
     int queryGridSteps;              // MSDFHIP_QUERY_GRID          grid form of the distance checks: edges a lane may walk per item (0 = off: the two older forms only)
     int queryBatch;                  // MSDFHIP_QUERY_BATCH         cooperative distance checks a wavefront of k_ec_query takes per ticket (default 1: more only lengthens the tail)
     bool noArgPayloadSingle;         // MSDFHIP_NO_ARG_PAYLOAD_SINGLE k_single_call reads small shapes from the staging area instead of its kernel arguments (A/B)
@@ -131,7 +131,7 @@ void readTuning() {
     t.devices[0] = 0;
     t.sidePriority = (env = getenv("MSDFHIP_SIDE_PRIORITY")) ? (env[0] == 'l' ? -1 : env[0] == 'h' ? 1 : env[0] == 'o' ? -2 : env[0] == 'r' ? -3 : 0) : -1;
     t.noClassSort = getenv("MSDFHIP_NO_CLASS_SORT") != NULL;
-    t.queryStatic = !((env = getenv("MSDFHIP_QUERY_STATIC")) && atoi(env) == 0);
+    t.queryStatic = (env = getenv("MSDFHIP_QUERY_STATIC")) ? atoi(env) : 2;
     t.queryGridSteps = (env = getenv("MSDFHIP_QUERY_GRID")) ? atoi(env) : 16;
     t.queryBatch = (env = getenv("MSDFHIP_QUERY_BATCH")) && atoi(env) > 0 ? atoi(env) : 1;
     t.noFusedSingle = getenv("MSDFHIP_NO_FUSED_SINGLE") != NULL;
@@ -1077,7 +1077,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     const size_t wanted = allTexels/512;
     unsigned queryBlocks = (unsigned) (wanted < 64 ? 64 : wanted > 8192 ? 8192 : wanted);
     // ... dealt out statically (k_ec_query: no ticket counter) to as many workgroups as the device holds at once
-    const bool staticDeal = tuning().queryStatic;
+    const bool staticDeal = tuning().queryStatic != 0;
     if (staticDeal) {
         const unsigned resident = queryResidentBlocks<N, OVERLAP>(b->device, queryLds);
         if (resident && queryBlocks > resident)
@@ -1102,7 +1102,7 @@ int launchEc(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, c
     hipLaunchKernelGGL((k_ec_query<N, OVERLAP>), dim3(queryBlocks), dim3(WAVE), queryLds, stream, b->nGlyphs, b->dGlyphContourOffsets, b->dContourOffsets,
                        (const EdgeRec *) viewOf(b).recs, viewOf(b).windings, dGlyphs, w, h, src, out, stencil, cfg,
                        (const EcGlyphParams *) b->dEcParams, (const EcCandidate *) deferred, seg, (const int *) offsets, offsets+2*(size_t) b->nGlyphs+2, tuning().queryBatch, slotCap, slotOffset, lpcMaxContours,
-                       b->overflowOut, ecOrder, staticDeal ? 1 : 0);
+                       b->overflowOut, ecOrder, staticDeal ? (tuning().queryStatic == 2 ? 5 : 1) : 0);
     if (b->overflowOut)
         b->overflowMirrored = true;                              // the caller looks at the count after its copy back and reruns with the pass below if needed
     else

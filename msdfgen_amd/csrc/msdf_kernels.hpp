@@ -1459,7 +1459,8 @@ MSDF_HD bool ecQueryListedFirst(unsigned count, int nE, int C, EcQueryPolicy q) 
 // chain) only small glyphs (<= lpcMaxEdges) use it; when the cooperative form of everything would cost more than wideLoad instructions
 // (440 k candidates of the CJK-like set: throughput bound) glyphs up to wideMaxEdges do. offsets[2G+3] = the bound in force.
 // ... followed by (edges, contours) per glyph, written by k_ec_params (k_ec_scan then reads two ints instead of walking two offset arrays).
-MSDF_HD size_t ecOffsetInts(int nGlyphs) { return 2*((size_t) nGlyphs+1)+2+2*(size_t) nGlyphs; }
+MSDF_HD size_t ecQueuesAt(int nGlyphs) { return 2*((size_t) nGlyphs+1)+2+2*(size_t) nGlyphs; }      // eight ticket counters, 64 bytes apart (k_ec_query, queryFlags & 4)
+MSDF_HD size_t ecOffsetInts(int nGlyphs) { return ecQueuesAt(nGlyphs)+8*16; }
 MSDF_HD size_t ecSizesAt(int nGlyphs) { return 2*((size_t) nGlyphs+1)+2; }
 
 // Positions, not glyphs: `order` (or NULL = identity) lists the glyphs HEAVIEST FIRST (edges x contours, sorted once per batch by the host),
@@ -1556,6 +1557,8 @@ k_ec_scan(int nGlyphs, const unsigned *__restrict__ header, unsigned seg, int *_
         offsets[nGlyphs] = carry[0];
         coop[nGlyphs] = carry[1];
         coop[nGlyphs+1] = 0;
+        for (int q = 0; q < 8; ++q)
+            offsets[ecQueuesAt(nGlyphs)+16*q] = 0;
         coop[nGlyphs+2] = lpcMaxContours.lpcMaxEdges|(gridOff ? 1<<30 : 0);
     }
 }
@@ -1590,7 +1593,7 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
            const int8_t *__restrict__ windings, const MsdfHipGlyph *__restrict__ glyphs, int width, int height, const float *__restrict__ src, float *__restrict__ out,
            uint8_t *__restrict__ stencilOut, MsdfHipConfig cfg, const EcGlyphParams *__restrict__ glyphParams, const EcCandidate *__restrict__ cands, unsigned seg,
            const int *__restrict__ offsets, int *__restrict__ counter, int itemsPerTicket, int slotCap, int slotOffset, EcQueryPolicy lpcMaxContours,
-           unsigned *__restrict__ overflowOut, const int *__restrict__ order, int staticDeal) {
+           unsigned *__restrict__ overflowOut, const int *__restrict__ order, int queryFlags) {   // queryFlags: 1 tickets dealt statically | 4 ... only the first, the others drawn from eight counters
     // overflowOut (single-shape host calls): the candidate-overflow count is mirrored next to the results, so that the host sees it with the
     // copy back instead of a k_ec_slow launch that does nothing in all but pathological cases (one launch less on a latency-bound path)
     if (overflowOut && blockIdx.x == 0 && threadIdx.x == 0)
@@ -1620,13 +1623,21 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
     // workgroup) serialize at ~12 ns each, across eight XCDs. The list is ordered longest items first (k_ec_scan), so a STATIC deal does nearly as well as
     // the dynamic one without a single atomic: workgroup b of W takes tickets b, 2W-1-b, 2W+b, 4W-1-b, ... (a serpentine: whoever drew the longest items of
     // one round gets the shortest of the next); W is what the device holds of this kernel at once (msdf_capi.hip: queryResidentBlocks).
-    const int dealt = staticDeal ? (int) gridDim.x : 0;
+    const int dealt = (queryFlags&1) ? (int) gridDim.x : 0;
     for (int round = 0;; ++round) {
 #if defined(MSDF_PROFILE_QUERY)
         MSDF_QSTAMP(q0);
 #endif
         int ticket = 0;
-        if (dealt) {
+        if (dealt && (queryFlags&4) && round > 0) {
+            // (variant: the first ticket dealt, the others drawn from eight counters -- workgroup b from counter b % 8, which hands out the tickets = b (mod 8))
+            const int q = (int) blockIdx.x&7;
+            if (threadIdx.x == 0)
+                ticket = atomicAdd(counter+(ecQueuesAt(batch.nGlyphs)-(2*(size_t) batch.nGlyphs+2))+16*q, 1);
+            ticket = dealt+__builtin_amdgcn_readfirstlane(ticket)*8+q;
+            if (ticket >= tickets)
+                break;
+        } else if (dealt) {
             if ((long long) round*dealt >= tickets)
                 break;
             ticket = (round&1) ? (round+1)*dealt-1-(int) blockIdx.x : round*dealt+(int) blockIdx.x;
