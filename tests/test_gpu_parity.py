@@ -318,7 +318,7 @@ def test_config4_full_size_atlas_8192_glyphs_48(oracle):
 def test_scheduling_knobs_do_not_change_a_byte():
     """Round 3 changed WHEN work runs, never what it computes: glyph classes heaviest first (MSDFHIP_NO_CLASS_SORT), side classes at low queue
     priority (MSDFHIP_SIDE_PRIORITY), distance checks per ticket
-    (MSDFHIP_QUERY_BATCH), which glyphs take the lane-per-candidate chunks / how many edges get LDS slots (MSDFHIP_QUERY_POLICY,
+    (MSDFHIP_QUERY_BATCH), the form and the ticket schedule of the distance checks (round 6: MSDFHIP_QUERY_GRID, MSDFHIP_QUERY_STATIC), which glyphs take the lane-per-candidate chunks / how many edges get LDS slots (MSDFHIP_QUERY_POLICY,
     MSDFHIP_QUERY_LDS -- i.e. k_ec_query's cooperative path with register records vs its chunk walk with batched scalar loads on the SAME
     candidates). 1 024 distinct DejaVu glyphs incl. the 543-edge symbol, msdf with the default correction and mtsdf with ALWAYS_CHECK."""
     import os
@@ -340,7 +340,12 @@ def test_scheduling_knobs_do_not_change_a_byte():
     knobs = [{"MSDFHIP_NO_CLASS_SORT": "1"}, {"MSDFHIP_QUERY_BATCH": "5"}, {"MSDFHIP_QUERY_POLICY": "150,0,2147483647,0,4e8"},
              {"MSDFHIP_QUERY_POLICY": "1,128,0,128,0"}, {"MSDFHIP_QUERY_LDS": "700,30"}, {"MSDFHIP_QUERY_LDS": "16,2"}, {"MSDFHIP_SERIAL_CLASSES": "1"}, {"MSDFHIP_SIDE_PRIORITY": "none"},
              {"MSDFHIP_SIDE_PRIORITY": "high"}, {"MSDFHIP_SHORT_ROUNDS": "0"}, {"MSDFHIP_SHORT_ROUNDS": "100000"}, {"MSDFHIP_SHARE_GRID": "0"}, {"MSDFHIP_SHARE_GRID": "3"},
-             {"MSDFHIP_PERSISTENT_ROUNDS": "1", "MSDFHIP_PERSISTENT_GRID": "300"}]   # (last two: four tiles / one tile per wavefront in every class launch)
+             {"MSDFHIP_PERSISTENT_ROUNDS": "1", "MSDFHIP_PERSISTENT_GRID": "300"},   # (last two: four tiles / one tile per wavefront in every class launch)
+             # round 6: the grid form of the distance checks (lanes = candidates x edge slices, partial selectors merged by shuffles) off / with other
+             # slice counts, and the three ways a wavefront of k_ec_query comes by its tickets (one counter / dealt statically / first dealt + eight counters)
+             {"MSDFHIP_QUERY_GRID": "0"}, {"MSDFHIP_QUERY_GRID": "2"}, {"MSDFHIP_QUERY_GRID": "5"}, {"MSDFHIP_QUERY_GRID": "64"},
+             {"MSDFHIP_QUERY_STATIC": "0"}, {"MSDFHIP_QUERY_STATIC": "1"}, {"MSDFHIP_QUERY_STATIC": "1", "MSDFHIP_QUERY_GRID": "0", "MSDFHIP_QUERY_BATCH": "3"},
+             {"MSDFHIP_QUERY_STATIC": "2", "MSDFHIP_QUERY_BATCH": "4"}]
     for env in knobs:
         os.environ.update(env)
         M.load().msdfhip_reload_tuning()
