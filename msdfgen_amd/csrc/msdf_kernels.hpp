@@ -64,6 +64,10 @@ struct WaveCtx {
     }
 };
 
+enum { PREP_WINDING_LDS_EDGES = 768 };                              // edges whose point(0) a winding wavefront parks in LDS at a time (12 KB; contours beyond: contourWindingsWave)
+#ifndef MSDF_PREP_ABLATE
+#define MSDF_PREP_ABLATE 0                                          // measurement builds only: 1 no windings, 3 no records (2, no contour search, hangs: a wrong contour makes visitToEdge loop)
+#endif
 // The first edgeBlocks workgroups digest one edge per thread; the workgroups after them compute the contour windings (k_windings' job, folded
 // into the same launch: the single-shape entry points are launch-latency bound): a lane per contour, except that contours of at least
 // PREP_WINDING_WAVE_MIN_EDGES edges -- whose serial walk by one lane would be the tail of the whole launch -- are taken by their wavefront together,
@@ -72,15 +76,74 @@ struct WaveCtx {
 __global__ void k_prep_records(EdgeRec *recs, int nEdges, int nContours, const int32_t *contourOffsets,
                                const double *points, const uint8_t *types, const uint8_t *colors, int8_t *windings, int edgeBlocks) {
     if ((int) blockIdx.x >= edgeBlocks) {
+#if MSDF_PREP_ABLATE == 1                                            // measurement only: no windings
+        return;
+#endif
         __shared__ double terms[4][64];
         const int wave = threadIdx.x>>6, lane = threadIdx.x&63;
         const int cBegin = ((int) blockIdx.x-edgeBlocks)*256+64*wave;
         if (cBegin >= nContours)
             return;
         const int c = cBegin+lane;
-        const bool isLong = c < nContours && contourOffsets[c+1]-contourOffsets[c] >= PREP_WINDING_WAVE_MIN_EDGES;
+        const int cb = c < nContours ? contourOffsets[c] : 0, ce = c < nContours ? contourOffsets[c+1] : 0;
+#if !defined(MSDF_PREP_LANE_WINDINGS)
+        const bool isLong = c < nContours && ce-cb > PREP_WINDING_LDS_EDGES;    // (beyond the LDS area: contourWindingsWave, a wavefront per contour, as before)
+#else
+        const bool isLong = c < nContours && ce-cb >= PREP_WINDING_WAVE_MIN_EDGES;
+#endif
+#if !defined(MSDF_PREP_LANE_WINDINGS)
+        // Round 6: a lane per contour made one DEPENDENT, first-touch memory round trip per edge -- up to 47 of them, 0.073 of the digest's 0.114 ms with
+        // the edge workgroups long gone (variants/pab1: the launch without windings). Now in two steps per group of consecutive contours whose edges fit the
+        // wavefront's LDS area: lanes = EDGES load the rows (coalesced, independent) and park point(0) of every edge (edge-segments.cpp:108-119, the
+        // reference's own expression); lanes = CONTOURS then add their shoelace terms in the reference's order (Contour.cpp:72-79) from LDS.
+        // Contours of fewer than three edges (other sample points, :59-71) keep contourWinding; a contour beyond the LDS area takes contourWindingsWave below.
+        // (The contours of 48 edges and more used to take that path, one after the other per wavefront, 64 ordered LDS additions per round: they were the launch's tail.)
+        __shared__ double startPoints[4][2*PREP_WINDING_LDS_EDGES];
+        double *pts = startPoints[wave];
+        WaveCtx sync;                                                // (its sync(): LDS hand-off between the lanes of one wavefront)
+        sync.lane = lane;
+        const bool mid = c < nContours && !isLong && ce-cb >= 3;
+        if (c < nContours && ce-cb < 3)
+            windings[c] = (int8_t) contourWinding(c, contourOffsets, points, types, colors);
+        for (int done = 0; done < WAVE;) {
+            if (!__shfl((int) mid, done)) {                          // (done is wave-uniform)
+                ++done;
+                continue;
+            }
+            const int base = __shfl(cb, done);
+            const bool fits = lane >= done && c < nContours && ce-base <= PREP_WINDING_LDS_EDGES;   // a run of lanes from `done` on (offsets do not decrease); the first fits
+            const int count = __popcll(__ballot(fits));
+            const int top = __shfl(ce, done+count-1);
+            for (int i = base+lane; i < top; i += WAVE) {
+                const V2 p0 = rawPoint(loadRaw(points, types, colors, i), 0);
+                pts[2*(i-base)] = p0.x, pts[2*(i-base)+1] = p0.y;
+            }
+            sync.sync();
+            if (mid && lane >= done && lane < done+count) {
+                double total = 0;
+                V2 prev = mk(pts[2*(ce-1-base)], pts[2*(ce-1-base)+1]);
+                int i = cb;
+                for (; i+4 <= ce; i += 4) {                          // (four points requested together: the chain is the additions, not the LDS reads)
+                    const double *q = pts+2*(i-base);
+                    const V2 c0 = mk(q[0], q[1]), c1 = mk(q[2], q[3]), c2 = mk(q[4], q[5]), c3 = mk(q[6], q[7]);
+                    const double t0 = shoelace(prev, c0), t1 = shoelace(c0, c1), t2 = shoelace(c1, c2), t3 = shoelace(c2, c3);
+                    total += t0, total += t1, total += t2, total += t3;
+                    prev = c3;
+                }
+                for (; i < ce; ++i) {
+                    const V2 cur = mk(pts[2*(i-base)], pts[2*(i-base)+1]);
+                    total += shoelace(prev, cur);
+                    prev = cur;
+                }
+                windings[c] = (int8_t) ((0 < total)-(total < 0));
+            }
+            sync.sync();
+            done += count;
+        }
+#else
         if (c < nContours && !isLong)
             windings[c] = (int8_t) contourWinding(c, contourOffsets, points, types, colors);
+#endif
         unsigned long long longMask = __ballot(isLong);
         WaveCtx ctx;
         ctx.lane = lane;
@@ -95,6 +158,9 @@ __global__ void k_prep_records(EdgeRec *recs, int nEdges, int nContours, const i
     if (slot >= nEdges)
         return;
     int lo = 0, hi = nContours-1;               // last contour c with contourOffsets[c] <= slot (skips empty contours)
+#if MSDF_PREP_ABLATE == 3                                            // measurement only: no records
+    return;
+#endif
     while (lo < hi) {
         int mid = (lo+hi+1)>>1;
         if (contourOffsets[mid] <= slot)
