@@ -72,6 +72,7 @@ struct Tuning {
     int microbatch;                  // MSDFHIP_MICROBATCH          0 / 1 disables the grouping of concurrent single-shape calls; N caps the group
     int sidePriority;                // MSDFHIP_SIDE_PRIORITY       queue priority of the side-class streams: low (-1, default) / none (0) / high (+1) / one (-2) / rest (-3)
     bool noClassSort;                // MSDFHIP_NO_CLASS_SORT       glyph classes in batch order instead of heaviest first (A/B)
+    bool noEcAhead;                  // MSDFHIP_NO_EC_AHEAD         k_ec_params behind the distance pass, as before round 6 (A/B)
     int queryStatic;                 // MSDFHIP_QUERY_STATIC        2: first ticket dealt, the others from eight counters; 0: k_ec_query draws its tickets from an atomic counter (rounds 2-5) instead of the static serpentine deal
     int queryGridSteps;              // MSDFHIP_QUERY_GRID          grid form of the distance checks: edges a lane may walk per item (0 = off: the two older forms only)
     int queryBatch;                  // MSDFHIP_QUERY_BATCH         cooperative distance checks a wavefront of k_ec_query takes per ticket (default 1: more only lengthens the tail)
@@ -131,6 +132,7 @@ void readTuning() {
     t.devices[0] = 0;
     t.sidePriority = (env = getenv("MSDFHIP_SIDE_PRIORITY")) ? (env[0] == 'l' ? -1 : env[0] == 'h' ? 1 : env[0] == 'o' ? -2 : env[0] == 'r' ? -3 : 0) : -1;
     t.noClassSort = getenv("MSDFHIP_NO_CLASS_SORT") != NULL;
+    t.noEcAhead = getenv("MSDFHIP_NO_EC_AHEAD") != NULL;
     t.queryStatic = (env = getenv("MSDFHIP_QUERY_STATIC")) ? atoi(env) : 2;
     t.queryGridSteps = (env = getenv("MSDFHIP_QUERY_GRID")) ? atoi(env) : 16;
     t.queryBatch = (env = getenv("MSDFHIP_QUERY_BATCH")) && atoi(env) > 0 ? atoi(env) : 1;
@@ -279,6 +281,7 @@ struct ScopedTimer {
 
 } // namespace
 
+struct EcAheadRequest { int channels, w, h; const MsdfHipGlyph *dGlyphs; const MsdfHipConfig *cfg; };
 struct MsdfHipBatch {
     int device;                       // the HIP device the batch lives on; every call on the batch binds the calling thread to it
     int nGlyphs, nContours, nEdges, maxContours, maxEdges;
@@ -317,6 +320,7 @@ struct MsdfHipBatch {
     mutable hipEvent_t ecOrderReady;  // (recorded behind that upload)
     mutable int *dEcOrder;            // glyph indices heaviest first (k_ec_scan / k_ec_query), built on first use; NULL: batch order
     mutable bool ecOrderTried;
+    mutable const struct EcAheadRequest *ecAheadWanted;   // msdfhip_batch_generate: the coming correction pass's k_ec_params may run NEXT TO the distance pass -- dispatchDistance queues it on a side stream behind the fork and clears this
     mutable bool ecParamsAhead;       // k_ec_params of the coming correction pass was launched ahead of the distance pass (prepareAhead): launchEc skips it
     mutable hipEvent_t afterDistance; // host-output pipeline: recorded on the call's stream between the distance pass and what follows it (NULL: not wanted)
     int glyphCap;                     // per-glyph work buffers are sized for max(nGlyphs, glyphCap) glyphs (views of the host-output pipeline)
@@ -325,7 +329,7 @@ struct MsdfHipBatch {
     MsdfHipBatch() : device(0), nGlyphs(0), nContours(0), nEdges(0), maxContours(0), maxEdges(0), ownsInputs(false), dGlyphContourOffsets(NULL),
                      dContourOffsets(NULL), dPoints(NULL), dTypes(NULL), dColors(NULL), dRecs(NULL), dWindings(NULL), dScratch(NULL), scratchFloats(0),
                      dDeferred(NULL), dEcParams(NULL), dGres(NULL), dWorkQueue(NULL), queueParity(0), gresBytes(0), gresExternal(false), deferredCap(0), bucketLimit(-1), dBucket(NULL), hBucket(NULL), bucketExternal(false), bucketUploaded(false), nOne(0), nSmall(0),
-                     smallMaxC(0), smallMaxE(0), oneMaxE(0), nHuge(0), restMaxC(0), restMaxE(0), restShare(1.f), serialClasses(false), overflowOut(NULL), overflowMirrored(false), hEcOrder(NULL), ecOrderReady(NULL), dEcOrder(NULL), ecOrderTried(false), ecParamsAhead(false), afterDistance(NULL), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
+                     smallMaxC(0), smallMaxE(0), oneMaxE(0), nHuge(0), restMaxC(0), restMaxE(0), restShare(1.f), serialClasses(false), overflowOut(NULL), overflowMirrored(false), hEcOrder(NULL), ecOrderReady(NULL), dEcOrder(NULL), ecOrderTried(false), ecAheadWanted(NULL), ecParamsAhead(false), afterDistance(NULL), glyphCap(0), forkEvent(NULL) { sideStream[0] = sideStream[1] = NULL, joinEvent[0] = joinEvent[1] = NULL; }
 };
 
 namespace {
@@ -763,6 +767,7 @@ int overlapClassLimit(int nch) {
     return limitAll;
 }
 
+int runCorrectionAhead(const MsdfHipBatch *b, const EcAheadRequest &req, hipStream_t stream);   // (below: runCorrection(..., paramsOnly))
 template <int SEL>
 int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, int h, float *dst, int toScratch, bool overlap, hipStream_t stream) {
     // A glyph whose survivor lists exceed a CU's LDS takes the list-free kernel (the reference cannot fail on a large shape; neither may this) --
@@ -867,6 +872,13 @@ int dispatchDistance(const MsdfHipBatch *b, const MsdfHipGlyph *dGlyphs, int w, 
     }
     // (an error between fork and join must not leave side-stream kernels unordered with the caller's stream: the launches only set rc,
     // the join below always runs)
+    if (b->ecAheadWanted && sOne != stream) {
+        // the correction pass's per-glyph constants (k_ec_params: 17 us + a dependent launch behind the join, round 6 timeline) depend on nothing the distance
+        // pass writes: ahead of the one-contour class on its side stream
+        const EcAheadRequest *req = b->ecAheadWanted;
+        b->ecAheadWanted = NULL;
+        rc = runCorrectionAhead(b, *req, sOne);
+    }
     if (nRest > 0) {                                             // first: few, heavy glyphs -- the longest tail
         LdsPlan rest = plan;                                     // sized for the batch's largest glyph
         rest.globalRes = true;
@@ -1148,6 +1160,10 @@ int ensureScratch(const MsdfHipBatch *b, size_t floats, float **out) {
 int runCorrection(const MsdfHipBatch *b, int channels, int w, int h, const MsdfHipGlyph *dGlyphs, const float *src, float *out, uint8_t *stencil,
                   const MsdfHipConfig &cfg, hipStream_t stream, bool paramsOnly = false) {
     return channels == 3 ? dispatchEc<3>(b, dGlyphs, w, h, src, out, stencil, cfg, stream, paramsOnly) : dispatchEc<4>(b, dGlyphs, w, h, src, out, stencil, cfg, stream, paramsOnly);
+}
+
+int runCorrectionAhead(const MsdfHipBatch *b, const EcAheadRequest &req, hipStream_t stream) {
+    return runCorrection(b, req.channels, req.w, req.h, req.dGlyphs, NULL, NULL, NULL, *req.cfg, stream, true);
 }
 
 // What a generate call on `b` will need that does NOT depend on other work of the device: the class lists of the overlapping combiner and the correction
@@ -1671,12 +1687,15 @@ int msdfhip_batch_generate(const MsdfHipBatch *b, int mode, int w, int h, const 
     }
     float *stageA = stages ? dScratch : NULL, *stageB = stages == 2 ? dScratch+tileFloats : NULL;
     float *dst = stages ? stageA : dOut;
+    EcAheadRequest ahead = { channelsOf(mode), w, h, dGlyphs, cfg };
+    b->ecAheadWanted = correct && !b->ecParamsAhead && !tuning().noEcAhead ? &ahead : NULL;
     switch (mode) {
         case 1: rc = dispatchDistance<1>(b, dGlyphs, w, h, dst, stages != 0, overlap, stream); break;
         case 2: rc = dispatchDistance<2>(b, dGlyphs, w, h, dst, stages != 0, overlap, stream); break;
         case 3: rc = dispatchDistance<3>(b, dGlyphs, w, h, dst, stages != 0, overlap, stream); break;
         default: rc = dispatchDistance<4>(b, dGlyphs, w, h, dst, stages != 0, overlap, stream); break;
     }
+    b->ecAheadWanted = NULL;                                     // (not taken: no side stream in this launch -- the correction pass launches k_ec_params itself)
     if (rc == MSDFHIP_OK && b->afterDistance)
         HIPCHK(hipEventRecord(b->afterDistance, stream));
     if (rc != MSDFHIP_OK || !stages)
