@@ -521,7 +521,7 @@ __device__ inline void selAddContour(Selector<SEL> &sel, const EdgeRec *rec, con
 // All S lanes of a candidate hold identical values afterwards and take identical branches; xor-shuffles below S never leave the (aligned) group, so
 // divergence BETWEEN candidates (second walks of the combiner) cannot make a lane read an inactive one.
 #ifndef MSDF_QGRID_ABLATE
-#define MSDF_QGRID_ABLATE 0                                         // measurement builds only (profiles/r06_ab_notes.md 12): 1 loads without evaluation, 2 one record for all lanes, 3 no items, 4 no distance query, 5 no loads / evaluation, 6 no shuffles either
+#define MSDF_QGRID_ABLATE 0                                         // measurement builds only (profiles/r06_ab_notes.md 12): 1 loads without evaluation, 2 one record for all lanes, 3 no items, 4 no distance query, 5 no loads / evaluation, 6 no shuffles either, 7 grid items only, 8 all but the grid items, 9 cooperative items without their query, 10 cooperative rounds without loads / evaluation
 #endif
 struct EdgesGrid {
     const int32_t *coff;
@@ -1062,8 +1062,12 @@ __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const
                 if (i < edges.nE) {
                     Selector<2> mine;
                     selInit(mine);
+#if MSDF_QGRID_ABLATE != 10                                         // (10, measurement only: cooperative rounds without loads / evaluation)
                     const EdgeRegs r = loadEdgeRegs(rec+i, i);
                     selAddEdge(mine, r, i, o);
+#else
+                    mine.c[0].td = o.x+i, mine.c[0].tdot = o.y;
+#endif
                     edges.slots[i] = mine.c[0];
                 }
             }
@@ -1099,8 +1103,12 @@ __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const
         selInit(mine);
         const int i = base+edges.lane;
         if (i < e) {
+#if MSDF_QGRID_ABLATE != 10
             const EdgeRegs r = loadEdgeRegs(rec+i, i);
             selAddEdge(mine, r, i, o);
+#else
+            mine.c[0].td = o.x+i, mine.c[0].tdot = o.y;
+#endif
         }
         PB &m = mine.c[0];
         MSDF_UNROLL
@@ -1133,6 +1141,9 @@ struct PsdfQueryCooperative {                                       // same quer
         for (int i = 0; i < 16; ++i)
             edges.prof[i] = 0;
         const unsigned long long qq0 = qNow();
+#endif
+#if MSDF_QGRID_ABLATE == 9                                          // measurement only: cooperative items without their distance query
+        return q.x+q.y;
 #endif
         if (slots)
             waveSync();                                             // the previous query's slot reads are done
@@ -1778,6 +1789,14 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
         const int gridS = ecQueryGridSlices(count, nE, C, lpcMaxContours);
 #if MSDF_QGRID_ABLATE == 3                                          // measurement only: ticket, lookup and glyph state of every item, nothing else
         if (count != 0xffffffffu)
+            continue;
+#endif
+#if MSDF_QGRID_ABLATE == 7                                          // measurement only: the grid items alone (no cooperative, no lane-per-candidate items)
+        if (!gridS)
+            continue;
+#endif
+#if MSDF_QGRID_ABLATE == 8                                          // measurement only: without the grid items
+        if (gridS)
             continue;
 #endif
         if (gridS) {                                                // lanes = (candidate, slice): 64 / gridS candidates per item
