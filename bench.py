@@ -134,6 +134,33 @@ def strong_scaling_one_gpu(M, torch, lib, dev, stream, cfg, steps=6, parts=(2, 4
     return res
 
 
+def two_batches_in_flight(M, torch, dev, batch, xfs, w, h, cfg, steps):
+    """Supplementary, NOT `value`: the same step with TWO batch objects (inputs, outputs and scratch of their own) on two streams, steps alternating -- step k+1's
+    digest and distance pass start under step k's tail (the distance checks' launch and the stream joins leave part of the device idle). What an atlas service
+    that renders batch after batch would see; every step still does all of its work on its own buffers. tools/r06_overlap.py is the experiment behind it."""
+    parts = []
+    for _ in range(2):
+        gb = M.GlyphBatch(batch, dev)
+        parts.append((gb, gb.descriptors(xfs, w, h, 3), torch.empty((batch.n_glyphs, h, w, 3), dtype=torch.float32, device=dev), torch.cuda.Stream(dev)))
+
+    def run(n):
+        for k in range(n):
+            gb, desc, out, s = parts[k % 2]
+            gb.digest(s)
+            gb.generate(M.MODE_MSDF, w, h, descriptors=desc, out=out, stream=s, config=cfg)
+    run(4)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize(dev)
+    ms = 1e3*(time.perf_counter()-t0)/steps
+    same = bool((parts[0][2] == parts[1][2]).all())
+    for gb, _, _, _ in parts:
+        gb.close()
+    return {"ms_per_step": ms, "glyphs_per_s": batch.n_glyphs/ms*1e3, "steps": steps, "tiles_of_the_two_batches_identical": same,
+            "note": "supplementary (not `value`): two batch objects on two streams, steps alternating, so that a step's low-occupancy tail overlaps the next step's start"}
+
+
 def algorithmic_bytes(batch, w, h, n):
     """per glyph W*H*N*4 (texels written once) + 72*E (each edge read once) + 48 (transform, mapping, dims)."""
     return batch.n_glyphs*(w*h*n*4+48)+72*batch.n_edges
@@ -678,6 +705,7 @@ def main():
             "note": "the 8-bit atlas (pixelFloatToByte on the device, a quarter of the D2H bytes) is what an atlas tool consumes; the float path is PCIe bound "
                     "(%d MB D2H). `value` above is the HBM-resident step as the bench contract asks" % (e2e["float_tiles"]["d2h_bytes"]//1000000)}
         res["strong_scaling"] = strong_scaling_one_gpu(M, torch, lib, dev, stream, cfg, steps=max(3, args.steps//6))
+        res["two_batches_in_flight"] = two_batches_in_flight(M, torch, dev, batch, xfs, w, h, cfg, max(6, args.steps))
         res["secondary"] = {"workload": "round 1's bench workload: DejaVuSans Basic-Latin (94 prepared shapes, 15.6 edges / 1.41 contours per glyph) tiled to %d glyphs" % args.glyphs,
                             "glyphs_per_s": args.glyphs*max(5, args.steps//3)/e2, "kernel_ms": {"distance": d2, "error_correction": c2}}
         g2.close()
