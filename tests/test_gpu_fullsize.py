@@ -69,6 +69,20 @@ def test_config4_dejavu_8192_every_tile(dejavu, oracle, size):
     print("config 4 %dx%d: %d of 8192 tiles differ bitwise from the compiled reference" % (size, size, nbad))
 
 
+def test_batch_of_more_than_8192_glyphs_every_tile(dejavu):
+    """One device batch of 10 000 glyphs (the 8 192 distinct ones in reverse order + the first 1 808 again) at 48x48: k_ec_scan's work list takes a second round of its
+    1 024 x 8 positions, the distance checks' statically dealt first tickets and eight ticket counters (round 6) cover a list longer than one round -- every tile against
+    the compiled reference's hash of its glyph."""
+    batch, z = dejavu
+    idx = list(range(8191, -1, -1))+list(range(1808))
+    sub, xfs = batch.select(idx), z["xf48"][idx]
+    gb = M.GlyphBatch(sub)
+    tiles = gb.generate(M.MODE_MSDF, 48, 48, xfs).cpu().numpy()
+    gb.close()
+    bad = [k for k, g in enumerate(idx) if not (sha(tiles[k]) == z["sha48"][g]).all()]
+    assert not bad, "%d of %d tiles differ from the reference bitwise (first: %s)" % (len(bad), len(idx), bad[:8])
+
+
 @pytest.mark.parametrize("tag,mode,size", [("mtsdf64", 4, 64), ("sdf48", 1, 48), ("psdf48", 2, 48)])
 def test_dejavu_8192_every_tile_other_field_types(dejavu, oracle, tag, mode, size):
     """The other three generators on the 8 192 distinct glyphs (config 3's mtsdf on the tail of a real font; sdf; psdf): every tile against
