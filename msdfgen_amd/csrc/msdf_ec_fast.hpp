@@ -114,10 +114,16 @@ template <class Sink>
 MSDF_HD int diagonalPairFast(const FastCtx &cx, float am, float dm, const float *a, const float *l, const float *q,
                              float dA, float dBC, float dD, float l0, float q0, float l1, float q1, Sink &sink) {
     const double qa = dD-dBC+dA, qb = dBC-dA-dA, qc = dA;   // float expressions promoted, exactly as passed at :295
+#if defined(MSDF_EC_ABLATE) && MSDF_EC_ABLATE == 7                       // measurement only: the diagonal pairs up to the root-range test (a result the compiler cannot fold)
+    return quadraticMayHaveRootInRange(qa, qb, qc) ? (qa == 0.12345678 ? 1 : 0) : (qb == 0.12345678 ? 1 : 0);
+#endif
     if (!quadraticMayHaveRootInRange(qa, qb, qc))
         return 0;
     double t[2];
     const int solutions = solveQuadratic(t, qa, qb, qc);
+#if defined(MSDF_EC_ABLATE) && MSDF_EC_ABLATE == 8                       // measurement only: ... up to solveQuadratic
+    return solutions >= 1 && t[0] == 1.2345e300 ? 1 : 0;
+#endif
     int verdict = 0;
     for (int i = 0; i < solutions; ++i) {
         if (t[i] > MSDF_ARTIFACT_T_EPSILON && t[i] < 1-MSDF_ARTIFACT_T_EPSILON) {
@@ -303,6 +309,14 @@ MSDF_HD int evaluatePair(const float *c, const float *n, const float *hb, const 
     const int dx = ecNeighbourDx(k), dy = ecNeighbourDy(k);
     const int i0 = j, i1 = j == 2 ? 0 : j+1;
     const float cm = medianf(c[0], c[1], c[2]), nm = medianf(n[0], n[1], n[2]);
+#if defined(MSDF_EC_ABLATE) && MSDF_EC_ABLATE == 5                       // measurement only: stage 2 without the linear pairs
+    if (k < 4)
+        return 0;
+#endif
+#if defined(MSDF_EC_ABLATE) && MSDF_EC_ABLATE == 6                       // measurement only: stage 2 without the diagonal pairs
+    if (k >= 4)
+        return 0;
+#endif
     if (k < 4) {
         cx.span = dy == 0 ? p.hSpan : p.vSpan;
         const float dA = pick3(c, i1)-pick3(c, i0), dB = pick3(n, i1)-pick3(n, i0);
