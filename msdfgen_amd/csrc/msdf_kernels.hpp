@@ -1030,6 +1030,8 @@ struct EdgesCooperative {
     PBSlot *slots;                      // LDS: one slot per edge of the glyph, or NULL (glyph too large: per-contour lane merge instead)
     PBSlot *merged;                     // LDS: one slot per contour (the contour's edges merged in visit order), valid with slots
     int nE, C;
+    mutable unsigned long long cached;  // (no slots) contours whose merged state already sits in merged[c]: the combiner's second walks do not evaluate a contour's edges again
+    int cacheCap;                       // contours merged[] has room for in that case (0: no caching)
 #if defined(MSDF_PROFILE_QUERY)
     mutable unsigned long long prof[16]; // [8] contour walks of pass 0 [9] bookkeeping [10] second walks [11] epilogue | [0] all-edge evaluation [1] per-contour slot merges
 #endif
@@ -1097,6 +1099,16 @@ __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const
         pbMerge(sel.c[0], whole);
         return;
     }
+    // A glyph without slots walks a contour in rounds of 64 edges -- and walked it AGAIN in every second walk of the combiner (members of the inner / outer selector,
+    // contour-combiners.cpp:88-93): the contour's merged state is kept in merged[c] after the first walk (round 6; wave-uniform query point, so one bit per contour).
+    const bool cacheable = c < 64 && c < edges.cacheCap;
+    if (cacheable && ((edges.cached>>c)&1ull)) {
+        const PBSlot whole = edges.merged[c];
+        pbMerge(sel.c[0], whole);
+        return;
+    }
+    PB contour;
+    pbInit(contour);
     const int e = edges.end(c);
     for (int base = edges.begin(c); base < e; base += WAVE) {
         Selector<2> mine;
@@ -1121,7 +1133,13 @@ __device__ inline void selAddContour(Selector<2> &sel, const EdgeRec *rec, const
         }
         PB all;                                                     // lane 0 holds the chunk's state: broadcast
         all.td = __shfl(m.td, 0), all.tdot = __shfl(m.tdot, 0), all.perp = __shfl(m.perp, 0), all.neg = __shfl(m.neg, 0), all.pos = __shfl(m.pos, 0);
-        pbMerge(sel.c[0], all);                                     // chunks in order; the running state is the earlier one
+        pbMerge(contour, all);                                      // chunks in order; the running state is the earlier one
+    }
+    pbMerge(sel.c[0], contour);                                     // (merge(sel, merge(chunks in order)) == the sequential merges: the earlier state survives ties either way)
+    if (cacheable) {
+        edges.merged[c] = contour;
+        edges.cached |= 1ull<<c;
+        waveSync();
     }
 }
 
@@ -1133,10 +1151,12 @@ struct PsdfQueryCooperative {                                       // same quer
     int C, lane;
     double *res;
     PBSlot *slots, *merged;
+    int cacheCap = 0;                                               // contours merged[] holds when the glyph has no slots (k_ec_query: the launch's mergedCap)
     __device__ double operator()(V2 q) const {
         double out[1];
         EdgesCooperative edges;
         edges.coff = coff, edges.lane = lane, edges.slots = slots, edges.merged = merged, edges.nE = coff[C]-coff[0], edges.C = C;
+        edges.cached = 0, edges.cacheCap = slots ? 0 : cacheCap;
 #if defined(MSDF_PROFILE_QUERY)
         for (int i = 0; i < 16; ++i)
             edges.prof[i] = 0;
@@ -1850,6 +1870,7 @@ k_ec_query(int nGlyphs, const int32_t *__restrict__ glyphContourOffsets, const i
             // glyph takes the other path too.
             query.slots = nE <= slotCap && C <= slotCap ? slotBuf : NULL;
             query.merged = slotBuf+slotCap;
+            query.cacheCap = OVERLAP ? (slotCap < slotOffset ? slotCap : slotOffset) : 0;   // (= mergedCap of the launch, msdf_capi.hip: launchEc)
             const size_t texel = cand.texel;
             const int rem = (int) (texel-(size_t) g*texelsPerGlyph);
             const int yn = rem/width, x = rem%width;
